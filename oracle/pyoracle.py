@@ -1,0 +1,344 @@
+"""TEST INFRASTRUCTURE ONLY -- ctypes front-end for the two CPU checkers declared in oracle/oracle_abi.h.
+
+    Oracle("port")       -> oracle/libtutu_oracle.so   (our CPU restatement)
+    Oracle("reference")  -> oracle/_ref/libtutu_ref.so (the reference's own code behind the same ABI)
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIBS = {
+    "port": os.path.join(HERE, "libtutu_oracle.so"),
+    "reference": os.path.join(HERE, "_ref", "libtutu_ref.so"),
+}
+
+MAT_DTYPE = np.dtype(
+    [
+        ("diffuse", "<f4", 3),
+        ("specular", "<f4", 3),
+        ("emission", "<f4", 3),
+        ("type", "<i4"),
+        ("alpha", "<f4"),
+        ("eta", "<f4"),
+        ("roughness", "<f4"),
+        ("metallic", "<f4"),
+    ]
+)
+assert MAT_DTYPE.itemsize == 56
+
+LAMBERTIAN, PERFECT_REFLECTIVE, PERFECT_REFRACTIVE, MICROFACET_R, MICROFACET_T, UNLIT = range(6)
+
+
+def make_material(type=LAMBERTIAN, diffuse=(0.9, 0.9, 0.9), emission=(0, 0, 0), alpha=1.0, eta=1.0, roughness=1.0,
+                  metallic=0.0, specular=(1, 1, 1)):
+    """Defaults = the reference's Material member initialisers (Material.hpp:21-30)."""
+    m = np.zeros((), dtype=MAT_DTYPE)
+    m["diffuse"] = diffuse
+    m["specular"] = specular
+    m["emission"] = emission
+    m["type"] = type
+    m["alpha"] = alpha
+    m["eta"] = eta
+    m["roughness"] = roughness
+    m["metallic"] = metallic
+    return m
+
+
+class _SceneDesc(C.Structure):
+    _fields_ = [
+        ("n_tris", C.c_int32),
+        ("verts", C.c_void_p),
+        ("normals", C.c_void_p),
+        ("mat_id", C.c_void_p),
+        ("n_mats", C.c_int32),
+        ("mats", C.c_void_p),
+        ("eta", C.c_float),
+        ("bkg", C.c_float * 3),
+        ("width", C.c_int32),
+        ("height", C.c_int32),
+        ("eye", C.c_float * 3),
+        ("viewdir", C.c_float * 3),
+        ("updir", C.c_float * 3),
+        ("hfov", C.c_int32),
+    ]
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def available(kind):
+    return os.path.exists(LIBS[kind])
+
+
+class Oracle:
+    def __init__(self, kind="port"):
+        path = LIBS[kind]
+        if not os.path.exists(path):
+            raise FileNotFoundError(f"{path} is not built (run `make -C oracle`)")
+        self.kind = kind
+        self.lib = C.CDLL(path)
+        self.lib.tor_kind.restype = C.c_char_p
+        assert self.lib.tor_kind().decode() == kind
+
+    # ---------------------------------------------------------------- RNG
+    def philox(self, ctr4, key0, key1):
+        ctr4 = np.ascontiguousarray(ctr4, dtype=np.uint32).reshape(-1, 4)
+        out = np.empty_like(ctr4)
+        self.lib.tor_philox4x32_10(C.c_int(len(ctr4)), _p(ctr4), C.c_uint32(key0), C.c_uint32(key1), _p(out))
+        return out
+
+    def rng_stream(self, pix, smp, key0, key1, n):
+        xi = np.empty(n, np.float32)
+        self.lib.tor_rng_stream(C.c_uint32(pix), C.c_uint32(smp), C.c_uint32(key0), C.c_uint32(key1), C.c_int(n), _p(xi))
+        return xi
+
+    # ---------------------------------------------------------------- pure functions
+    def bbox_intersect(self, pmin, pmax, o, d):
+        pmin, pmax, o, d = map(_f32, (pmin, pmax, o, d))
+        n = len(o)
+        hit = np.empty(n, np.uint8)
+        self.lib.tor_bbox_intersect(C.c_int(n), _p(pmin), _p(pmax), _p(o), _p(d), _p(hit))
+        return hit
+
+    def tri_intersect(self, verts9, normals9, o, d):
+        verts9, normals9, o, d = map(_f32, (verts9, normals9, o, d))
+        n = len(o)
+        hit = np.empty(n, np.uint8)
+        t = np.empty(n, np.float32)
+        pos = np.empty((n, 3), np.float32)
+        Ns = np.empty((n, 3), np.float32)
+        Ng = np.empty((n, 3), np.float32)
+        self.lib.tor_tri_intersect(C.c_int(n), _p(verts9), _p(normals9), _p(o), _p(d), _p(hit), _p(t), _p(pos), _p(Ns), _p(Ng))
+        return hit, t, pos, Ns, Ng
+
+    def tri_area(self, verts9):
+        verts9 = _f32(verts9).reshape(-1, 9)
+        out = np.empty(len(verts9), np.float32)
+        self.lib.tor_tri_area(C.c_int(len(verts9)), _p(verts9), _p(out))
+        return out
+
+    def _vec1(self, fn, *arrs, out_cols=3):
+        arrs = [_f32(a) for a in arrs]
+        n = len(arrs[0])
+        out = np.empty((n, 3), np.float32) if out_cols == 3 else np.empty(n, np.float32)
+        fn(C.c_int(n), *[_p(a) for a in arrs], _p(out))
+        return out
+
+    def normalized(self, v):
+        return self._vec1(self.lib.tor_math_normalized, v)
+
+    def fresnel(self, I, N, eta_i, eta_t):
+        return self._vec1(self.lib.tor_math_fresnel, I, N, eta_i, eta_t, out_cols=1)
+
+    def fresnel_schlick(self, cos_theta, F0):
+        return self._vec1(self.lib.tor_math_fresnel_schlick, cos_theta, F0)
+
+    def reflect(self, I, N):
+        return self._vec1(self.lib.tor_math_reflect, I, N)
+
+    def refract(self, I, N, eta_i, eta_t):
+        return self._vec1(self.lib.tor_math_refract, I, N, eta_i, eta_t)
+
+    def D(self, h, nrm, rough):
+        return self._vec1(self.lib.tor_math_D, h, nrm, rough, out_cols=1)
+
+    def G(self, wi, wo, nrm, rough, h):
+        return self._vec1(self.lib.tor_math_G, wi, wo, nrm, rough, h, out_cols=1)
+
+    def mis(self, a, b):
+        return self._vec1(self.lib.tor_math_mis, a, b, out_cols=1)
+
+    def local2world(self, N, d):
+        return self._vec1(self.lib.tor_math_local2world, N, d)
+
+    def write_pixel(self, c):
+        c = _f32(c).ravel()
+        out = np.empty(len(c), np.int32)
+        self.lib.tor_write_pixel(C.c_int(len(c)), _p(c), _p(out))
+        return out
+
+    # ---------------------------------------------------------------- material
+    def mat_bxdf(self, mat, wi, wo, Ng, Ns, eta_scene=1.0, tir=None):
+        wi, wo, Ng, Ns = map(_f32, (wi, wo, Ng, Ns))
+        n = len(wi)
+        m = np.ascontiguousarray(mat, dtype=MAT_DTYPE)
+        out = np.empty((n, 3), np.float32)
+        tirp = None
+        if tir is not None:
+            tir = np.ascontiguousarray(tir, dtype=np.uint8)
+            tirp = _p(tir)
+        self.lib.tor_mat_bxdf(C.c_int(n), _p(m), _p(wi), _p(wo), _p(Ng), _p(Ns), C.c_float(eta_scene), tirp, _p(out))
+        return out
+
+    def mat_pdf(self, mat, wi, wo, N, eta_i=1.0, eta_t=None):
+        wi, wo, N = map(_f32, (wi, wo, N))
+        n = len(wi)
+        m = np.ascontiguousarray(mat, dtype=MAT_DTYPE)
+        if eta_t is None:
+            eta_t = float(m["eta"])
+        out = np.empty(n, np.float32)
+        self.lib.tor_mat_pdf(C.c_int(n), _p(m), _p(wi), _p(wo), _p(N), C.c_float(eta_i), C.c_float(eta_t), _p(out))
+        return out
+
+    def mat_sample(self, mat, wo, N, xi3, eta_i=1.0):
+        wo, N, xi3 = map(_f32, (wo, N, xi3))
+        n = len(wo)
+        m = np.ascontiguousarray(mat, dtype=MAT_DTYPE)
+        wi = np.zeros((n, 3), np.float32)
+        ok = np.empty(n, np.uint8)
+        sp = np.empty(n, np.uint8)
+        nd = np.empty(n, np.int32)
+        self.lib.tor_mat_sample(C.c_int(n), _p(m), _p(wo), _p(N), C.c_float(eta_i), _p(xi3), _p(wi), _p(ok), _p(sp), _p(nd))
+        return wi, ok, sp, nd
+
+    # ---------------------------------------------------------------- scene
+    def scene(self, scene):
+        return OracleScene(self, scene)
+
+    def ref_load_obj(self, path, cap=200000):
+        assert self.kind == "reference"
+        v = np.zeros((cap, 9), np.float32)
+        nr = np.zeros((cap, 9), np.float32)
+        n = C.c_int32(0)
+        rc = self.lib.tor_ref_load_obj(path.encode(), C.c_int(cap), C.byref(n), _p(v), _p(nr))
+        if rc != 0:
+            return None
+        return v[: n.value].copy(), nr[: n.value].copy()
+
+
+class OracleScene:
+    """scene: dict with verts (n,9), normals (n,9), mat_id (n,), mats (MAT_DTYPE array), eta, bkg, width, height,
+    eye, viewdir, updir, hfov."""
+
+    def __init__(self, oracle, scene):
+        self.o = oracle
+        self.lib = oracle.lib
+        self.verts = _f32(scene["verts"]).reshape(-1, 9)
+        self.normals = _f32(scene["normals"]).reshape(-1, 9)
+        self.mat_id = np.ascontiguousarray(scene["mat_id"], dtype=np.int32)
+        self.mats = np.ascontiguousarray(scene["mats"], dtype=MAT_DTYPE)
+        self.W = int(scene["width"])
+        self.H = int(scene["height"])
+        d = _SceneDesc()
+        d.n_tris = len(self.verts)
+        d.verts = self.verts.ctypes.data
+        d.normals = self.normals.ctypes.data
+        d.mat_id = self.mat_id.ctypes.data
+        d.n_mats = len(self.mats)
+        d.mats = self.mats.ctypes.data
+        d.eta = float(scene.get("eta", 1.0))
+        d.bkg = (C.c_float * 3)(*[float(x) for x in scene.get("bkg", (0, 0, 0))])
+        d.width = self.W
+        d.height = self.H
+        d.eye = (C.c_float * 3)(*[float(x) for x in scene["eye"]])
+        d.viewdir = (C.c_float * 3)(*[float(x) for x in scene["viewdir"]])
+        d.updir = (C.c_float * 3)(*[float(x) for x in scene["updir"]])
+        d.hfov = int(scene["hfov"])
+        self.h = C.c_void_p()
+        rc = self.lib.tor_scene_create(C.byref(d), C.byref(self.h))
+        if rc != 0:
+            raise RuntimeError(f"tor_scene_create failed: {rc}")
+
+    def close(self):
+        if self.h:
+            self.lib.tor_scene_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def bvh_dump(self):
+        cap = 2 * len(self.verts) + 8
+        b = np.zeros((cap, 6), np.float32)
+        leaf = np.zeros(cap, np.int32)
+        n = C.c_int32(0)
+        self.lib.tor_scene_bvh_dump(self.h, C.c_int(cap), C.byref(n), _p(b), _p(leaf))
+        return b[: n.value].copy(), leaf[: n.value].copy()
+
+    def closest(self, o, d):
+        o, d = _f32(o), _f32(d)
+        n = len(o)
+        hit = np.empty(n, np.uint8)
+        t = np.empty(n, np.float32)
+        tri = np.empty(n, np.int32)
+        pos = np.empty((n, 3), np.float32)
+        Ns = np.empty((n, 3), np.float32)
+        Ng = np.empty((n, 3), np.float32)
+        self.lib.tor_scene_closest(self.h, C.c_int(n), _p(o), _p(d), _p(hit), _p(t), _p(tri), _p(pos), _p(Ns), _p(Ng))
+        return hit, t, tri, pos, Ns, Ng
+
+    def any_hit(self, orig, target):
+        orig, target = _f32(orig), _f32(target)
+        n = len(orig)
+        b = np.empty(n, np.uint8)
+        self.lib.tor_scene_any(self.h, C.c_int(n), _p(orig), _p(target), _p(b))
+        return b
+
+    def lights(self):
+        cap = len(self.verts)
+        tri = np.zeros(cap, np.int32)
+        n = C.c_int32(0)
+        self.lib.tor_scene_lights(self.h, C.c_int(cap), C.byref(n), _p(tri))
+        return tri[: n.value].copy()
+
+    def sample_light(self, xi3):
+        xi3 = _f32(xi3)
+        n = len(xi3)
+        tri = np.empty(n, np.int32)
+        pos = np.empty((n, 3), np.float32)
+        nrm = np.empty((n, 3), np.float32)
+        pdf = np.empty(n, np.float32)
+        self.lib.tor_scene_sample_light(self.h, C.c_int(n), _p(xi3), _p(tri), _p(pos), _p(nrm), _p(pdf))
+        return tri, pos, nrm, pdf
+
+    def light_pdf(self, tri):
+        tri = np.ascontiguousarray(tri, dtype=np.int32)
+        out = np.empty(len(tri), np.float32)
+        self.lib.tor_scene_light_pdf(self.h, C.c_int(len(tri)), _p(tri), _p(out))
+        return out
+
+    def camera(self):
+        out = np.empty(18, np.float32)
+        self.lib.tor_camera(self.h, _p(out))
+        return out.reshape(6, 3)
+
+    def raydir(self, px, py):
+        px = np.ascontiguousarray(px, dtype=np.int32)
+        py = np.ascontiguousarray(py, dtype=np.int32)
+        d = np.empty((len(px), 3), np.float32)
+        self.lib.tor_camera_raydir(self.h, C.c_int(len(px)), _p(px), _p(py), _p(d))
+        return d
+
+    def trace_samples(self, pix, smp, key0, key1, stats=False):
+        pix = np.ascontiguousarray(pix, dtype=np.uint32)
+        smp = np.ascontiguousarray(smp, dtype=np.uint32)
+        n = len(pix)
+        L = np.empty((n, 3), np.float32)
+        nd = np.empty(n, np.int32)
+        nc = np.empty(n, np.int32)
+        self.lib.tor_trace_samples(self.h, C.c_int(n), _p(pix), _p(smp), C.c_uint32(key0), C.c_uint32(key1), _p(L), _p(nd), _p(nc))
+        return (L, nd, nc) if stats else L
+
+    def render(self, spp, key0, key1, rect=None, nthreads=None):
+        if rect is None:
+            rect = (0, 0, self.W, self.H)
+        if nthreads is None:
+            nthreads = os.cpu_count() or 1
+        rgb = np.zeros((self.H, self.W, 3), np.float32)
+        rc = self.lib.tor_render(self.h, C.c_int(spp), C.c_uint32(key0), C.c_uint32(key1), C.c_int(rect[0]), C.c_int(rect[1]),
+                                 C.c_int(rect[2]), C.c_int(rect[3]), C.c_int(nthreads), _p(rgb))
+        if rc != 0:
+            raise RuntimeError(f"tor_render failed: {rc}")
+        return rgb
