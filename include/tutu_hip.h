@@ -1,0 +1,204 @@
+/* tutu_hip.h -- C ABI of the MI355X (gfx950) path-tracing integrator.
+ *
+ * This library is a drop-in for ONE path of bobhansky/TutuRenderer: what happens inside
+ *     IIntegrator::integrate(PPMGenerator* g)            (reference include/IIntegrator.hpp:17-24)
+ * when the integrator is PathTracing (include/PathTracing.hpp:352-516), i.e. the per-pixel / per-sample loop
+ * sub_render_pt -> PathTracing::traceRay -> BVH closest-hit / any-hit -> Material BxDF / sample / pdf.
+ * The reference has no process or device boundary anywhere; this header inserts one at that seam.  A host-side
+ * C++ mirror of the reference's Renderer / IIntegrator / Scene / PPMGenerator surface that calls these entry points
+ * lives in tuturenderer_amd/host/ (see INTEGRATION.md for the binding a maintainer of the reference would add).
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes, no C++/torch types.  Every function returns 0 (TUTU_OK) or a negative
+ *     TUTU_E_* code; nothing throws across the boundary; tutu_hip_error_string() names a code.
+ *   - The caller owns every host buffer it passes; the library copies what it needs during the call.  The library
+ *     owns all device memory behind the opaque TutuCtx.
+ *   - One host thread per context at a time (the reference's integrate() is not re-entrant either: globals SPP,
+ *     records -- global.hpp:19, IIntegrator.hpp:15).  A multi-GPU driver creates one context per device.
+ *   - All arithmetic is IEEE fp32 without FMA contraction, in the reference's expression order.
+ */
+#ifndef TUTU_HIP_H
+#define TUTU_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TUTU_OK 0
+#define TUTU_E_INVALID -1      /* bad argument (null pointer, negative size, index out of range) */
+#define TUTU_E_NO_DEVICE -2    /* no HIP device / device index out of range */
+#define TUTU_E_HIP -3          /* a HIP runtime call failed; see tutu_hip_last_error() */
+#define TUTU_E_OOM -4          /* device or host allocation failed */
+#define TUTU_E_BVH_DEPTH -5    /* BVH deeper than the traversal stack (TUTU_MAX_BVH_DEPTH) */
+#define TUTU_E_UNSUPPORTED -6  /* feature outside the PathTracing hot path (textures, spheres) */
+
+#define TUTU_MAX_BVH_DEPTH 30
+
+/* MaterialType, same order as reference Material.hpp:9-16 */
+enum TutuMaterialType {
+	TUTU_LAMBERTIAN = 0,
+	TUTU_PERFECT_REFLECTIVE = 1,
+	TUTU_PERFECT_REFRACTIVE = 2,
+	TUTU_MICROFACET_R = 3,
+	TUTU_MICROFACET_T = 4,
+	TUTU_UNLIT = 5
+};
+
+/* Same fields, order and size (56 B) as the reference's `class Material` data members (Material.hpp:21-30). */
+typedef struct TutuMaterial {
+	float diffuse[3];
+	float specular[3];
+	float emission[3];
+	int32_t type; /* TutuMaterialType */
+	float alpha;  /* opacity */
+	float eta;    /* index of refraction */
+	float roughness;
+	float metallic;
+} TutuMaterial;
+
+/* What Renderer::render() sees of the scene when it calls integrate(g): the triangle list of g->scene.objList in
+ * load order (PPMGenerator::loadObj, PPMGenerator.hpp:164-208), each triangle's Material, the scene IOR g->eta and
+ * g->bkgcolor.  Lights are not passed: like PPMGenerator::initializeLights (PPMGenerator.hpp:317-324) the library
+ * takes every triangle whose material has a non-zero emission, in list order. */
+typedef struct TutuSceneDesc {
+	uint32_t n_tris;
+	const float* verts;    /* n_tris*9: v0 v1 v2 (Triangle.hpp:11-14) */
+	const float* normals;  /* n_tris*9: n0 n1 n2, un-normalised allowed (Triangle.hpp:16) */
+	const int32_t* mat_id; /* n_tris: index into mats */
+	uint32_t n_mats;
+	const TutuMaterial* mats;
+	float eta;    /* g->eta: 4th number of the `bkgcolor` keyword */
+	float bkg[3]; /* g->bkgcolor */
+} TutuSceneDesc;
+
+/* The camera keywords of config.txt (imsize / eye / viewdir / hfov / updir; PPMGenerator.hpp:492-540). */
+typedef struct TutuCameraDesc {
+	int32_t width, height;
+	float eye[3], viewdir[3], updir[3];
+	int32_t hfov; /* integer degrees */
+} TutuCameraDesc;
+
+/* The six vectors PathTracing::integrate derives from the camera (PathTracing.hpp:357-391) and hands to its
+ * worker threads (Thread_arg_pt, PathTracing.hpp:13-23). */
+typedef struct TutuCameraFrame {
+	int32_t width, height;
+	float ul[3], delta_h[3], delta_v[3], c_off_h[3], c_off_v[3], eye[3];
+} TutuCameraFrame;
+
+typedef struct TutuRenderParams {
+	int32_t spp;         /* the reference's global `SPP` (global.hpp:19) */
+	uint32_t key0, key1; /* Philox4x32-10 key; draw k of sample s of pixel p = word k&3 of philox((p, s, k>>2, 0), key) */
+	/* Work list: either an explicit list of pixel indices (y*width+x), or, when pixels == NULL, the rectangle
+	 * [x0,x1) x [y0,y1) in row-major order.  Output i of the call belongs to work item i. */
+	const int32_t* pixels;
+	int32_t n_pixels;
+	int32_t x0, y0, x1, y1;
+	int32_t spp_per_pass; /* samples per pixel traced per wavefront pass; 0 = choose from max_paths */
+	int64_t max_paths;    /* cap on paths in flight per pass (device memory ~ 400 B each); 0 = default 16 Mi */
+} TutuRenderParams;
+
+typedef struct TutuStats {
+	uint64_t samples;      /* work items * spp */
+	uint64_t closest_rays; /* closest-hit rays traced (primary rays counted once per pixel, as traced) */
+	uint64_t shadow_rays;  /* any-hit rays traced */
+	uint64_t segments;     /* path vertices shaded */
+	uint32_t passes;
+	uint32_t trace_launches; /* launches of the closest-hit traversal kernel */
+	float ms_total;          /* device time of the whole call's kernels, HIP events on the library's stream */
+	float ms_trace_closest;  /* summed over launches */
+	float ms_trace_any;
+	float ms_shade;
+	float ms_other; /* primary rays, resolve, memsets */
+} TutuStats;
+
+typedef struct TutuHit {
+	float t;     /* FLT_MAX on a miss */
+	float b1;    /* barycentric weight of v1 */
+	float b2;    /* barycentric weight of v2 */
+	int32_t tri; /* index into the caller's triangle list, -1 on a miss */
+} TutuHit;
+
+/* Flattened BVH as the traversal kernels read it (host-side builder exposed for parity tests). */
+typedef struct TutuBvhInfo {
+	uint32_t n_tris;
+	uint32_t n_inner;    /* inner nodes (64 B each) */
+	uint32_t depth;      /* longest root-to-leaf path, in edges */
+	float root_bounds[6];
+} TutuBvhInfo;
+
+typedef struct TutuCtx TutuCtx;
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Host-only helpers (no GPU needed) */
+
+/* Camera::initialize (Camera.hpp:12-17,43-44) + the camera-frame lines of PathTracing::integrate
+ * (PathTracing.hpp:357-391). */
+int tutu_camera_frame(const TutuCameraDesc* cam, TutuCameraFrame* out);
+
+/* BVHAccel::recursiveBuild (BVH.hpp:47-123) over the triangle list: median split on the centroid along the
+ * longest axis, one triangle per leaf, same std::sort, same tie order.  Writes the tree in pre-order like the
+ * parity oracles do: bounds6[i] = pMin,pMax ; leaf_tri[i] = triangle index or -1 for an inner node.
+ * cap = capacity of the two arrays in nodes (2*n_tris-1 are needed). */
+int tutu_bvh_build_preorder(uint32_t n_tris, const float* verts, uint32_t cap, uint32_t* n_nodes, float* bounds6,
+                            int32_t* leaf_tri, TutuBvhInfo* info);
+
+const char* tutu_hip_error_string(int code);
+const char* tutu_hip_last_error(void); /* text of the last HIP failure on this thread */
+const char* tutu_hip_version(void);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Device entry points */
+
+int tutu_hip_device_count(int* count);
+
+/* Renderer::Renderer's scene set-up for this path (Renderer.hpp:35-54: Scene::initializeBVH) plus
+ * Renderer::render's g->initializeLights() (Renderer.hpp:64): builds the BVH on the host, flattens scene, lights
+ * and materials to linear arrays and uploads them to `device`. */
+int tutu_hip_create(const TutuSceneDesc* scene, int device, TutuCtx** out);
+int tutu_hip_destroy(TutuCtx* ctx);
+
+/* IIntegrator::integrate for PathTracing: out_rgb[i*3..] = linear radiance of work item i, exactly what
+ * sub_render_pt stores into g->cam.FrameBuffer.rgb (PathTracing.hpp:501-513): (1/spp) * sum over samples whose
+ * radiance has no NaN component.  out_rgb is a HOST pointer to n_items*3 floats. */
+int tutu_hip_render(TutuCtx* ctx, const TutuCameraFrame* cam, const TutuRenderParams* params, float* out_rgb,
+                    TutuStats* stats);
+
+/* Same, but out_rgb is a DEVICE pointer on ctx's device (e.g. a torch tensor's data_ptr); work is enqueued on
+ * `stream` (a hipStream_t, NULL = the context's own stream) and the call returns after the work is complete. */
+int tutu_hip_render_device(TutuCtx* ctx, const TutuCameraFrame* cam, const TutuRenderParams* params,
+                           float* d_out_rgb, void* stream, TutuStats* stats);
+
+/* Kernel-level entry points for parity tests.
+ * closest: BVHStrategy::UpdateInter -> getIntersection (BVHStrategy.hpp:8-11, BVH.hpp:145-167)
+ * any:     isShadowRayBlocked -> hasIntersection (IIntegrator.hpp:135-153, BVH.hpp:170-194): orig and the target
+ *          point (light position), blocked[i] = 1 when some triangle is hit with t < dist and |t-dist| >= 1e-4. */
+int tutu_hip_trace_closest(TutuCtx* ctx, uint32_t n, const float* orig, const float* dir, TutuHit* hits);
+int tutu_hip_trace_any(TutuCtx* ctx, uint32_t n, const float* orig, const float* target, uint8_t* blocked);
+
+/* Radiance of individual samples (pixel index, sample index) -- one PathTracing::traceRay(eye, dir, 0, 1) each
+ * (PathTracing.hpp:509), NaN samples returned as they are.  Runs the same wavefront pipeline as tutu_hip_render. */
+int tutu_hip_trace_samples(TutuCtx* ctx, const TutuCameraFrame* cam, uint32_t n, const uint32_t* pix,
+                           const uint32_t* smp, uint32_t key0, uint32_t key1, float* L3);
+
+/* Device evaluation of the material functions on arrays (one material, n evaluations), for function-level parity:
+ * Material::BxDF (Material.hpp:62-191), Material::pdf (:350-439), Material::sampleDirection (:200-343) with the
+ * three random numbers of each evaluation supplied by the caller. */
+int tutu_hip_eval_bxdf(TutuCtx* ctx, uint32_t n, const TutuMaterial* m, const float* wi, const float* wo,
+                       const float* Ng, const float* Ns, float eta_scene, const uint8_t* tir, float* out3);
+int tutu_hip_eval_pdf(TutuCtx* ctx, uint32_t n, const TutuMaterial* m, const float* wi, const float* wo,
+                      const float* N, float eta_i, float eta_t, float* out);
+int tutu_hip_eval_sample(TutuCtx* ctx, uint32_t n, const TutuMaterial* m, const float* wo, const float* N,
+                         float eta_i, const float* xi3, float* wi, uint8_t* ok, uint8_t* special, int32_t* ndraws);
+/* sampleLight (IIntegrator.hpp:173-192) + Triangle::samplePoint (Triangle.hpp:119-142) with supplied xi */
+int tutu_hip_eval_sample_light(TutuCtx* ctx, uint32_t n, const float* xi3, int32_t* tri, float* pos, float* nrm,
+                               float* pdf);
+
+/* scene facts */
+int tutu_hip_scene_info(TutuCtx* ctx, TutuBvhInfo* bvh, uint32_t* n_lights);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TUTU_HIP_H */

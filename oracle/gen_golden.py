@@ -1,0 +1,103 @@
+#!/usr/bin/env python3
+"""TEST INFRASTRUCTURE ONLY -- writes the golden vectors under tests/golden/ and the veach scene dump.
+
+Run in the build container (needs /root/reference and oracle/_ref/libtutu_ref.so):
+
+    make -C oracle && python oracle/gen_golden.py
+
+Every output stored here was produced by the REFERENCE'S OWN CODE (oracle/ref_harness.cpp compiled against
+/root/reference/include), on inputs regenerated from fixed seeds by oracle/parity_cases.py.  The files hold data
+only (arrays of inputs' checksums and expected outputs); nothing of the reference's source text is stored.
+"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from oracle import parity_cases as pc  # noqa: E402
+from oracle.pyoracle import (MICROFACET_R, MICROFACET_T, PERFECT_REFLECTIVE, PERFECT_REFRACTIVE, Oracle,  # noqa: E402
+                             make_material)
+from tuturenderer_amd import scenes  # noqa: E402
+
+REF_MODEL = "/root/reference/model"
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+def golden_scenes():
+    """name -> (scene dict, Philox key word 1).  Small images: the vectors are per-sample, not per-image."""
+    return {
+        "cornell": (lambda: scenes.cornell_box(96, 96), 1),
+        "cornell_ggxT_mirror": (lambda: scenes.cornell_box(
+            96, 96, tall=make_material(MICROFACET_T, (0.725, 0.71, 0.68), eta=1.5, roughness=0.2),
+            short=make_material(PERFECT_REFLECTIVE, (0.725, 0.71, 0.68))), 2),
+        "cornell_ggxR_glass": (lambda: scenes.cornell_box(
+            96, 96, tall=make_material(MICROFACET_R, (0.725, 0.71, 0.68), roughness=0.3, metallic=0.5),
+            short=make_material(PERFECT_REFRACTIVE, (0.725, 0.71, 0.68), eta=1.5)), 3),
+        "veach": (lambda: scenes.veach_room(96, 72, small_light=False), 5),
+        "veach_slight": (lambda: scenes.veach_room(96, 72, small_light=True), 6),
+    }
+
+
+def main():
+    R = Oracle("reference")
+    os.makedirs(GOLD, exist_ok=True)
+
+    # ---- scene data: the reference's own OBJ loading of its model files
+    obj = {}
+    for name, v in scenes.cornell_parts():
+        rv, rn = R.ref_load_obj(f"{REF_MODEL}/cornellBox/{name}.obj")
+        obj[f"cornell_{name}_verts"] = rv
+        obj[f"cornell_{name}_normals"] = rn
+    np.savez_compressed(os.path.join(GOLD, "obj_cornell.npz"), **obj)
+    veach = {}
+    for name in ["room", "Llight", "sLight", "table", "glass", "tallLamp", "wallLamp"]:
+        rv, rn = R.ref_load_obj(f"{REF_MODEL}/veach_bdpt/veach_{name}.obj")
+        veach[f"{name}_verts"] = rv
+        veach[f"{name}_normals"] = rn
+        print("veach", name, len(rv))
+    os.makedirs(scenes.DATA, exist_ok=True)
+    np.savez_compressed(os.path.join(scenes.DATA, "veach_room.npz"), **veach)
+
+    # ---- function-level vectors
+    fn = {}
+    for k, v in pc.run_bbox(R).items():
+        fn[f"bbox.{k}"] = v
+    for k, v in pc.run_tri(R).items():
+        fn[f"tri.{k}"] = v
+    for k, v in pc.run_math(R).items():
+        fn[f"math.{k}"] = v
+    for name, m in pc.material_set():
+        fn.update(pc.run_material(R, name, m))
+    # Philox known answers (Random123 kat_vectors) + the xi stream of one sample
+    fn["philox.ctr"] = np.array([[0, 0, 0, 0], [0xFFFFFFFF] * 4, [0x243F6A88, 0x85A308D3, 0x13198A2E, 0x03707344]], np.uint32)
+    fn["philox.key"] = np.array([[0, 0], [0xFFFFFFFF, 0xFFFFFFFF], [0xA4093822, 0x299F31D0]], np.uint32)
+    fn["philox.out"] = np.stack([R.philox(fn["philox.ctr"][i:i + 1], *[int(x) for x in fn["philox.key"][i]])[0] for i in range(3)])
+    fn["philox.stream"] = R.rng_stream(12345, 7, pc.KEY0, 2, 64)
+    np.savez_compressed(os.path.join(GOLD, "functions.npz"), **fn)
+
+    # ---- scene-level vectors + per-sample radiance
+    for name, (mk, key1) in golden_scenes().items():
+        sc = mk()
+        S = R.scene(sc)
+        out = {}
+        b, leaf = S.bvh_dump()
+        out["bvh.bounds"] = b
+        out["bvh.leaf_tri"] = leaf
+        for k, v in pc.run_scene(S).items():
+            out[f"scene.{k}"] = v
+        for k, v in pc.run_samples(S, key1).items():
+            out[f"samples.{k}"] = v
+        # a small full render (spp 16) for the image-level check
+        out["render.rgb"] = S.render(16, pc.KEY0, key1)
+        np.savez_compressed(os.path.join(GOLD, f"scene_{name}.npz"), **out)
+        L = out["samples.L"]
+        print(name, "tris", len(sc["verts"]), "nodes", len(leaf), "mean L", float(np.nanmean(L)), "nan", int(np.isnan(L).sum()),
+              "closest/sample", float(out["samples.nclosest"].mean()), "img mean", float(out["render.rgb"].mean()))
+        S.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,300 @@
+"""tuturenderer_amd -- MI355X-native path-tracing integrator, drop-in for TutuRenderer's PathTracing hot path.
+
+Python front-end over the C ABI of include/tutu_hip.h (tuturenderer_amd/libtutu_hip.so, hand-written HIP for
+gfx950).  There is no CPU fallback: if the library is not built, or no GPU is present, the calls raise.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import scenes  # noqa: F401
+from .scenes import MAT_DTYPE
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libtutu_hip.so")
+
+# every symbol include/tutu_hip.h declares
+ABI_SYMBOLS = [
+    "tutu_camera_frame", "tutu_bvh_build_preorder", "tutu_hip_error_string", "tutu_hip_last_error", "tutu_hip_version",
+    "tutu_hip_device_count", "tutu_hip_create", "tutu_hip_destroy", "tutu_hip_render", "tutu_hip_render_device",
+    "tutu_hip_trace_closest", "tutu_hip_trace_any", "tutu_hip_trace_samples", "tutu_hip_eval_bxdf", "tutu_hip_eval_pdf",
+    "tutu_hip_eval_sample", "tutu_hip_eval_sample_light", "tutu_hip_scene_info",
+]
+
+
+class TutuError(RuntimeError):
+    pass
+
+
+class SceneDesc(C.Structure):
+    _fields_ = [("n_tris", C.c_uint32), ("verts", C.c_void_p), ("normals", C.c_void_p), ("mat_id", C.c_void_p),
+                ("n_mats", C.c_uint32), ("mats", C.c_void_p), ("eta", C.c_float), ("bkg", C.c_float * 3)]
+
+
+class CameraDesc(C.Structure):
+    _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("eye", C.c_float * 3), ("viewdir", C.c_float * 3),
+                ("updir", C.c_float * 3), ("hfov", C.c_int32)]
+
+
+class CameraFrame(C.Structure):
+    _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("ul", C.c_float * 3), ("delta_h", C.c_float * 3),
+                ("delta_v", C.c_float * 3), ("c_off_h", C.c_float * 3), ("c_off_v", C.c_float * 3), ("eye", C.c_float * 3)]
+
+
+class RenderParams(C.Structure):
+    _fields_ = [("spp", C.c_int32), ("key0", C.c_uint32), ("key1", C.c_uint32), ("pixels", C.c_void_p),
+                ("n_pixels", C.c_int32), ("x0", C.c_int32), ("y0", C.c_int32), ("x1", C.c_int32), ("y1", C.c_int32),
+                ("spp_per_pass", C.c_int32), ("max_paths", C.c_int64)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("samples", C.c_uint64), ("closest_rays", C.c_uint64), ("shadow_rays", C.c_uint64), ("segments", C.c_uint64),
+                ("passes", C.c_uint32), ("trace_launches", C.c_uint32), ("ms_total", C.c_float), ("ms_trace_closest", C.c_float),
+                ("ms_trace_any", C.c_float), ("ms_shade", C.c_float), ("ms_other", C.c_float)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+class BvhInfo(C.Structure):
+    _fields_ = [("n_tris", C.c_uint32), ("n_inner", C.c_uint32), ("depth", C.c_uint32), ("root_bounds", C.c_float * 6)]
+
+
+HIT_DTYPE = np.dtype([("t", "<f4"), ("b1", "<f4"), ("b2", "<f4"), ("tri", "<i4")])
+
+_lib = None
+
+
+def load_library():
+    """dlopen the product library and check that it exports the whole ABI.  Raises if it is missing: there is
+    no fallback path."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise TutuError(f"{LIB_PATH} is not built -- run `make -C tuturenderer_amd/csrc` (hipcc, gfx950). "
+                        "There is no CPU fallback for the render path.")
+    lib = C.CDLL(LIB_PATH)
+    missing = [s for s in ABI_SYMBOLS if not hasattr(lib, s)]
+    if missing:
+        raise TutuError(f"{LIB_PATH} lacks ABI symbols: {missing}")
+    lib.tutu_hip_error_string.restype = C.c_char_p
+    lib.tutu_hip_last_error.restype = C.c_char_p
+    lib.tutu_hip_version.restype = C.c_char_p
+    _lib = lib
+    return lib
+
+
+def _check(rc, what):
+    if rc != 0:
+        lib = load_library()
+        msg = lib.tutu_hip_error_string(rc).decode()
+        detail = lib.tutu_hip_last_error().decode()
+        raise TutuError(f"{what}: {msg} ({rc}) {detail}")
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def device_count():
+    lib = load_library()
+    n = C.c_int(0)
+    rc = lib.tutu_hip_device_count(C.byref(n))
+    return n.value if rc == 0 else 0
+
+
+def camera_frame(scene):
+    """tutu_camera_frame: Camera::initialize + the camera-frame lines of PathTracing::integrate."""
+    lib = load_library()
+    cd = CameraDesc()
+    cd.width, cd.height, cd.hfov = int(scene["width"]), int(scene["height"]), int(scene["hfov"])
+    cd.eye = (C.c_float * 3)(*[float(x) for x in scene["eye"]])
+    cd.viewdir = (C.c_float * 3)(*[float(x) for x in scene["viewdir"]])
+    cd.updir = (C.c_float * 3)(*[float(x) for x in scene["updir"]])
+    cf = CameraFrame()
+    _check(lib.tutu_camera_frame(C.byref(cd), C.byref(cf)), "tutu_camera_frame")
+    return cf
+
+
+def camera_frame_array(scene):
+    cf = camera_frame(scene)
+    return np.array([list(cf.ul), list(cf.delta_h), list(cf.delta_v), list(cf.c_off_h), list(cf.c_off_v), list(cf.eye)], np.float32)
+
+
+def bvh_build_preorder(verts):
+    """Host BVH build (same tree as BVHAccel::recursiveBuild); returns (bounds6, leaf_tri, info dict)."""
+    lib = load_library()
+    verts = _f32(verts).reshape(-1, 9)
+    n = len(verts)
+    cap = max(1, 2 * n)
+    b = np.zeros((cap, 6), np.float32)
+    leaf = np.zeros(cap, np.int32)
+    nn = C.c_uint32(0)
+    info = BvhInfo()
+    _check(lib.tutu_bvh_build_preorder(C.c_uint32(n), _p(verts), C.c_uint32(cap), C.byref(nn), _p(b), _p(leaf), C.byref(info)),
+           "tutu_bvh_build_preorder")
+    return b[: nn.value].copy(), leaf[: nn.value].copy(), {"n_tris": info.n_tris, "n_inner": info.n_inner, "depth": info.depth,
+                                                            "root_bounds": np.array(list(info.root_bounds), np.float32)}
+
+
+class Context:
+    """One scene on one GPU (TutuCtx).  `scene` is a dict as produced by tuturenderer_amd.scenes."""
+
+    def __init__(self, scene, device=0):
+        self.lib = load_library()
+        self.scene = scene
+        self.W, self.H = int(scene["width"]), int(scene["height"])
+        self._verts = _f32(scene["verts"]).reshape(-1, 9)
+        self._normals = _f32(scene["normals"]).reshape(-1, 9)
+        self._mat_id = np.ascontiguousarray(scene["mat_id"], dtype=np.int32)
+        self._mats = np.ascontiguousarray(scene["mats"], dtype=MAT_DTYPE)
+        d = SceneDesc()
+        d.n_tris = len(self._verts)
+        d.verts, d.normals, d.mat_id = self._verts.ctypes.data, self._normals.ctypes.data, self._mat_id.ctypes.data
+        d.n_mats = len(self._mats)
+        d.mats = self._mats.ctypes.data
+        d.eta = float(scene.get("eta", 1.0))
+        d.bkg = (C.c_float * 3)(*[float(x) for x in scene.get("bkg", (0, 0, 0))])
+        self.h = C.c_void_p()
+        _check(self.lib.tutu_hip_create(C.byref(d), C.c_int(device), C.byref(self.h)), "tutu_hip_create")
+        self.cam = camera_frame(scene)
+        self.device = device
+        self.last_stats = None
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.tutu_hip_destroy(self.h)
+            self.h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def info(self):
+        b = BvhInfo()
+        nl = C.c_uint32(0)
+        _check(self.lib.tutu_hip_scene_info(self.h, C.byref(b), C.byref(nl)), "tutu_hip_scene_info")
+        return {"n_tris": b.n_tris, "n_inner": b.n_inner, "depth": b.depth, "n_lights": nl.value}
+
+    def _params(self, spp, key0, key1, pixels, rect, spp_per_pass, max_paths):
+        rp = RenderParams()
+        rp.spp, rp.key0, rp.key1 = int(spp), int(key0), int(key1)
+        rp.spp_per_pass, rp.max_paths = int(spp_per_pass), int(max_paths)
+        keep = None
+        if pixels is not None:
+            keep = np.ascontiguousarray(pixels, dtype=np.int32)
+            rp.pixels, rp.n_pixels = keep.ctypes.data, len(keep)
+            n = len(keep)
+        else:
+            if rect is None:
+                rect = (0, 0, self.W, self.H)
+            rp.x0, rp.y0, rp.x1, rp.y1 = [int(v) for v in rect]
+            n = (rp.x1 - rp.x0) * (rp.y1 - rp.y0)
+        return rp, n, keep, rect
+
+    def render(self, spp, key0, key1, pixels=None, rect=None, spp_per_pass=0, max_paths=0, full_frame=True):
+        """IIntegrator::integrate.  Returns (H,W,3) float32 when full_frame (untouched pixels are 0), else the
+        compact (n,3) array of the work items."""
+        rp, n, keep, rect = self._params(spp, key0, key1, pixels, rect, spp_per_pass, max_paths)
+        out = np.zeros((n, 3), np.float32)
+        st = Stats()
+        _check(self.lib.tutu_hip_render(self.h, C.byref(self.cam), C.byref(rp), _p(out), C.byref(st)), "tutu_hip_render")
+        self.last_stats = st.as_dict()
+        if not full_frame:
+            return out
+        img = np.zeros((self.H * self.W, 3), np.float32)
+        if keep is not None:
+            img[keep] = out
+        else:
+            x0, y0, x1, y1 = rect
+            img.reshape(self.H, self.W, 3)[y0:y1, x0:x1] = out.reshape(y1 - y0, x1 - x0, 3)
+        return img.reshape(self.H, self.W, 3)
+
+    def render_device(self, d_out_ptr, spp, key0, key1, pixels=None, rect=None, spp_per_pass=0, max_paths=0, stream=None):
+        """Same, writing the compact (n,3) result to device memory at d_out_ptr (e.g. torch_tensor.data_ptr())."""
+        rp, n, keep, rect = self._params(spp, key0, key1, pixels, rect, spp_per_pass, max_paths)
+        st = Stats()
+        _check(self.lib.tutu_hip_render_device(self.h, C.byref(self.cam), C.byref(rp), C.c_void_p(d_out_ptr),
+                                               C.c_void_p(stream) if stream else None, C.byref(st)), "tutu_hip_render_device")
+        self.last_stats = st.as_dict()
+        return n
+
+    def trace_samples(self, pix, smp, key0, key1):
+        pix = np.ascontiguousarray(pix, dtype=np.uint32)
+        smp = np.ascontiguousarray(smp, dtype=np.uint32)
+        L = np.zeros((len(pix), 3), np.float32)
+        _check(self.lib.tutu_hip_trace_samples(self.h, C.byref(self.cam), C.c_uint32(len(pix)), _p(pix), _p(smp), C.c_uint32(key0),
+                                               C.c_uint32(key1), _p(L)), "tutu_hip_trace_samples")
+        return L
+
+    # ---- kernel-level entry points
+    def trace_closest(self, o, d):
+        o, d = _f32(o), _f32(d)
+        hits = np.zeros(len(o), HIT_DTYPE)
+        _check(self.lib.tutu_hip_trace_closest(self.h, C.c_uint32(len(o)), _p(o), _p(d), _p(hits)), "tutu_hip_trace_closest")
+        return hits
+
+    def trace_any(self, orig, target):
+        orig, target = _f32(orig), _f32(target)
+        b = np.zeros(len(orig), np.uint8)
+        _check(self.lib.tutu_hip_trace_any(self.h, C.c_uint32(len(orig)), _p(orig), _p(target), _p(b)), "tutu_hip_trace_any")
+        return b
+
+    def eval_bxdf(self, mat, wi, wo, Ng, Ns, eta_scene=1.0, tir=None):
+        wi, wo, Ng, Ns = map(_f32, (wi, wo, Ng, Ns))
+        m = np.ascontiguousarray(mat, dtype=MAT_DTYPE)
+        out = np.zeros((len(wi), 3), np.float32)
+        tirp = None
+        if tir is not None:
+            tir = np.ascontiguousarray(tir, dtype=np.uint8)
+            tirp = _p(tir)
+        _check(self.lib.tutu_hip_eval_bxdf(self.h, C.c_uint32(len(wi)), _p(m), _p(wi), _p(wo), _p(Ng), _p(Ns), C.c_float(eta_scene), tirp,
+                                           _p(out)), "tutu_hip_eval_bxdf")
+        return out
+
+    def eval_pdf(self, mat, wi, wo, N, eta_i=1.0, eta_t=None):
+        wi, wo, N = map(_f32, (wi, wo, N))
+        m = np.ascontiguousarray(mat, dtype=MAT_DTYPE)
+        if eta_t is None:
+            eta_t = float(m["eta"])
+        out = np.zeros(len(wi), np.float32)
+        _check(self.lib.tutu_hip_eval_pdf(self.h, C.c_uint32(len(wi)), _p(m), _p(wi), _p(wo), _p(N), C.c_float(eta_i), C.c_float(eta_t),
+                                          _p(out)), "tutu_hip_eval_pdf")
+        return out
+
+    def eval_sample(self, mat, wo, N, xi3, eta_i=1.0):
+        wo, N, xi3 = map(_f32, (wo, N, xi3))
+        m = np.ascontiguousarray(mat, dtype=MAT_DTYPE)
+        n = len(wo)
+        wi = np.zeros((n, 3), np.float32)
+        ok = np.zeros(n, np.uint8)
+        sp = np.zeros(n, np.uint8)
+        nd = np.zeros(n, np.int32)
+        _check(self.lib.tutu_hip_eval_sample(self.h, C.c_uint32(n), _p(m), _p(wo), _p(N), C.c_float(eta_i), _p(xi3), _p(wi), _p(ok), _p(sp),
+                                             _p(nd)), "tutu_hip_eval_sample")
+        return wi, ok, sp, nd
+
+    def eval_sample_light(self, xi3):
+        xi3 = _f32(xi3)
+        n = len(xi3)
+        tri = np.zeros(n, np.int32)
+        pos = np.zeros((n, 3), np.float32)
+        nrm = np.zeros((n, 3), np.float32)
+        pdf = np.zeros(n, np.float32)
+        _check(self.lib.tutu_hip_eval_sample_light(self.h, C.c_uint32(n), _p(xi3), _p(tri), _p(pos), _p(nrm), _p(pdf)),
+               "tutu_hip_eval_sample_light")
+        return tri, pos, nrm, pdf

@@ -1,0 +1,592 @@
+// Wavefront path-tracing pipeline on the device: path records, the shade stage (connect + vertex shading), the
+// traversal stages and the resolve.  Restates PathTracing::traceRay / calcForRefractive (PathTracing.hpp:80-279,
+// MIS branch) as a lock-step loop over path depth; every recursive return in the reference is multiplicative, so a
+// path carries its throughput `beta` forward and adds `beta * term` to its radiance as terms appear.
+//
+// One iteration d of the loop (host enqueues, no host sync inside a pass):
+//     shade(d)           connect vertex d-1 to the hit found for its BSDF ray (MIS-weighted emission or Russian
+//                        roulette), then shade vertex d: light sample -> shadow request, BSDF sample -> next ray
+//     trace_closest      extension rays of all surviving paths; writes the hit and files each path under the
+//                        material class of what it hit (sort by material)
+//     trace_any          shadow requests; an unblocked one adds its pre-multiplied contribution to the path
+//
+// HBM layout: a path record is 8 x 16 B in structure-of-arrays form (each field array is read/written as full
+// dwordx4 per lane, consecutive lanes -> consecutive 16 B).  Survivors are written compacted into the other of
+// two record buffers, so every stage reads and writes dense arrays; the only gather is shade's read of its
+// input through the per-class permutation.
+#pragma once
+#include "device_trace.h"
+
+namespace tutu {
+
+#define TUTU_NCLASS 8
+#define TUTU_CLASS_EMISSIVE 6
+#define TUTU_CLASS_MISS 7
+
+#define TUTU_FLAG_PREV_REFRACTIVE 1u  // vertex d-1 was PERFECT_REFRACTIVE / MICROFACET_T (calcForRefractive)
+#define TUTU_FLAG_PREV_MIRROR_PM1 2u  // vertex d-1 PERFECT_REFLECTIVE with mat_pdf == 1 (PathTracing.hpp:252-253)
+#define TUTU_FLAG_KILL 4u             // NEE hit the `r2*pdf < MIN_DIVISOR` early return (PathTracing.hpp:215)
+
+struct Queue {  // structure-of-arrays path records, capacity P each
+	float4* A;  // ray origin xyz | pixel index (RNG counter word 0)
+	float4* B;  // ray direction xyz (NOT normalised for mirror/refraction, as in the reference) | smp<<8 | draw
+	float4* C;  // hit: t, b1, b2 | triangle (leaf order, -1 miss)            -- written by trace_closest
+	float4* D;  // beta xyz | mat_pdf of the BSDF sample at the previous vertex
+	float4* E;  // tp xyz (the reference's Russian-roulette variable, NOT the throughput) | flags
+	float4* F;  // L xyz (radiance gathered so far) | unused
+	float4* G;  // position of the previous vertex xyz | path id within the pass
+	float4* H;  // f_r at the previous vertex xyz | |Ng.wi| there
+};
+
+struct Counters {  // one per depth, zeroed at pass start
+	uint32_t queue_n;   // records appended by shade(d)
+	uint32_t shadow_n;  // shadow requests appended by shade(d)
+	uint32_t cls[TUTU_NCLASS];
+	uint32_t pad[6];
+};
+
+struct Totals {  // accumulated over a render call
+	unsigned long long closest_rays, shadow_rays, segments, pad;
+};
+
+struct PassParams {
+	SceneDev sc;
+	uint32_t key0, key1;
+	int depth;
+	int npix;   // work items
+	int s0;     // first sample index of this pass
+	int cap;    // record capacity P
+	const float4* prim_dir;  // per item: primary direction xyz | pixel index
+	const float4* prim_hit;  // per item: t, b1, b2 | tri
+	const uint32_t* smp_list;  // optional: per item sample index (tutu_hip_trace_samples); then one sample per item
+	float eye[3];
+	Queue qin, qout;
+	float4* shadowq;  // 3 x float4 per request
+	float4* Lout;     // per path: final radiance xyz
+	uint32_t* perm;   // TUTU_NCLASS x cap
+	Counters* cnt_in;
+	Counters* cnt_out;
+	Totals* totals;
+};
+
+// wave-aggregated append: returns this lane's slot (valid when want)
+TUTU_DEV uint32_t wave_append(bool want, uint32_t* counter) {
+	const unsigned long long m = __ballot(want);
+	uint32_t slot = 0;
+	if (m) {
+		const int lane = __lane_id();
+		const int leader = __ffsll((long long)m) - 1;
+		uint32_t base = 0;
+		if (lane == leader) base = atomicAdd(counter, (uint32_t)__popcll(m));
+		base = (uint32_t)__shfl((int)base, leader);
+		slot = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+	}
+	return slot;
+}
+
+TUTU_DEV Mat load_mat(const SceneDev& sc, int id) {
+	const float4 a = sc.mats[4 * id + 0];
+	const float4 b = sc.mats[4 * id + 1];
+	const float4 c = sc.mats[4 * id + 2];
+	Mat m;
+	m.diffuse = mk(a.x, a.y, a.z);
+	m.type = __float_as_int(a.w);
+	m.emission = mk(b.x, b.y, b.z);
+	m.has_emission = __float_as_int(b.w);
+	m.alpha = c.x;
+	m.eta = c.y;
+	m.roughness = c.z;
+	m.metallic = c.w;
+	return m;
+}
+
+// sampleLight (IIntegrator.hpp:173-192) + Triangle::samplePoint (Triangle.hpp:119-142)
+struct LightSample {
+	V3 pos, N, emission;
+	float pdf;
+	int tri;
+};
+TUTU_DEV LightSample sample_light(const SceneDev& sc, Rng& rng) {
+	const int size = sc.n_lights;
+	int index = (int)(rng.next() * (size - 1) + 0.4999f);  // drawn even when size == 1; not uniform for size > 2 [sic]
+	if (size == 1) index = 0;
+	const float4 a = sc.lights[6 * index + 0];
+	const float4 b = sc.lights[6 * index + 1];
+	const float4 c = sc.lights[6 * index + 2];
+	const float4 d = sc.lights[6 * index + 3];
+	const float4 e = sc.lights[6 * index + 4];
+	const float4 f = sc.lights[6 * index + 5];
+	const V3 v0 = mk(a.x, a.y, a.z), v1 = mk(a.w, b.x, b.y), v2 = mk(b.z, b.w, c.x);
+	const V3 n0 = mk(c.y, c.z, c.w), n1 = mk(d.x, d.y, d.z), n2 = mk(d.w, e.x, e.y);
+	float u = rng.next();
+	float v = rng.next() * (1 - u);  // non-uniform over the triangle [sic]
+	LightSample s;
+	s.pos = (1 - u - v) * v0 + u * v1 + v * v2;
+	s.N = normalized((1 - u - v) * n0 + u * n1 + v * n2);
+	s.emission = mk(e.z, e.w, f.x);
+	s.pdf = f.y;
+	s.tri = __float_as_int(f.z);
+	return s;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// shade stage.  FIRST = depth 0: paths are created from the per-pixel primary hit (all spp of a pixel share one
+// primary ray -- there is no pixel jitter in the reference, PathTracing.hpp:503-509).
+template <bool FIRST>
+__global__ void __launch_bounds__(256) k_shade(PassParams pp) {
+	const SceneDev& sc = pp.sc;
+	const int lane = __lane_id();
+	const int depth = pp.depth;
+
+	// work decomposition: FIRST: grid (ceil(npix/256), samples) ; else: persistent, wave-sized chunks over the
+	// class-sorted permutation, class boundaries padded to a wave so that a wave sees one class
+	uint32_t cnt[TUTU_NCLASS];
+	uint32_t pref[TUTU_NCLASS + 1];
+	uint32_t total_chunks = 0;
+	if (!FIRST) {
+		pref[0] = 0;
+#pragma unroll
+		for (int c = 0; c < TUTU_NCLASS; c++) {
+			cnt[c] = pp.cnt_in->cls[c];
+			pref[c + 1] = pref[c] + ((cnt[c] + 63u) >> 6);
+		}
+		total_chunks = pref[TUTU_NCLASS];
+	}
+	const uint32_t wave_global = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+	const uint32_t n_waves = (gridDim.x * blockDim.x) >> 6;
+
+	for (uint32_t chunk = FIRST ? 0u : wave_global; FIRST ? (chunk == 0u) : (chunk < total_chunks); chunk += n_waves) {
+		bool act;
+		uint32_t idx = 0;
+		if (FIRST) {
+			idx = blockIdx.x * blockDim.x + threadIdx.x;  // work item
+			act = idx < (uint32_t)pp.npix;
+		} else {
+			int c = 0;
+#pragma unroll
+			for (int k = 1; k < TUTU_NCLASS; k++)
+				if (chunk >= pref[k]) c = k;
+			const uint32_t j = (chunk - pref[c]) * 64u + lane;
+			act = j < cnt[c];
+			if (act) idx = pp.perm[(size_t)c * pp.cap + j];
+		}
+
+		// ---- load the path
+		V3 o = mk1(0.f), d = mk1(0.f), beta = mk1(1.f), tp = mk1(1.f), L = mk1(0.f), prev_pos = mk1(0.f), fprev = mk1(0.f);
+		float t = FLT_MAX, b1 = 0.f, b2 = 0.f, pm = 0.f, cosprev = 0.f;
+		int tri = -1;
+		uint32_t pix = 0, smp = 0, draw = 0, flags = 0, path_id = 0;
+		if (act) {
+			if (FIRST) {
+				const float4 pd = pp.prim_dir[idx];
+				const float4 ph = pp.prim_hit[idx];
+				o = mk(pp.eye[0], pp.eye[1], pp.eye[2]);
+				d = mk(pd.x, pd.y, pd.z);
+				pix = __float_as_uint(pd.w);
+				t = ph.x; b1 = ph.y; b2 = ph.z; tri = __float_as_int(ph.w);
+				if (pp.smp_list) {
+					smp = pp.smp_list[idx];
+					path_id = idx;
+				} else {
+					smp = (uint32_t)pp.s0 + blockIdx.y;
+					path_id = blockIdx.y * (uint32_t)pp.npix + idx;
+				}
+			} else {
+				const float4 A = pp.qin.A[idx], B = pp.qin.B[idx], C = pp.qin.C[idx], D = pp.qin.D[idx];
+				const float4 E = pp.qin.E[idx], F = pp.qin.F[idx], G = pp.qin.G[idx], H = pp.qin.H[idx];
+				o = mk(A.x, A.y, A.z); pix = __float_as_uint(A.w);
+				d = mk(B.x, B.y, B.z);
+				const uint32_t sd = __float_as_uint(B.w);
+				smp = sd >> 8; draw = sd & 0xFFu;
+				t = C.x; b1 = C.y; b2 = C.z; tri = __float_as_int(C.w);
+				beta = mk(D.x, D.y, D.z); pm = D.w;
+				tp = mk(E.x, E.y, E.z); flags = __float_as_uint(E.w);
+				L = mk(F.x, F.y, F.z);
+				prev_pos = mk(G.x, G.y, G.z); path_id = __float_as_uint(G.w);
+				fprev = mk(H.x, H.y, H.z); cosprev = H.w;
+			}
+		}
+
+		Rng rng;
+		rng.init(pix, smp, draw, pp.key0, pp.key1);
+		const bool hit = tri >= 0;
+		bool fin = false;  // path ends here: write its radiance
+		bool go = act;     // proceed to shading of the vertex at `depth`
+
+		// hit-point data (Triangle.hpp:50-57)
+		V3 pos = mk1(0.f), Ns = mk1(0.f), Ng = mk1(0.f);
+		int mat_id = 0;
+		float hit_light_pdf = 0.f;
+		if (act && hit) {
+			const float4 s0 = sc.tri_shade[3 * tri + 0];
+			const float4 s1 = sc.tri_shade[3 * tri + 1];
+			const float4 s2 = sc.tri_shade[3 * tri + 2];
+			const float4 q2 = sc.tri_isect[3 * tri + 2];
+			const V3 n0 = mk(s0.x, s0.y, s0.z), n1 = mk(s0.w, s1.x, s1.y), n2 = mk(s1.z, s1.w, s2.x);
+			mat_id = __float_as_int(s2.y);
+			hit_light_pdf = s2.w;
+			pos = o + t * d;
+			Ns = normalized((n0 * (1 - b1 - b2)) + n1 * b1 + n2 * b2);
+			Ng = mk(q2.y, q2.z, q2.w);
+		}
+
+		// ---- connect: finish vertex depth-1 now that the hit of its BSDF ray is known (PathTracing.hpp:234-278)
+		if (act) {
+			if (FIRST) {
+				if (!hit) {  // :150
+					L = L + beta * mk(sc.bkg[0], sc.bkg[1], sc.bkg[2]);
+					fin = true;
+					go = false;
+				}
+			} else if (flags & TUTU_FLAG_KILL) {
+				fin = true;
+				go = false;
+			} else if (flags & TUTU_FLAG_PREV_REFRACTIVE) {
+				if (!hit) {  // :150 reached through calcForRefractive's recursive call
+					L = L + beta * mk(sc.bkg[0], sc.bkg[1], sc.bkg[2]);
+					fin = true;
+					go = false;
+				}
+			} else if (!hit) {  // :234 -- background is NOT added for secondary misses
+				fin = true;
+				go = false;
+			} else {
+				bool indirect = true;
+				if (hit_light_pdf) {  // getLightPdf > 0 (:239-240); non-zero test, as there
+					const V3 light_N = normalized(Ns);
+					const float cos_theta_prime = dot(light_N, -d);
+					if (!(cos_theta_prime <= 0)) {  // else: back of a light, falls into the indirect branch (:243-244)
+						indirect = false;
+						const float r2 = norm2(pos - prev_pos);
+						const float l_pdf_transformed = hit_light_pdf * r2 / cos_theta_prime;
+						float mis_weight_m = getMisWeight(pm, l_pdf_transformed);
+						if (flags & TUTU_FLAG_PREV_MIRROR_PM1) mis_weight_m = 1.f;
+						const Mat lm = load_mat(sc, mat_id);
+						if (!(pm < TUTU_MIN_DIVISOR)) L = L + beta * (mis_weight_m * lm.emission * fprev * cosprev / pm);
+						fin = true;
+						go = false;
+					}
+				}
+				if (indirect) {  // :264-277
+					tp = (depth - 1) > TUTU_MIN_DEPTH ? tp : mk1(1.f);
+					const float rr_prob = std_max(tp.x, std_max(tp.y, tp.z));
+					if (rng.next() > rr_prob) {
+						fin = true;
+						go = false;
+					} else {
+						const V3 coe = fprev * cosprev / (pm * rr_prob);
+						if (pm * rr_prob < TUTU_MIN_DIVISOR) {
+							fin = true;
+							go = false;
+						} else {
+							tp = tp * coe;
+							beta = beta * coe;
+						}
+					}
+				}
+			}
+			if (go && depth > TUTU_MAX_DEPTH) {  // :140 / :82
+				fin = true;
+				go = false;
+			}
+		}
+
+		// ---- shade the vertex at `depth`
+		bool has_next = false, has_shadow = false;
+		V3 n_o = mk1(0.f), n_d = mk1(0.f), n_f = mk1(0.f), sh_o = mk1(0.f), sh_t = mk1(0.f), sh_c = mk1(0.f);
+		float n_pm = 0.f, n_cos = 0.f;
+		uint32_t n_flags = 0, sh_flags = 0;
+		const unsigned long long seg_mask = __ballot(go);
+		if (go) {
+			Mat m = load_mat(sc, mat_id);  // per-hit copy, like Intersection::mtlcolor
+			const V3 wo = -d;
+			if (m.type == TUTU_PERFECT_REFRACTIVE || m.type == TUTU_MICROFACET_T) {
+				// calcForRefractive, PathTracing.hpp:80-134
+				float eta_i = sc.eta, eta_t = m.eta;
+				V3 wi = mk1(0.f);
+				bool ok, TIR;
+				sampleDirection(m, wo, Ns, wi, eta_i, rng, ok, TIR);
+				wi = normalized(wi);
+				float p = mat_pdf(m, wi, wo, Ns, eta_i, eta_t);
+				if (TIR) {
+					wi = normalized(getReflectionDir(wo, Ns));
+					p = 1;
+					if (m.type == TUTU_MICROFACET_T) {
+						V3 interNs = Ns;
+						if (dot(wo, Ng) < 0) {
+							float tmp = eta_i; eta_i = eta_t; eta_t = tmp;
+							interNs = -interNs;
+						}
+						const V3 h = normalized(wo + wi);
+						const float cosTheta = fabsf(dot(interNs, h));
+						wi = normalized(getReflectionDir(wo, h));
+						p = 1 * D_ndf(h, interNs, m.roughness) * cosTheta / (4.f * dot(wo, h));
+					}
+				}
+				const V3 f_r = BxDF(m, wi, wo, Ng, Ns, eta_i, TIR);
+				V3 rayOrig = pos;
+				float cosv = 0;
+				if (dot(wi, Ns) > 0) {
+					rayOrig = rayOrig + Ns * TUTU_EPSILON;
+					cosv = fabsf(dot(Ng, wi));
+				} else {
+					rayOrig = rayOrig - Ns * TUTU_EPSILON;
+					cosv = fabsf(dot(-Ng, wi));
+				}
+				// :128-133 -- the reference traces the continuation and then drops it when pdf < MIN_DIVISOR
+				if (p < TUTU_MIN_DIVISOR || depth + 1 > TUTU_MAX_DEPTH) {
+					fin = true;
+				} else {
+					beta = ((beta * cosv) * f_r) / p;
+					tp = mk1(1.f);
+					n_o = rayOrig;
+					n_d = wi;
+					n_flags = TUTU_FLAG_PREV_REFRACTIVE;
+					has_next = true;
+				}
+			} else if (m.type == TUTU_UNLIT) {  // :161
+				L = L + beta * m.diffuse;
+				fin = true;
+			} else if (m.has_emission) {  // :164-170
+				if (depth == 0) L = L + beta * m.emission;
+				fin = true;
+			} else {
+				// ---- light sampling, :180-219
+				if (sc.n_lights > 0) {
+					const LightSample ls = sample_light(sc, rng);
+					const bool rayInside = dot(Ns, wo) < 0;
+					V3 shadowRayOrig = pos;
+					V3 lightPos = ls.pos;
+					if (rayInside) shadowRayOrig = shadowRayOrig - Ns * TUTU_EPSILON;
+					else shadowRayOrig = shadowRayOrig + Ns * TUTU_EPSILON;
+					lightPos = lightPos + ls.N * TUTU_EPSILON;
+					V3 wi = ls.pos - pos;
+					const float r2 = norm2(wi);
+					wi = normalized(wi);
+					if (!(dot(wi, ls.N) > 0)) {
+						const float mpdf = mat_pdf(m, wi, wo, Ns, sc.eta, m.eta);
+						const V3 light_N = normalized(ls.N);
+						const float cos_theta_prime = dot(light_N, -wi);
+						if (!(cos_theta_prime <= 0)) {
+							const float cos_theta = fabsf(dot(Ng, wi));
+							const float pdfl = ls.pdf;
+							const float light_pdf = pdfl * r2 / cos_theta_prime;
+							const float mis_weight_l = getMisWeight(light_pdf, mpdf);
+							const V3 f_r = BxDF(m, wi, wo, Ng, Ns, sc.eta, false);
+							sh_o = shadowRayOrig;
+							sh_t = lightPos;
+							has_shadow = true;
+							if (r2 * pdfl < TUTU_MIN_DIVISOR) {
+								sh_flags = TUTU_FLAG_KILL;  // :215: an UNBLOCKED shadow ray ends the whole path here
+							} else {
+								sh_c = beta * (mis_weight_l * ls.emission * f_r * cos_theta * cos_theta_prime / (r2 * pdfl));
+							}
+						}
+					}
+				}
+				// ---- BSDF sampling, :222-233
+				V3 wi = mk1(0.f);
+				bool ok, special;
+				sampleDirection(m, wo, Ns, wi, sc.eta, rng, ok, special);
+				if (!ok) {
+					fin = true;  // :225-226
+				} else {
+					n_pm = mat_pdf(m, wi, wo, Ns, sc.eta, m.eta);
+					V3 rayOrig = pos;
+					if (dot(wi, Ns) < 0) rayOrig = rayOrig - Ns * TUTU_EPSILON;
+					else rayOrig = rayOrig + Ns * TUTU_EPSILON;
+					n_f = BxDF(m, wi, wo, Ng, Ns, sc.eta, false);
+					n_cos = fabsf(dot(Ng, wi));
+					n_o = rayOrig;
+					n_d = wi;
+					n_flags = (m.type == TUTU_PERFECT_REFLECTIVE && n_pm == 1.f) ? TUTU_FLAG_PREV_MIRROR_PM1 : 0u;
+					has_next = true;
+				}
+				if (has_shadow && (sh_flags & TUTU_FLAG_KILL) && !has_next) has_shadow = false;  // nothing left to kill
+			}
+		}
+
+		// ---- outputs (all lanes of the wave arrive here together)
+		const uint32_t slot = wave_append(has_next, &pp.cnt_out->queue_n);
+		const uint32_t sslot = wave_append(has_shadow, &pp.cnt_out->shadow_n);
+		if (has_next) {
+			pp.qout.A[slot] = make_float4(n_o.x, n_o.y, n_o.z, __uint_as_float(pix));
+			pp.qout.B[slot] = make_float4(n_d.x, n_d.y, n_d.z, __uint_as_float((smp << 8) | (rng.draw & 0xFFu)));
+			pp.qout.D[slot] = make_float4(beta.x, beta.y, beta.z, n_pm);
+			pp.qout.E[slot] = make_float4(tp.x, tp.y, tp.z, __uint_as_float(n_flags));
+			pp.qout.F[slot] = make_float4(L.x, L.y, L.z, 0.f);
+			pp.qout.G[slot] = make_float4(pos.x, pos.y, pos.z, __uint_as_float(path_id));
+			pp.qout.H[slot] = make_float4(n_f.x, n_f.y, n_f.z, n_cos);
+		}
+		if (has_shadow) {
+			const int dest = has_next ? (int)slot : ~(int)path_id;
+			pp.shadowq[3 * (size_t)sslot + 0] = make_float4(sh_o.x, sh_o.y, sh_o.z, sh_t.x);
+			pp.shadowq[3 * (size_t)sslot + 1] = make_float4(sh_t.y, sh_t.z, sh_c.x, sh_c.y);
+			pp.shadowq[3 * (size_t)sslot + 2] = make_float4(sh_c.z, __int_as_float(dest), __uint_as_float(sh_flags), 0.f);
+		}
+		if (fin) pp.Lout[path_id] = make_float4(L.x, L.y, L.z, 0.f);
+		if (seg_mask && lane == (__ffsll((long long)seg_mask) - 1)) atomicAdd(&pp.totals->segments, (unsigned long long)__popcll(seg_mask));
+		if (FIRST) break;
+	}
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// closest-hit stage over the records of q[0, n): writes C and files the record under its material class
+struct TraceParams {
+	SceneDev sc;
+	Queue q;
+	const uint32_t* n_ptr;  // device count of records
+	uint32_t* cls;          // TUTU_NCLASS class counters (zeroed)
+	uint32_t* perm;         // TUTU_NCLASS x cap
+	int cap;
+	Totals* totals;
+};
+
+__global__ void __launch_bounds__(256) k_trace_closest(TraceParams tp) {
+	__shared__ int stack[TUTU_STACK_DEPTH * 256];
+	const SceneDev& sc = tp.sc;
+	const uint32_t n = *tp.n_ptr;
+	const uint32_t n_pad = (n + 63u) & ~63u;
+	const int lane = __lane_id();
+	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_pad; i += gridDim.x * blockDim.x) {
+		const bool act = i < n;
+		int cls = -1;
+		if (act) {
+			const float4 A = tp.q.A[i], B = tp.q.B[i];
+			float t, u, v;
+			int tri;
+			trace_closest(sc, mk(A.x, A.y, A.z), mk(B.x, B.y, B.z), stack + threadIdx.x, 256, t, u, v, tri);
+			tp.q.C[i] = make_float4(t, u, v, __int_as_float(tri));
+			if (tri < 0) {
+				cls = TUTU_CLASS_MISS;
+			} else {
+				const int mat = __float_as_int(sc.tri_shade[3 * tri + 2].y);
+				const int type = __float_as_int(sc.mats[4 * mat + 0].w);
+				const int emis = __float_as_int(sc.mats[4 * mat + 1].w);
+				// refractive types are tested before emission in traceRay (PathTracing.hpp:152-170)
+				cls = (emis && type != TUTU_PERFECT_REFRACTIVE && type != TUTU_MICROFACET_T) ? TUTU_CLASS_EMISSIVE : type;
+				if (cls < 0 || cls > TUTU_CLASS_EMISSIVE) cls = TUTU_UNLIT;  // unknown enum values: filed with UNLIT, shaded by their own `default:` branches
+			}
+		}
+#pragma unroll
+		for (int c = 0; c < TUTU_NCLASS; c++) {
+			const bool mine = cls == c;
+			const uint32_t slot = wave_append(mine, &tp.cls[c]);
+			if (mine) tp.perm[(size_t)c * tp.cap + slot] = i;
+		}
+	}
+	if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&tp.totals->closest_rays, (unsigned long long)n);
+	(void)lane;
+}
+
+// any-hit stage over the shadow requests
+struct ShadowParams {
+	SceneDev sc;
+	const float4* shadowq;
+	const uint32_t* n_ptr;
+	Queue q;       // the record buffer the requests point into
+	float4* Lout;  // for requests of paths that already ended
+	Totals* totals;
+};
+
+__global__ void __launch_bounds__(256) k_trace_any(ShadowParams sp) {
+	__shared__ int stack[TUTU_STACK_DEPTH * 256];
+	const uint32_t n = *sp.n_ptr;
+	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+		const float4 e0 = sp.shadowq[3 * (size_t)i + 0];
+		const float4 e1 = sp.shadowq[3 * (size_t)i + 1];
+		const float4 e2 = sp.shadowq[3 * (size_t)i + 2];
+		const V3 so = mk(e0.x, e0.y, e0.z), lo = mk(e0.w, e1.x, e1.y), c = mk(e1.z, e1.w, e2.x);
+		const int dest = __float_as_int(e2.y);
+		const uint32_t fl = __float_as_uint(e2.z);
+		const bool blocked = trace_any(sp.sc, so, lo, stack + threadIdx.x, 256);
+		if (!blocked) {
+			if (fl & TUTU_FLAG_KILL) {
+				float4 E = sp.q.E[dest];
+				E.w = __uint_as_float(__float_as_uint(E.w) | TUTU_FLAG_KILL);
+				sp.q.E[dest] = E;
+			} else if (dest >= 0) {
+				float4 F = sp.q.F[dest];
+				F.x = F.x + c.x; F.y = F.y + c.y; F.z = F.z + c.z;
+				sp.q.F[dest] = F;
+			} else {
+				float4 F = sp.Lout[~dest];
+				F.x = F.x + c.x; F.y = F.y + c.y; F.z = F.z + c.z;
+				sp.Lout[~dest] = F;
+			}
+		}
+	}
+	if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&sp.totals->shadow_rays, (unsigned long long)n);
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// primary rays: one per work item (sub_render_pt, PathTracing.hpp:501-504; c_off_v twice, c_off_h unused [sic])
+struct PrimaryParams {
+	SceneDev sc;
+	TutuCameraFrame cam;
+	const int32_t* pixels;  // optional explicit list
+	const uint32_t* pix_list_u;  // optional (trace_samples): per item pixel index
+	int n;
+	int x0, y0, rect_w;
+	float4* prim_dir;
+	float4* prim_hit;
+	Totals* totals;
+};
+
+__global__ void __launch_bounds__(256) k_primary(PrimaryParams p) {
+	__shared__ int stack[TUTU_STACK_DEPTH * 256];
+	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < (uint32_t)p.n) {
+		int pix;
+		if (p.pix_list_u) pix = (int)p.pix_list_u[i];
+		else if (p.pixels) pix = p.pixels[i];
+		else pix = (p.y0 + (int)(i / (uint32_t)p.rect_w)) * p.cam.width + p.x0 + (int)(i % (uint32_t)p.rect_w);
+		const int x = pix % p.cam.width, y = pix / p.cam.width;
+		const V3 ul = ld3(p.cam.ul), dh = ld3(p.cam.delta_h), dv = ld3(p.cam.delta_v), cov = ld3(p.cam.c_off_v), eye = ld3(p.cam.eye);
+		const V3 pixelPos = ul + (float)x * dh + (float)y * dv + cov + cov;
+		const V3 rayDir = normalized((pixelPos - eye));
+		float t, u, v;
+		int tri;
+		trace_closest(p.sc, eye, rayDir, stack + threadIdx.x, 256, t, u, v, tri);
+		p.prim_dir[i] = make_float4(rayDir.x, rayDir.y, rayDir.z, __uint_as_float((uint32_t)pix));
+		p.prim_hit[i] = make_float4(t, u, v, __int_as_float(tri));
+	}
+	if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&p.totals->closest_rays, (unsigned long long)p.n);
+}
+
+// resolve: estimate += sample unless NaN, in sample order (PathTracing.hpp:507-513)
+__global__ void __launch_bounds__(256) k_resolve(const float4* Lout, float4* accum, int npix, int nsamples) {
+	const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+	if (p >= (uint32_t)npix) return;
+	float4 a = accum[p];
+	for (int s = 0; s < nsamples; s++) {
+		const float4 r = Lout[(size_t)s * npix + p];
+		if (!isnan(r.x) && !isnan(r.y) && !isnan(r.z)) {
+			a.x = a.x + r.x;
+			a.y = a.y + r.y;
+			a.z = a.z + r.z;
+		}
+	}
+	accum[p] = a;
+}
+
+// color = estimate * SPP_inv (PathTracing.hpp:513)
+__global__ void __launch_bounds__(256) k_finalize(const float4* accum, float* out, int npix, float spp_inv) {
+	const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+	if (p >= (uint32_t)npix) return;
+	const float4 a = accum[p];
+	out[3 * (size_t)p + 0] = a.x * spp_inv;
+	out[3 * (size_t)p + 1] = a.y * spp_inv;
+	out[3 * (size_t)p + 2] = a.z * spp_inv;
+}
+
+__global__ void __launch_bounds__(256) k_copy_L(const float4* Lout, float* out, int n) {
+	const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+	if (p >= (uint32_t)n) return;
+	const float4 a = Lout[p];
+	out[3 * (size_t)p + 0] = a.x;
+	out[3 * (size_t)p + 1] = a.y;
+	out[3 * (size_t)p + 2] = a.z;
+}
+
+}  // namespace tutu

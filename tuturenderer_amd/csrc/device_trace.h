@@ -1,0 +1,207 @@
+// BVH traversal on the device: closest-hit (BVH.hpp:145-167 semantics) and any-hit (BVH.hpp:170-194 semantics)
+// over the flattened tree of host_scene.hpp.  One ray per lane, per-lane traversal stack in LDS laid out
+// [entry][lane] so that the 64 lanes of a wave hit 64 consecutive banks.
+//
+// Semantics kept from the reference:
+//   * slab test = BoundBox::IntersectRay (BoundBox.hpp:55-92) verbatim: 1/dir may be +-inf, NaN falls through the
+//     `?:` selects, accept iff t_enter <= t_exit && t_exit >= 0;
+//   * triangle test = Triangle::intersect (Triangle.hpp:23-74): two-sided, rejects |dir.n| < 1e-4, strict
+//     t,u,v,1-u-v > 0;
+//   * a triangle is only ever tested after the boxes of ALL its ancestors were hit, exactly as in the recursion;
+//   * closest hit = minimum t, exact ties resolved toward the leftmost leaf (`<=` at BVH.hpp:165) -- triangles are
+//     stored in left-to-right leaf order, so the tie-break is `index <`.
+// What is new: near-child-first order and pruning of subtrees whose entry distance exceeds the best t so far
+// (times 1+1e-4 of slack, to stay on the safe side of the two different roundings of slab-t and triangle-t).
+// The reference visits every node whose box is hit; the result is the same, the work is not.
+#pragma once
+#include <float.h>
+#include <limits.h>
+
+#include "device_math.h"
+
+namespace tutu {
+
+#define TUTU_STACK_DEPTH 32
+#define TUTU_PRUNE_SLACK 1.0001f
+
+struct SceneDev {
+	const float4* nodes;      // 4 x float4 per inner node (GpuNode)
+	const float4* tri_isect;  // 3 x float4 per triangle   (GpuTriIsect)
+	const float4* tri_shade;  // 3 x float4 per triangle   (GpuTriShade)
+	const float4* mats;       // 4 x float4 per material   (GpuMaterial)
+	const float4* lights;     // 6 x float4 per light      (GpuLight)
+	int n_lights;
+	int root_ref;  // >=0 inner node, <0 leaf ~tri, INT_MIN empty
+	float root_min[3], root_max[3];
+	float eta;
+	float bkg[3];
+	int n_tris;
+};
+
+struct RayPre {
+	V3 o, d, inv;
+	bool nx, ny, nz;
+};
+TUTU_DEV RayPre make_ray(V3 o, V3 d) {
+	RayPre r;
+	r.o = o;
+	r.d = d;
+	r.inv = mk(1 / d.x, 1 / d.y, 1 / d.z);  // BoundBox.hpp:57
+	r.nx = d.x < 0;
+	r.ny = d.y < 0;
+	r.nz = d.z < 0;
+	return r;
+}
+
+// BoundBox::IntersectRay, BoundBox.hpp:55-92
+TUTU_DEV bool slab(const RayPre& r, float minx, float miny, float minz, float maxx, float maxy, float maxz, float& t_enter) {
+	float tmin_x = (minx - r.o.x) * r.inv.x;
+	float tmax_x = (maxx - r.o.x) * r.inv.x;
+	float tmin_y = (miny - r.o.y) * r.inv.y;
+	float tmax_y = (maxy - r.o.y) * r.inv.y;
+	float tmin_z = (minz - r.o.z) * r.inv.z;
+	float tmax_z = (maxz - r.o.z) * r.inv.z;
+	if (r.nx) { float s = tmin_x; tmin_x = tmax_x; tmax_x = s; }
+	if (r.ny) { float s = tmin_y; tmin_y = tmax_y; tmax_y = s; }
+	if (r.nz) { float s = tmin_z; tmin_z = tmax_z; tmax_z = s; }
+	float buffer = tmin_y > tmin_z ? tmin_y : tmin_z;
+	t_enter = tmin_x > buffer ? tmin_x : buffer;
+	buffer = tmax_y < tmax_z ? tmax_y : tmax_z;
+	float t_exit = tmax_x < buffer ? tmax_x : buffer;
+	return (t_enter <= t_exit && t_exit >= 0.f);
+}
+
+// Triangle::intersect, Triangle.hpp:23-59 (E1, E2 and the normalised normal are hoisted to the host)
+TUTU_DEV bool tri_test(const SceneDev& sc, int ti, const RayPre& r, float& t, float& u, float& v) {
+	const float4 q0 = sc.tri_isect[3 * ti + 0];
+	const float4 q1 = sc.tri_isect[3 * ti + 1];
+	const float4 q2 = sc.tri_isect[3 * ti + 2];
+	const V3 v0 = mk(q0.x, q0.y, q0.z);
+	const V3 E1 = mk(q0.w, q1.x, q1.y);
+	const V3 E2 = mk(q1.z, q1.w, q2.x);
+	const V3 normal = mk(q2.y, q2.z, q2.w);
+	const V3 S = r.o - v0;
+	const V3 S1 = cross(r.d, E2);
+	const V3 S2 = cross(S, E1);
+	if (float_equal(dot(r.d, normal), 0.f)) return false;
+	const float det = dot(S1, E1);
+	if (det == 0.f) return false;
+	const float left = 1.0f / det;
+	t = dot(S2, E2) * left;
+	u = dot(S1, S) * left;
+	v = dot(S2, r.d) * left;
+	return (t > 0 && 1 - u - v > 0 && u > 0 && v > 0);
+}
+
+struct ChildTest {
+	bool hl, hr;
+	float tl, tr;
+	int left, right;
+};
+TUTU_DEV ChildTest test_children(const SceneDev& sc, int node, const RayPre& r, float lim) {
+	const float4 a = sc.nodes[4 * node + 0];
+	const float4 b = sc.nodes[4 * node + 1];
+	const float4 c = sc.nodes[4 * node + 2];
+	const float4 e = sc.nodes[4 * node + 3];
+	ChildTest ct;
+	ct.hl = slab(r, a.x, a.y, a.z, a.w, b.x, b.y, ct.tl);
+	ct.hr = slab(r, b.z, b.w, c.x, c.y, c.z, c.w, ct.tr);
+	if (ct.hl && !(ct.tl <= lim)) ct.hl = false;
+	if (ct.hr && !(ct.tr <= lim)) ct.hr = false;
+	ct.left = __float_as_int(e.x);
+	ct.right = __float_as_int(e.y);
+	return ct;
+}
+
+// getIntersection, BVH.hpp:145-167.  stack = this lane's column of the LDS stack, `stride` ints between entries.
+TUTU_DEV void trace_closest(const SceneDev& sc, V3 o, V3 d, int* stack, int stride, float& best_t, float& best_u,
+                            float& best_v, int& best_tri) {
+	best_t = FLT_MAX;
+	best_u = 0.f;
+	best_v = 0.f;
+	best_tri = -1;
+	if (sc.root_ref == INT_MIN) return;
+	const RayPre r = make_ray(o, d);
+	float te;
+	if (!slab(r, sc.root_min[0], sc.root_min[1], sc.root_min[2], sc.root_max[0], sc.root_max[1], sc.root_max[2], te)) return;
+	int cur = sc.root_ref;
+	int sp = 0;
+	for (;;) {
+		if (cur < 0) {
+			const int ti = ~cur;
+			float t, u, v;
+			if (tri_test(sc, ti, r, t, u, v)) {
+				if (t < best_t || (t == best_t && ti < best_tri)) {
+					best_t = t;
+					best_u = u;
+					best_v = v;
+					best_tri = ti;
+				}
+			}
+		} else {
+			const float lim = best_tri >= 0 ? best_t * TUTU_PRUNE_SLACK : FLT_MAX;
+			const ChildTest ct = test_children(sc, cur, r, lim);
+			if (ct.hl && ct.hr) {
+				if (ct.tr < ct.tl) {
+					stack[sp * stride] = ct.left;
+					cur = ct.right;
+				} else {
+					stack[sp * stride] = ct.right;
+					cur = ct.left;
+				}
+				sp++;
+				continue;
+			} else if (ct.hl) {
+				cur = ct.left;
+				continue;
+			} else if (ct.hr) {
+				cur = ct.right;
+				continue;
+			}
+		}
+		if (sp == 0) break;
+		sp--;
+		cur = stack[sp * stride];
+	}
+}
+
+// isShadowRayBlocked -> hasIntersection, IIntegrator.hpp:135-153 + BVH.hpp:170-194
+TUTU_DEV bool trace_any(const SceneDev& sc, V3 orig, V3 lightPos, int* stack, int stride) {
+	if (sc.root_ref == INT_MIN) return false;
+	const V3 raydir = normalized(lightPos - orig);
+	const float dis = norm(lightPos - orig);
+	const RayPre r = make_ray(orig, raydir);
+	float te;
+	if (!slab(r, sc.root_min[0], sc.root_min[1], sc.root_min[2], sc.root_max[0], sc.root_max[1], sc.root_max[2], te)) return false;
+	const float lim = dis * TUTU_PRUNE_SLACK;
+	int cur = sc.root_ref;
+	int sp = 0;
+	for (;;) {
+		if (cur < 0) {
+			float t, u, v;
+			if (tri_test(sc, ~cur, r, t, u, v)) {
+				if (t < dis && !float_equal(t, dis)) return true;
+			}
+		} else {
+			const ChildTest ct = test_children(sc, cur, r, lim);
+			if (ct.hl && ct.hr) {
+				stack[sp * stride] = ct.right;
+				sp++;
+				cur = ct.left;
+				continue;
+			} else if (ct.hl) {
+				cur = ct.left;
+				continue;
+			} else if (ct.hr) {
+				cur = ct.right;
+				continue;
+			}
+		}
+		if (sp == 0) break;
+		sp--;
+		cur = stack[sp * stride];
+	}
+	return false;
+}
+
+}  // namespace tutu

@@ -1,0 +1,373 @@
+// Host-side scene preparation (see host_scene.hpp).  Compiled with -ffp-contract=off: every float below is
+// produced by the same IEEE fp32 operations, in the same order, as the reference produces it.
+#include "host_scene.hpp"
+
+#include <algorithm>
+#include <climits>
+#include <cmath>
+#include <cstring>
+
+namespace tutu {
+
+namespace {
+
+struct Box {
+	float mn[3], mx[3];
+};
+
+inline Box box2(const float* p1, const float* p2) {  // BoundBox(Vector3f&, Vector3f&)  BoundBox.hpp:13-27
+	Box b;
+	for (int k = 0; k < 3; k++) {
+		b.mn[k] = fminf(p1[k], p2[k]);
+		b.mx[k] = fmaxf(p1[k], p2[k]);
+	}
+	return b;
+}
+inline Box box_union(const Box& a, const Box& b) {  // Union(BoundBox&, BoundBox&)  BoundBox.hpp:97-109
+	Box r;
+	for (int k = 0; k < 3; k++) {
+		r.mn[k] = fminf(a.mn[k], b.mn[k]);
+		r.mx[k] = fmaxf(a.mx[k], b.mx[k]);
+	}
+	return r;
+}
+inline Box box_union_pt(const Box& a, const float* v) {  // Union(BoundBox&, Vector3f&)  BoundBox.hpp:112-124
+	Box r;
+	for (int k = 0; k < 3; k++) {
+		r.mn[k] = fminf(a.mn[k], v[k]);
+		r.mx[k] = fmaxf(a.mx[k], v[k]);
+	}
+	return r;
+}
+inline float centroid(const Box& b, int k) { return 0.5f * b.mn[k] + 0.5f * b.mx[k]; }  // BoundBox.hpp:35
+inline int max_extent(const Box& b) {                                                    // BoundBox.hpp:43-52
+	const float dx = b.mx[0] - b.mn[0], dy = b.mx[1] - b.mn[1], dz = b.mx[2] - b.mn[2];
+	if (dx > dy && dx > dz) return 0;
+	else if (dy > dz) return 1;
+	else return 2;
+}
+
+struct Builder {
+	const std::vector<Box>& tb;
+	std::vector<BuildNode>& out;
+	uint32_t max_depth = 0;
+
+	void set_bounds(int id, const Box& b) {
+		for (int k = 0; k < 3; k++) {
+			out[id].pmin[k] = b.mn[k];
+			out[id].pmax[k] = b.mx[k];
+		}
+	}
+	Box get_bounds(int id) const {
+		Box b;
+		for (int k = 0; k < 3; k++) {
+			b.mn[k] = out[id].pmin[k];
+			b.mx[k] = out[id].pmax[k];
+		}
+		return b;
+	}
+
+	// BVHAccel::recursiveBuild (BVH.hpp:47-123).  The reference copies the object list at every level and sorts
+	// the copy; sorting the sub-range of one index array in place performs the same comparisons on the same
+	// sequence, hence the same permutation.
+	int build(int32_t* first, int32_t* last, uint32_t depth) {
+		const int id = (int)out.size();
+		out.push_back(BuildNode{{0, 0, 0}, {0, 0, 0}, -1, -1, -1});
+		if (depth > max_depth) max_depth = depth;
+		const size_t n = (size_t)(last - first);
+		if (n == 0) return id;
+		if (n == 1) {
+			set_bounds(id, tb[first[0]]);
+			out[id].tri = first[0];
+			return id;
+		}
+		if (n == 2) {
+			const int l = build(first, first + 1, depth + 1);
+			const int r = build(first + 1, first + 2, depth + 1);
+			out[id].left = l;
+			out[id].right = r;
+			set_bounds(id, box_union(get_bounds(l), get_bounds(r)));
+			return id;
+		}
+		Box ub = box_union(tb[first[0]], tb[first[1]]);
+		for (size_t i = 2; i < n; i++) ub = box_union(ub, tb[first[i]]);
+		const int axis = max_extent(ub);
+		const std::vector<Box>& b = tb;
+		std::sort(first, last, [&b, axis](int32_t o1, int32_t o2) -> bool { return centroid(b[o1], axis) < centroid(b[o2], axis); });
+		int32_t* middle = first + (n / 2);
+		const int l = build(first, middle, depth + 1);
+		const int r = build(middle, last, depth + 1);
+		out[id].left = l;
+		out[id].right = r;
+		set_bounds(id, box_union(get_bounds(l), get_bounds(r)));
+		return id;
+	}
+};
+
+inline void sub3(const float* a, const float* b, float* r) {
+	r[0] = a[0] - b[0];
+	r[1] = a[1] - b[1];
+	r[2] = a[2] - b[2];
+}
+inline void cross3(const float* a, const float* b, float* r) {  // Vector.hpp:223-225
+	r[0] = a[1] * b[2] - a[2] * b[1];
+	r[1] = a[2] * b[0] - a[0] * b[2];
+	r[2] = a[0] * b[1] - a[1] * b[0];
+}
+inline void normalize3(float* v) {  // Vector.hpp:213-220
+	const float mag = sqrtf((v[0] * v[0] + v[1] * v[1] + v[2] * v[2]));
+	if (mag > 0) {
+		const float inv = 1 / mag;
+		v[0] = v[0] * inv;
+		v[1] = v[1] * inv;
+		v[2] = v[2] * inv;
+	}
+}
+
+}  // namespace
+
+int build_reference_tree(uint32_t n_tris, const float* verts, std::vector<BuildNode>& out, uint32_t* depth) {
+	out.clear();
+	if (depth) *depth = 0;
+	if (n_tris == 0) return TUTU_OK;
+	if (!verts) return TUTU_E_INVALID;
+	std::vector<Box> tb(n_tris);
+	for (uint32_t i = 0; i < n_tris; i++) {
+		const float* v = verts + 9 * (size_t)i;
+		tb[i] = box_union_pt(box2(v, v + 3), v + 6);  // Triangle::initializeBound  Triangle.hpp:104-107
+	}
+	std::vector<int32_t> idx(n_tris);
+	for (uint32_t i = 0; i < n_tris; i++) idx[i] = (int32_t)i;
+	out.reserve(2 * (size_t)n_tris);
+	Builder b{tb, out};
+	b.build(idx.data(), idx.data() + n_tris, 0);
+	if (depth) *depth = b.max_depth;
+	return TUTU_OK;
+}
+
+int build_host_scene(const TutuSceneDesc* d, HostScene& hs) {
+	if (!d) return TUTU_E_INVALID;
+	const uint32_t n = d->n_tris;
+	if (n > 0 && (!d->verts || !d->normals || !d->mat_id)) return TUTU_E_INVALID;
+	if (d->n_mats > 0 && !d->mats) return TUTU_E_INVALID;
+	for (uint32_t i = 0; i < n; i++)
+		if (d->mat_id[i] < 0 || (uint32_t)d->mat_id[i] >= d->n_mats) return TUTU_E_INVALID;
+
+	hs.eta = d->eta;
+	memcpy(hs.bkg, d->bkg, sizeof(hs.bkg));
+	hs.mats.resize(d->n_mats);
+	for (uint32_t i = 0; i < d->n_mats; i++) {
+		const TutuMaterial& m = d->mats[i];
+		GpuMaterial g;
+		memset(&g, 0, sizeof(g));
+		memcpy(g.diffuse, m.diffuse, 12);
+		memcpy(g.emission, m.emission, 12);
+		g.type = m.type;
+		g.has_emission = (m.emission[0] || m.emission[1] || m.emission[2]) ? 1 : 0;  // Material::hasEmission  :54-56
+		g.alpha = m.alpha;
+		g.eta = m.eta;
+		g.roughness = m.roughness;
+		g.metallic = m.metallic;
+		hs.mats[i] = g;
+	}
+
+	std::vector<BuildNode> tree;
+	int rc = build_reference_tree(n, d->verts, tree, &hs.depth);
+	if (rc != TUTU_OK) return rc;
+	if (hs.depth > TUTU_MAX_BVH_DEPTH) return TUTU_E_BVH_DEPTH;
+
+	// leaf order = left-to-right walk = the order in which getIntersection's `<=` resolves exact-t ties
+	// (BVH.hpp:165).  Triangles are stored in that order so the kernels break ties by index.
+	std::vector<int32_t> order;  // leaf-order -> original
+	order.reserve(n);
+	hs.leaf_of_orig.assign(n, -1);
+	std::vector<int32_t> inner_id(tree.size(), -1);
+	{
+		int32_t next_inner = 0;
+		for (size_t i = 0; i < tree.size(); i++) {
+			if (tree[i].left >= 0 || tree[i].right >= 0) inner_id[i] = next_inner++;  // pre-order numbering
+			else if (tree[i].tri >= 0) {
+				hs.leaf_of_orig[tree[i].tri] = (int32_t)order.size();
+				order.push_back(tree[i].tri);
+			}
+		}
+		hs.nodes.assign((size_t)next_inner, GpuNode{});
+	}
+	auto ref_of = [&](int32_t bn) -> int32_t {
+		if (tree[bn].left >= 0 || tree[bn].right >= 0) return inner_id[bn];
+		return ~hs.leaf_of_orig[tree[bn].tri];
+	};
+	for (size_t i = 0; i < tree.size(); i++) {
+		if (inner_id[i] < 0) continue;
+		GpuNode& g = hs.nodes[inner_id[i]];
+		const BuildNode& l = tree[tree[i].left];
+		const BuildNode& r = tree[tree[i].right];
+		memcpy(g.lmin, l.pmin, 12);
+		memcpy(g.lmax, l.pmax, 12);
+		memcpy(g.rmin, r.pmin, 12);
+		memcpy(g.rmax, r.pmax, 12);
+		g.left = ref_of(tree[i].left);
+		g.right = ref_of(tree[i].right);
+		g.pad0 = g.pad1 = 0;
+	}
+	if (tree.empty()) {
+		hs.root_ref = INT_MIN;
+		memset(hs.root_min, 0, 12);
+		memset(hs.root_max, 0, 12);
+	} else {
+		hs.root_ref = ref_of(0);
+		memcpy(hs.root_min, tree[0].pmin, 12);
+		memcpy(hs.root_max, tree[0].pmax, 12);
+	}
+
+	// lights: PPMGenerator::initializeLights order = object-list order (PPMGenerator.hpp:317-324)
+	std::vector<int32_t> light_orig;
+	for (uint32_t i = 0; i < n; i++)
+		if (hs.mats[d->mat_id[i]].has_emission) light_orig.push_back((int32_t)i);
+	const int size = (int)light_orig.size();
+
+	hs.tri_isect.resize(n);
+	hs.tri_shade.resize(n);
+	std::vector<float> area(n, 0.f);
+	for (uint32_t li = 0; li < n; li++) {
+		const int32_t o = order[li];
+		const float* v = d->verts + 9 * (size_t)o;
+		const float* nn = d->normals + 9 * (size_t)o;
+		GpuTriIsect& t = hs.tri_isect[li];
+		memcpy(t.v0, v, 12);
+		sub3(v + 3, v, t.e1);      // E1 = v1 - v0            Triangle.hpp:25
+		sub3(v + 6, v, t.e2);      // E2 = v2 - v0            Triangle.hpp:26
+		cross3(t.e1, t.e2, t.n);   // normal = E1 x E2        Triangle.hpp:34
+		const float cx = t.n[0], cy = t.n[1], cz = t.n[2];
+		normalize3(t.n);           // normalized(normal)      Triangle.hpp:35
+		area[li] = sqrtf(cx * cx + cy * cy + cz * cz) * 0.5f;  // Triangle::getArea  Triangle.hpp:109-116
+		GpuTriShade& s = hs.tri_shade[li];
+		memcpy(s.n0, nn, 12);
+		memcpy(s.n1, nn + 3, 12);
+		memcpy(s.n2, nn + 6, 12);
+		s.mat = d->mat_id[o];
+		s.orig = o;
+		s.light_pdf = hs.mats[s.mat].has_emission ? 1 / (size * area[li]) : 0.f;  // getLightPdf  IIntegrator.hpp:166-167
+	}
+	hs.lights.resize(light_orig.size());
+	for (size_t k = 0; k < light_orig.size(); k++) {
+		const int32_t o = light_orig[k];
+		const int32_t li = hs.leaf_of_orig[o];
+		const float* v = d->verts + 9 * (size_t)o;
+		const float* nn = d->normals + 9 * (size_t)o;
+		GpuLight& L = hs.lights[k];
+		memcpy(L.v0, v, 12);
+		memcpy(L.v1, v + 3, 12);
+		memcpy(L.v2, v + 6, 12);
+		memcpy(L.n0, nn, 12);
+		memcpy(L.n1, nn + 3, 12);
+		memcpy(L.n2, nn + 6, 12);
+		memcpy(L.emission, hs.mats[d->mat_id[o]].emission, 12);
+		L.pdf = (1.f / (size * area[li]));  // sampleLight  IIntegrator.hpp:191
+		L.tri = li;
+		L.pad = 0;
+	}
+	return TUTU_OK;
+}
+
+}  // namespace tutu
+
+// ------------------------------------------------------------------------------------------------------------
+// C ABI: host-only helpers
+extern "C" {
+
+int tutu_bvh_build_preorder(uint32_t n_tris, const float* verts, uint32_t cap, uint32_t* n_nodes, float* bounds6,
+                            int32_t* leaf_tri, TutuBvhInfo* info) {
+	if (!n_nodes) return TUTU_E_INVALID;
+	std::vector<tutu::BuildNode> tree;
+	uint32_t depth = 0;
+	int rc = tutu::build_reference_tree(n_tris, verts, tree, &depth);
+	if (rc != TUTU_OK) return rc;
+	*n_nodes = (uint32_t)tree.size();
+	uint32_t inner = 0;
+	for (size_t i = 0; i < tree.size(); i++) {
+		const bool is_inner = tree[i].left >= 0 || tree[i].right >= 0;
+		inner += is_inner ? 1u : 0u;
+		if (i < cap && bounds6 && leaf_tri) {
+			memcpy(bounds6 + 6 * i, tree[i].pmin, 12);
+			memcpy(bounds6 + 6 * i + 3, tree[i].pmax, 12);
+			leaf_tri[i] = is_inner ? -1 : tree[i].tri;
+		}
+	}
+	if (info) {
+		info->n_tris = n_tris;
+		info->n_inner = inner;
+		info->depth = depth;
+		memset(info->root_bounds, 0, sizeof(info->root_bounds));
+		if (!tree.empty()) {
+			memcpy(info->root_bounds, tree[0].pmin, 12);
+			memcpy(info->root_bounds + 3, tree[0].pmax, 12);
+		}
+	}
+	return TUTU_OK;
+}
+
+// Camera::initialize (Camera.hpp:12-17, 43-44) followed by the camera-frame lines of PathTracing::integrate
+// (PathTracing.hpp:357-391).  M_PI there is the float literal 3.1415926535897f (global.hpp:15).
+int tutu_camera_frame(const TutuCameraDesc* cam, TutuCameraFrame* out) {
+	if (!cam || !out || cam->width <= 0 || cam->height <= 0) return TUTU_E_INVALID;
+	const float kPi = 3.1415926535897f;
+	using namespace tutu;
+	float fwd[3] = {cam->viewdir[0], cam->viewdir[1], cam->viewdir[2]};
+	normalize3(fwd);  // cam.fwdDir
+	float right[3];
+	cross3(fwd, cam->updir, right);
+	normalize3(right);
+	float up[3];
+	cross3(right, fwd, up);
+	normalize3(up);  // cam.upDir
+	const float tanHalfHfov = tanf((cam->hfov * 0.5f) * kPi / 180.f);
+	const float imagePlaneDist = cam->width / (2.f * tanHalfHfov);
+
+	float u[3], v[3];
+	cross3(fwd, up, u);
+	normalize3(u);
+	cross3(u, fwd, v);
+	normalize3(v);
+	const float d = imagePlaneDist;
+	const float width_half = fabsf(tanf((cam->hfov / 2.f) * kPi / 180.f) * d);
+	const float aspect_ratio = cam->width / (float)cam->height;
+	const float height_half = width_half / aspect_ratio;
+	float n[3] = {cam->viewdir[0], cam->viewdir[1], cam->viewdir[2]};
+	normalize3(n);  // normalized(g->viewdir)
+	float ul[3], ur[3], ll[3];
+	for (int k = 0; k < 3; k++) {
+		// eyePos + d*n -/+ width_half*u +/- height_half*v, left to right
+		ul[k] = ((cam->eye[k] + n[k] * d) - u[k] * width_half) + v[k] * height_half;
+		ur[k] = ((cam->eye[k] + n[k] * d) + u[k] * width_half) + v[k] * height_half;
+		ll[k] = ((cam->eye[k] + n[k] * d) - u[k] * width_half) - v[k] * height_half;
+	}
+	out->width = cam->width;
+	out->height = cam->height;
+	for (int k = 0; k < 3; k++) {
+		out->ul[k] = ul[k];
+		out->delta_h[k] = (cam->width != 1) ? (ur[k] - ul[k]) / (float)(cam->width - 1) : 0.f;
+		out->delta_v[k] = (cam->height != 1) ? (ll[k] - ul[k]) / (float)(cam->height - 1) : 0.f;
+		out->c_off_h[k] = (ur[k] - ul[k]) / (float)(cam->width * 2);
+		out->c_off_v[k] = (ll[k] - ul[k]) / (float)(cam->height * 2);
+		out->eye[k] = cam->eye[k];
+	}
+	return TUTU_OK;
+}
+
+const char* tutu_hip_error_string(int code) {
+	switch (code) {
+	case TUTU_OK: return "ok";
+	case TUTU_E_INVALID: return "invalid argument";
+	case TUTU_E_NO_DEVICE: return "no such HIP device";
+	case TUTU_E_HIP: return "HIP runtime error";
+	case TUTU_E_OOM: return "out of memory";
+	case TUTU_E_BVH_DEPTH: return "BVH deeper than the traversal stack";
+	case TUTU_E_UNSUPPORTED: return "feature outside the PathTracing hot path";
+	default: return "unknown error";
+	}
+}
+
+const char* tutu_hip_version(void) { return "tuturenderer_amd 0.1 (gfx950)"; }
+
+}  // extern "C"

@@ -1,0 +1,89 @@
+// Host-side scene preparation for the HIP path tracer: BVH build (same tree as the reference builds), flattening
+// into the linear arrays the kernels read, light list, camera frame.  Plain C++, no GPU calls.
+#pragma once
+#include <cstdint>
+#include <vector>
+
+#include "../../include/tutu_hip.h"
+
+namespace tutu {
+
+struct F3 {
+	float x, y, z;
+};
+
+// One inner node of the flattened tree, 64 B = one cache-line-half, fetched as 4 x dwordx4.
+// Both children's boxes live in the parent, so one fetch feeds two slab tests and leaves have no node at all.
+// child < 0  ->  leaf, triangle (leaf-order) index = ~child
+struct GpuNode {
+	float lmin[3], lmax[3];
+	float rmin[3], rmax[3];
+	int32_t left, right;
+	int32_t pad0, pad1;
+};
+static_assert(sizeof(GpuNode) == 64, "GpuNode must be 64 B");
+
+// Triangle as the intersector reads it (48 B = 3 x dwordx4): v0, E1 = v1-v0, E2 = v2-v0, n = normalized(E1 x E2).
+// These are exactly the per-test temporaries of Triangle::intersect (Triangle.hpp:25-35), hoisted to the host;
+// the host computes them with the same fp32 operations, so the bits are the same.
+struct GpuTriIsect {
+	float v0[3], e1[3], e2[3], n[3];
+};
+static_assert(sizeof(GpuTriIsect) == 48, "GpuTriIsect must be 48 B");
+
+// Triangle as shading reads it (48 B): vertex normals, material, original index, light pdf.
+struct GpuTriShade {
+	float n0[3], n1[3], n2[3];
+	int32_t mat;      // index into materials
+	int32_t orig;     // index in the caller's triangle list
+	float light_pdf;  // 1/(n_lights*area) when the material is emissive, else 0   (IIntegrator.hpp:155-168)
+};
+static_assert(sizeof(GpuTriShade) == 48, "GpuTriShade must be 48 B");
+
+// Material as the kernels read it (64 B)
+struct GpuMaterial {
+	float diffuse[3];
+	int32_t type;
+	float emission[3];
+	int32_t has_emission;
+	float alpha, eta, roughness, metallic;
+	float pad[4];
+};
+static_assert(sizeof(GpuMaterial) == 64, "GpuMaterial must be 64 B");
+
+// Light = emissive triangle (96 B)
+struct GpuLight {
+	float v0[3], v1[3], v2[3];
+	float n0[3], n1[3], n2[3];
+	float emission[3];
+	float pdf;    // 1/(n_lights*area)            (IIntegrator.hpp:191)
+	int32_t tri;  // leaf-order triangle index
+	int32_t pad;
+};
+static_assert(sizeof(GpuLight) == 96, "GpuLight must be 96 B");
+
+struct HostScene {
+	std::vector<GpuNode> nodes;       // inner nodes; nodes[0] is the root when n_tris >= 2
+	std::vector<GpuTriIsect> tri_isect;  // leaf order
+	std::vector<GpuTriShade> tri_shade;  // leaf order
+	std::vector<GpuMaterial> mats;
+	std::vector<GpuLight> lights;
+	std::vector<int32_t> leaf_of_orig;  // original triangle index -> leaf-order index
+	float root_min[3], root_max[3];
+	int32_t root_ref;  // >=0 inner node index, <0 leaf (~tri), or INT32_MIN for an empty scene
+	uint32_t depth;
+	float eta;
+	float bkg[3];
+};
+
+// Pre-order tree in the reference's own shape (used by tutu_bvh_build_preorder and by flatten()).
+struct BuildNode {
+	float pmin[3], pmax[3];
+	int32_t left, right;  // indices into the build-node array, -1 for none
+	int32_t tri;          // original triangle index for a leaf, -1 otherwise
+};
+
+int build_reference_tree(uint32_t n_tris, const float* verts, std::vector<BuildNode>& out, uint32_t* depth);
+int build_host_scene(const TutuSceneDesc* d, HostScene& out);
+
+}  // namespace tutu

@@ -1,0 +1,716 @@
+// C ABI of the gfx950 path tracer (include/tutu_hip.h): context, device buffers, the per-pass launch sequence.
+// No CPU fallback exists anywhere in this file: without a HIP device every device entry point returns
+// TUTU_E_NO_DEVICE / TUTU_E_HIP.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <climits>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/tutu_hip.h"
+#include "device_shade.h"
+#include "host_scene.hpp"
+
+using namespace tutu;
+
+static thread_local std::string g_last_error;
+
+#define HIP_TRY(expr)                                                                                   \
+	do {                                                                                                \
+		hipError_t _e = (expr);                                                                         \
+		if (_e != hipSuccess) {                                                                         \
+			char _buf[512];                                                                             \
+			snprintf(_buf, sizeof(_buf), "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+			g_last_error = _buf;                                                                        \
+			return (_e == hipErrorOutOfMemory) ? TUTU_E_OOM : TUTU_E_HIP;                               \
+		}                                                                                               \
+	} while (0)
+
+namespace {
+
+enum EvKind { EV_TRACE_CLOSEST = 0, EV_TRACE_ANY = 1, EV_SHADE = 2, EV_OTHER = 3, EV_NKIND = 4 };
+
+struct EvPair {
+	hipEvent_t a, b;
+	int kind;
+};
+
+template <typename T>
+struct DevBuf {
+	T* p = nullptr;
+	size_t n = 0;
+	int ensure(size_t want) {
+		if (want <= n && p) return TUTU_OK;
+		if (p) (void)hipFree(p);
+		p = nullptr;
+		n = 0;
+		if (want == 0) return TUTU_OK;
+		HIP_TRY(hipMalloc((void**)&p, want * sizeof(T)));
+		n = want;
+		return TUTU_OK;
+	}
+	void release() {
+		if (p) (void)hipFree(p);
+		p = nullptr;
+		n = 0;
+	}
+};
+
+}  // namespace
+
+struct TutuCtx {
+	int device = 0;
+	hipStream_t stream = nullptr;
+	int n_cu = 256;
+	HostScene hs;
+	SceneDev sc;
+	DevBuf<float4> d_nodes, d_tri_isect, d_tri_shade, d_mats, d_lights;
+	// work buffers
+	size_t cap = 0;
+	DevBuf<float4> qbuf[2][8];
+	DevBuf<float4> shadowq, Lout, prim_dir, prim_hit, accum;
+	DevBuf<uint32_t> perm;
+	DevBuf<Counters> counters;
+	DevBuf<Totals> totals;
+	DevBuf<int32_t> pixels;
+	DevBuf<uint32_t> u32a, u32b;
+	DevBuf<float> out_stage;
+	std::vector<EvPair> ev_pool;
+	size_t ev_used = 0;
+};
+
+namespace {
+
+Queue queue_of(TutuCtx* c, int which) {
+	Queue q;
+	q.A = c->qbuf[which][0].p; q.B = c->qbuf[which][1].p; q.C = c->qbuf[which][2].p; q.D = c->qbuf[which][3].p;
+	q.E = c->qbuf[which][4].p; q.F = c->qbuf[which][5].p; q.G = c->qbuf[which][6].p; q.H = c->qbuf[which][7].p;
+	return q;
+}
+
+int ensure_work(TutuCtx* c, size_t cap, size_t nitems) {
+	int rc;
+	if (cap > c->cap) {
+		for (int w = 0; w < 2; w++)
+			for (int f = 0; f < 8; f++)
+				if ((rc = c->qbuf[w][f].ensure(cap)) != TUTU_OK) return rc;
+		if ((rc = c->shadowq.ensure(3 * cap)) != TUTU_OK) return rc;
+		if ((rc = c->Lout.ensure(cap)) != TUTU_OK) return rc;
+		if ((rc = c->perm.ensure((size_t)TUTU_NCLASS * cap)) != TUTU_OK) return rc;
+		c->cap = cap;
+	}
+	if ((rc = c->prim_dir.ensure(nitems)) != TUTU_OK) return rc;
+	if ((rc = c->prim_hit.ensure(nitems)) != TUTU_OK) return rc;
+	if ((rc = c->accum.ensure(nitems)) != TUTU_OK) return rc;
+	if ((rc = c->counters.ensure(TUTU_MAX_DEPTH + 3)) != TUTU_OK) return rc;
+	if ((rc = c->totals.ensure(1)) != TUTU_OK) return rc;
+	return TUTU_OK;
+}
+
+int ev_begin(TutuCtx* c, hipStream_t s, int kind, size_t* idx) {
+	if (c->ev_used == c->ev_pool.size()) {
+		EvPair p;
+		HIP_TRY(hipEventCreate(&p.a));
+		HIP_TRY(hipEventCreate(&p.b));
+		p.kind = kind;
+		c->ev_pool.push_back(p);
+	}
+	*idx = c->ev_used++;
+	c->ev_pool[*idx].kind = kind;
+	HIP_TRY(hipEventRecord(c->ev_pool[*idx].a, s));
+	return TUTU_OK;
+}
+int ev_end(TutuCtx* c, hipStream_t s, size_t idx) {
+	HIP_TRY(hipEventRecord(c->ev_pool[idx].b, s));
+	return TUTU_OK;
+}
+
+#define TIMED(kind, ...)                                      \
+	do {                                                      \
+		size_t _ei = 0;                                       \
+		int _rc = ev_begin(c, s, kind, &_ei);                 \
+		if (_rc != TUTU_OK) return _rc;                       \
+		__VA_ARGS__;                                          \
+		HIP_TRY(hipGetLastError());                           \
+		_rc = ev_end(c, s, _ei);                              \
+		if (_rc != TUTU_OK) return _rc;                       \
+	} while (0)
+
+int persistent_grid(TutuCtx* c, size_t upper_items) {
+	size_t blocks = (upper_items + 255) / 256;
+	size_t maxb = (size_t)c->n_cu * 8;
+	if (blocks < 1) blocks = 1;
+	return (int)std::min(blocks, maxb);
+}
+
+// One wavefront pass over `npix` work items x `nsamp` samples (or, with smp_list, one sample per item).
+int run_pass(TutuCtx* c, hipStream_t s, const TutuCameraFrame* cam, uint32_t key0, uint32_t key1, int npix, int s0, int nsamp,
+             const uint32_t* d_smp_list, uint32_t* n_trace_launches) {
+	const size_t npaths = (size_t)npix * (size_t)nsamp;
+	Counters* cnt = c->counters.p;
+	HIP_TRY(hipMemsetAsync(cnt, 0, sizeof(Counters) * (TUTU_MAX_DEPTH + 3), s));
+
+	PassParams pp;
+	memset(&pp, 0, sizeof(pp));
+	pp.sc = c->sc;
+	pp.key0 = key0;
+	pp.key1 = key1;
+	pp.npix = npix;
+	pp.s0 = s0;
+	pp.cap = (int)c->cap;
+	pp.prim_dir = c->prim_dir.p;
+	pp.prim_hit = c->prim_hit.p;
+	pp.smp_list = d_smp_list;
+	memcpy(pp.eye, cam->eye, sizeof(pp.eye));
+	pp.shadowq = c->shadowq.p;
+	pp.Lout = c->Lout.p;
+	pp.perm = c->perm.p;
+	pp.totals = c->totals.p;
+
+	const int grid = persistent_grid(c, npaths);
+	for (int d = 0; d <= TUTU_MAX_DEPTH + 1; d++) {
+		pp.depth = d;
+		pp.qin = queue_of(c, (d + 1) & 1);
+		pp.qout = queue_of(c, d & 1);
+		pp.cnt_in = d > 0 ? &cnt[d - 1] : nullptr;
+		pp.cnt_out = &cnt[d];
+		if (d == 0) {
+			dim3 g((unsigned)((npix + 255) / 256), (unsigned)nsamp, 1);
+			TIMED(EV_SHADE, k_shade<true><<<g, dim3(256), 0, s>>>(pp));
+		} else {
+			TraceParams tp;
+			tp.sc = c->sc;
+			tp.q = pp.qin;
+			tp.n_ptr = &cnt[d - 1].queue_n;
+			tp.cls = cnt[d - 1].cls;
+			tp.perm = c->perm.p;
+			tp.cap = (int)c->cap;
+			tp.totals = c->totals.p;
+			TIMED(EV_TRACE_CLOSEST, k_trace_closest<<<dim3(grid), dim3(256), 0, s>>>(tp));
+			(*n_trace_launches)++;
+			ShadowParams sp;
+			sp.sc = c->sc;
+			sp.shadowq = c->shadowq.p;
+			sp.n_ptr = &cnt[d - 1].shadow_n;
+			sp.q = pp.qin;
+			sp.Lout = c->Lout.p;
+			sp.totals = c->totals.p;
+			TIMED(EV_TRACE_ANY, k_trace_any<<<dim3(grid), dim3(256), 0, s>>>(sp));
+			TIMED(EV_SHADE, k_shade<false><<<dim3(grid), dim3(256), 0, s>>>(pp));
+		}
+	}
+	return TUTU_OK;
+}
+
+int launch_primary(TutuCtx* c, hipStream_t s, const TutuCameraFrame* cam, int n, const int32_t* d_pixels, const uint32_t* d_pix_u,
+                   int x0, int y0, int rect_w) {
+	PrimaryParams p;
+	memset(&p, 0, sizeof(p));
+	p.sc = c->sc;
+	p.cam = *cam;
+	p.pixels = d_pixels;
+	p.pix_list_u = d_pix_u;
+	p.n = n;
+	p.x0 = x0;
+	p.y0 = y0;
+	p.rect_w = rect_w > 0 ? rect_w : 1;
+	p.prim_dir = c->prim_dir.p;
+	p.prim_hit = c->prim_hit.p;
+	p.totals = c->totals.p;
+	TIMED(EV_OTHER, k_primary<<<dim3((n + 255) / 256), dim3(256), 0, s>>>(p));
+	return TUTU_OK;
+}
+
+int collect_stats(TutuCtx* c, hipStream_t s, TutuStats* st, uint64_t samples, uint32_t passes, uint32_t trace_launches) {
+	HIP_TRY(hipStreamSynchronize(s));
+	if (!st) {
+		c->ev_used = 0;
+		return TUTU_OK;
+	}
+	memset(st, 0, sizeof(*st));
+	Totals t;
+	HIP_TRY(hipMemcpy(&t, c->totals.p, sizeof(t), hipMemcpyDeviceToHost));
+	st->samples = samples;
+	st->closest_rays = t.closest_rays;
+	st->shadow_rays = t.shadow_rays;
+	st->segments = t.segments;
+	st->passes = passes;
+	st->trace_launches = trace_launches;
+	float ms[EV_NKIND] = {0, 0, 0, 0};
+	for (size_t i = 0; i < c->ev_used; i++) {
+		float e = 0.f;
+		HIP_TRY(hipEventElapsedTime(&e, c->ev_pool[i].a, c->ev_pool[i].b));
+		ms[c->ev_pool[i].kind] += e;
+	}
+	if (c->ev_used > 0) {
+		float tot = 0.f;
+		HIP_TRY(hipEventElapsedTime(&tot, c->ev_pool[0].a, c->ev_pool[c->ev_used - 1].b));
+		st->ms_total = tot;
+	}
+	st->ms_trace_closest = ms[EV_TRACE_CLOSEST];
+	st->ms_trace_any = ms[EV_TRACE_ANY];
+	st->ms_shade = ms[EV_SHADE];
+	st->ms_other = ms[EV_OTHER];
+	c->ev_used = 0;
+	return TUTU_OK;
+}
+
+int render_impl(TutuCtx* c, const TutuCameraFrame* cam, const TutuRenderParams* rp, float* d_out, hipStream_t s, TutuStats* st) {
+	if (!c || !cam || !rp || !d_out) return TUTU_E_INVALID;
+	if (rp->spp <= 0 || cam->width <= 0 || cam->height <= 0) return TUTU_E_INVALID;
+	int npix, x0 = 0, y0 = 0, rect_w = 1;
+	if (rp->pixels) {
+		if (rp->n_pixels <= 0) return TUTU_E_INVALID;
+		npix = rp->n_pixels;
+		for (int i = 0; i < npix; i++)
+			if (rp->pixels[i] < 0 || rp->pixels[i] >= cam->width * cam->height) return TUTU_E_INVALID;
+	} else {
+		if (rp->x0 < 0 || rp->y0 < 0 || rp->x1 > cam->width || rp->y1 > cam->height || rp->x1 <= rp->x0 || rp->y1 <= rp->y0)
+			return TUTU_E_INVALID;
+		x0 = rp->x0;
+		y0 = rp->y0;
+		rect_w = rp->x1 - rp->x0;
+		npix = rect_w * (rp->y1 - rp->y0);
+	}
+	HIP_TRY(hipSetDevice(c->device));
+	const int64_t max_paths = rp->max_paths > 0 ? rp->max_paths : ((int64_t)16 << 20);
+	int spp_pass = rp->spp_per_pass > 0 ? rp->spp_per_pass : (int)std::max<int64_t>(1, max_paths / npix);
+	spp_pass = std::min(spp_pass, rp->spp);
+	spp_pass = std::min(spp_pass, 65535);  // grid.y limit
+	const size_t cap = (size_t)npix * (size_t)spp_pass;
+	int rc = ensure_work(c, cap, (size_t)npix);
+	if (rc != TUTU_OK) return rc;
+	const int32_t* d_pixels = nullptr;
+	if (rp->pixels) {
+		if ((rc = c->pixels.ensure((size_t)npix)) != TUTU_OK) return rc;
+		HIP_TRY(hipMemcpyAsync(c->pixels.p, rp->pixels, sizeof(int32_t) * (size_t)npix, hipMemcpyHostToDevice, s));
+		d_pixels = c->pixels.p;
+	}
+	c->ev_used = 0;
+	HIP_TRY(hipMemsetAsync(c->totals.p, 0, sizeof(Totals), s));
+	if ((rc = launch_primary(c, s, cam, npix, d_pixels, nullptr, x0, y0, rect_w)) != TUTU_OK) return rc;
+	HIP_TRY(hipMemsetAsync(c->accum.p, 0, sizeof(float4) * (size_t)npix, s));
+	uint32_t passes = 0, trace_launches = 0;
+	for (int s0 = 0; s0 < rp->spp; s0 += spp_pass) {
+		const int ns = std::min(spp_pass, rp->spp - s0);
+		if ((rc = run_pass(c, s, cam, rp->key0, rp->key1, npix, s0, ns, nullptr, &trace_launches)) != TUTU_OK) return rc;
+		TIMED(EV_OTHER, k_resolve<<<dim3((npix + 255) / 256), dim3(256), 0, s>>>(c->Lout.p, c->accum.p, npix, ns));
+		passes++;
+	}
+	const float spp_inv = 1.f / rp->spp;  // SPP_inv, global.hpp:20
+	TIMED(EV_OTHER, k_finalize<<<dim3((npix + 255) / 256), dim3(256), 0, s>>>(c->accum.p, d_out, npix, spp_inv));
+	return collect_stats(c, s, st, (uint64_t)npix * (uint64_t)rp->spp, passes, trace_launches);
+}
+
+template <typename T>
+int upload(DevBuf<float4>& buf, const std::vector<T>& v, hipStream_t s) {
+	const size_t bytes = v.size() * sizeof(T);
+	int rc = buf.ensure(std::max<size_t>(1, bytes / sizeof(float4)));
+	if (rc != TUTU_OK) return rc;
+	if (bytes) HIP_TRY(hipMemcpyAsync(buf.p, v.data(), bytes, hipMemcpyHostToDevice, s));
+	return TUTU_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* tutu_hip_last_error(void) { return g_last_error.c_str(); }
+
+int tutu_hip_device_count(int* count) {
+	if (!count) return TUTU_E_INVALID;
+	*count = 0;
+	hipError_t e = hipGetDeviceCount(count);
+	if (e != hipSuccess) {
+		g_last_error = std::string("hipGetDeviceCount failed: ") + hipGetErrorString(e);
+		*count = 0;
+		return TUTU_E_NO_DEVICE;
+	}
+	return TUTU_OK;
+}
+
+int tutu_hip_create(const TutuSceneDesc* scene, int device, TutuCtx** out) {
+	if (!scene || !out) return TUTU_E_INVALID;
+	*out = nullptr;
+	int ndev = 0;
+	int rc = tutu_hip_device_count(&ndev);
+	if (rc != TUTU_OK) return rc;
+	if (device < 0 || device >= ndev) return TUTU_E_NO_DEVICE;
+	TutuCtx* c = new TutuCtx();
+	rc = build_host_scene(scene, c->hs);
+	if (rc != TUTU_OK) {
+		delete c;
+		return rc;
+	}
+	c->device = device;
+	auto fail = [&](int code) {
+		tutu_hip_destroy(c);
+		return code;
+	};
+	if (hipSetDevice(device) != hipSuccess) return fail(TUTU_E_NO_DEVICE);
+	hipDeviceProp_t prop;
+	if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+	if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) return fail(TUTU_E_HIP);
+	hipStream_t s = c->stream;
+	if ((rc = upload(c->d_nodes, c->hs.nodes, s)) != TUTU_OK) return fail(rc);
+	if ((rc = upload(c->d_tri_isect, c->hs.tri_isect, s)) != TUTU_OK) return fail(rc);
+	if ((rc = upload(c->d_tri_shade, c->hs.tri_shade, s)) != TUTU_OK) return fail(rc);
+	if ((rc = upload(c->d_mats, c->hs.mats, s)) != TUTU_OK) return fail(rc);
+	if ((rc = upload(c->d_lights, c->hs.lights, s)) != TUTU_OK) return fail(rc);
+	if (hipStreamSynchronize(s) != hipSuccess) return fail(TUTU_E_HIP);
+	SceneDev& sc = c->sc;
+	sc.nodes = c->d_nodes.p;
+	sc.tri_isect = c->d_tri_isect.p;
+	sc.tri_shade = c->d_tri_shade.p;
+	sc.mats = c->d_mats.p;
+	sc.lights = c->d_lights.p;
+	sc.n_lights = (int)c->hs.lights.size();
+	sc.root_ref = c->hs.root_ref;
+	memcpy(sc.root_min, c->hs.root_min, 12);
+	memcpy(sc.root_max, c->hs.root_max, 12);
+	sc.eta = c->hs.eta;
+	memcpy(sc.bkg, c->hs.bkg, 12);
+	sc.n_tris = (int)c->hs.tri_isect.size();
+	*out = c;
+	return TUTU_OK;
+}
+
+int tutu_hip_destroy(TutuCtx* c) {
+	if (!c) return TUTU_OK;
+	(void)hipSetDevice(c->device);
+	if (c->stream) (void)hipStreamSynchronize(c->stream);
+	for (auto& e : c->ev_pool) {
+		(void)hipEventDestroy(e.a);
+		(void)hipEventDestroy(e.b);
+	}
+	c->d_nodes.release(); c->d_tri_isect.release(); c->d_tri_shade.release(); c->d_mats.release(); c->d_lights.release();
+	for (int w = 0; w < 2; w++)
+		for (int f = 0; f < 8; f++) c->qbuf[w][f].release();
+	c->shadowq.release(); c->Lout.release(); c->prim_dir.release(); c->prim_hit.release(); c->accum.release();
+	c->perm.release(); c->counters.release(); c->totals.release(); c->pixels.release(); c->u32a.release(); c->u32b.release();
+	c->out_stage.release();
+	if (c->stream) (void)hipStreamDestroy(c->stream);
+	delete c;
+	return TUTU_OK;
+}
+
+int tutu_hip_scene_info(TutuCtx* c, TutuBvhInfo* bvh, uint32_t* n_lights) {
+	if (!c) return TUTU_E_INVALID;
+	if (bvh) {
+		bvh->n_tris = (uint32_t)c->hs.tri_isect.size();
+		bvh->n_inner = (uint32_t)c->hs.nodes.size();
+		bvh->depth = c->hs.depth;
+		memcpy(bvh->root_bounds, c->hs.root_min, 12);
+		memcpy(bvh->root_bounds + 3, c->hs.root_max, 12);
+	}
+	if (n_lights) *n_lights = (uint32_t)c->hs.lights.size();
+	return TUTU_OK;
+}
+
+int tutu_hip_render_device(TutuCtx* c, const TutuCameraFrame* cam, const TutuRenderParams* rp, float* d_out, void* stream, TutuStats* st) {
+	if (!c) return TUTU_E_INVALID;
+	hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+	return render_impl(c, cam, rp, d_out, s, st);
+}
+
+int tutu_hip_render(TutuCtx* c, const TutuCameraFrame* cam, const TutuRenderParams* rp, float* out_rgb, TutuStats* st) {
+	if (!c || !cam || !rp || !out_rgb) return TUTU_E_INVALID;
+	int npix;
+	if (rp->pixels) npix = rp->n_pixels;
+	else npix = (rp->x1 - rp->x0) * (rp->y1 - rp->y0);
+	if (npix <= 0) return TUTU_E_INVALID;
+	HIP_TRY(hipSetDevice(c->device));
+	int rc = c->out_stage.ensure(3 * (size_t)npix);
+	if (rc != TUTU_OK) return rc;
+	rc = render_impl(c, cam, rp, c->out_stage.p, c->stream, st);
+	if (rc != TUTU_OK) return rc;
+	HIP_TRY(hipMemcpy(out_rgb, c->out_stage.p, sizeof(float) * 3 * (size_t)npix, hipMemcpyDeviceToHost));
+	return TUTU_OK;
+}
+
+int tutu_hip_trace_samples(TutuCtx* c, const TutuCameraFrame* cam, uint32_t n, const uint32_t* pix, const uint32_t* smp,
+                           uint32_t key0, uint32_t key1, float* L3) {
+	if (!c || !cam || !pix || !smp || !L3) return TUTU_E_INVALID;
+	if (n == 0) return TUTU_OK;
+	for (uint32_t i = 0; i < n; i++)
+		if (pix[i] >= (uint32_t)(cam->width * cam->height)) return TUTU_E_INVALID;
+	HIP_TRY(hipSetDevice(c->device));
+	hipStream_t s = c->stream;
+	int rc = ensure_work(c, n, n);
+	if (rc != TUTU_OK) return rc;
+	if ((rc = c->u32a.ensure(n)) != TUTU_OK) return rc;
+	if ((rc = c->u32b.ensure(n)) != TUTU_OK) return rc;
+	if ((rc = c->out_stage.ensure(3 * (size_t)n)) != TUTU_OK) return rc;
+	HIP_TRY(hipMemcpyAsync(c->u32a.p, pix, sizeof(uint32_t) * n, hipMemcpyHostToDevice, s));
+	HIP_TRY(hipMemcpyAsync(c->u32b.p, smp, sizeof(uint32_t) * n, hipMemcpyHostToDevice, s));
+	c->ev_used = 0;
+	HIP_TRY(hipMemsetAsync(c->totals.p, 0, sizeof(Totals), s));
+	if ((rc = launch_primary(c, s, cam, (int)n, nullptr, c->u32a.p, 0, 0, 1)) != TUTU_OK) return rc;
+	uint32_t tl = 0;
+	if ((rc = run_pass(c, s, cam, key0, key1, (int)n, 0, 1, c->u32b.p, &tl)) != TUTU_OK) return rc;
+	hipLaunchKernelGGL(k_copy_L, dim3((n + 255) / 256), dim3(256), 0, s, c->Lout.p, c->out_stage.p, (int)n);
+	HIP_TRY(hipGetLastError());
+	HIP_TRY(hipStreamSynchronize(s));
+	c->ev_used = 0;
+	HIP_TRY(hipMemcpy(L3, c->out_stage.p, sizeof(float) * 3 * (size_t)n, hipMemcpyDeviceToHost));
+	return TUTU_OK;
+}
+
+}  // extern "C"
+
+// ---------------------------------------------------------------------------------------------------------
+// kernel-level parity entry points
+namespace {
+
+__global__ void __launch_bounds__(256) k_test_closest(SceneDev sc, const float* o, const float* d, uint32_t n, TutuHit* hits) {
+	__shared__ int stack[TUTU_STACK_DEPTH * 256];
+	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n) return;
+	float t, u, v;
+	int tri;
+	trace_closest(sc, ld3(o + 3 * (size_t)i), ld3(d + 3 * (size_t)i), stack + threadIdx.x, 256, t, u, v, tri);
+	TutuHit h;
+	h.t = t;
+	h.b1 = u;
+	h.b2 = v;
+	h.tri = tri >= 0 ? __float_as_int(sc.tri_shade[3 * tri + 2].z) : -1;  // back to the caller's triangle index
+	hits[i] = h;
+}
+
+__global__ void __launch_bounds__(256) k_test_any(SceneDev sc, const float* o, const float* tgt, uint32_t n, uint8_t* blocked) {
+	__shared__ int stack[TUTU_STACK_DEPTH * 256];
+	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n) return;
+	blocked[i] = trace_any(sc, ld3(o + 3 * (size_t)i), ld3(tgt + 3 * (size_t)i), stack + threadIdx.x, 256) ? 1 : 0;
+}
+
+TUTU_DEV Mat mat_from_abi(const TutuMaterial& m) {
+	Mat r;
+	r.diffuse = mk(m.diffuse[0], m.diffuse[1], m.diffuse[2]);
+	r.emission = mk(m.emission[0], m.emission[1], m.emission[2]);
+	r.type = m.type;
+	r.has_emission = (m.emission[0] || m.emission[1] || m.emission[2]) ? 1 : 0;
+	r.alpha = m.alpha;
+	r.eta = m.eta;
+	r.roughness = m.roughness;
+	r.metallic = m.metallic;
+	return r;
+}
+
+__global__ void k_test_bxdf(TutuMaterial m, const float* wi, const float* wo, const float* Ng, const float* Ns, float eta_scene,
+                            const uint8_t* tir, uint32_t n, float* out3) {
+	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n) return;
+	const Mat mm = mat_from_abi(m);
+	const V3 r = BxDF(mm, ld3(wi + 3 * (size_t)i), ld3(wo + 3 * (size_t)i), ld3(Ng + 3 * (size_t)i), ld3(Ns + 3 * (size_t)i), eta_scene,
+	                  tir ? tir[i] != 0 : false);
+	out3[3 * (size_t)i + 0] = r.x;
+	out3[3 * (size_t)i + 1] = r.y;
+	out3[3 * (size_t)i + 2] = r.z;
+}
+
+__global__ void k_test_pdf(TutuMaterial m, const float* wi, const float* wo, const float* N, float eta_i, float eta_t, uint32_t n, float* out) {
+	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n) return;
+	const Mat mm = mat_from_abi(m);
+	out[i] = mat_pdf(mm, ld3(wi + 3 * (size_t)i), ld3(wo + 3 * (size_t)i), ld3(N + 3 * (size_t)i), eta_i, eta_t);
+}
+
+__global__ void k_test_sample(TutuMaterial m, const float* wo, const float* N, float eta_i, const float* xi3, uint32_t n, float* wi,
+                              uint8_t* okv, uint8_t* spv, int32_t* nd) {
+	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n) return;
+	Mat mm = mat_from_abi(m);
+	Rng rng;
+	rng.init(0, 0, 0, 0, 0);
+	rng.inj = xi3 + 3 * (size_t)i;
+	V3 res = mk1(0.f);
+	bool ok, sp;
+	sampleDirection(mm, ld3(wo + 3 * (size_t)i), ld3(N + 3 * (size_t)i), res, eta_i, rng, ok, sp);
+	wi[3 * (size_t)i + 0] = res.x;
+	wi[3 * (size_t)i + 1] = res.y;
+	wi[3 * (size_t)i + 2] = res.z;
+	okv[i] = ok ? 1 : 0;
+	spv[i] = sp ? 1 : 0;
+	nd[i] = (int32_t)rng.draw;
+}
+
+__global__ void k_test_sample_light(SceneDev sc, const float* xi3, uint32_t n, int32_t* tri, float* pos, float* nrm, float* pdf) {
+	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n) return;
+	if (sc.n_lights <= 0) {
+		tri[i] = -1;
+		pdf[i] = 0.f;
+		return;
+	}
+	Rng rng;
+	rng.init(0, 0, 0, 0, 0);
+	rng.inj = xi3 + 3 * (size_t)i;
+	const LightSample ls = sample_light(sc, rng);
+	tri[i] = __float_as_int(sc.tri_shade[3 * ls.tri + 2].z);
+	pos[3 * (size_t)i + 0] = ls.pos.x; pos[3 * (size_t)i + 1] = ls.pos.y; pos[3 * (size_t)i + 2] = ls.pos.z;
+	nrm[3 * (size_t)i + 0] = ls.N.x; nrm[3 * (size_t)i + 1] = ls.N.y; nrm[3 * (size_t)i + 2] = ls.N.z;
+	pdf[i] = ls.pdf;
+}
+
+// scratch device copies for the test entry points
+struct Scratch {
+	std::vector<void*> ptrs;
+	~Scratch() {
+		for (void* p : ptrs) (void)hipFree(p);
+	}
+	template <typename T>
+	int up(const T* host, size_t n, T** dev) {
+		*dev = nullptr;
+		if (!host) return TUTU_OK;
+		HIP_TRY(hipMalloc((void**)dev, std::max<size_t>(1, n) * sizeof(T)));
+		ptrs.push_back(*dev);
+		HIP_TRY(hipMemcpy(*dev, host, n * sizeof(T), hipMemcpyHostToDevice));
+		return TUTU_OK;
+	}
+	template <typename T>
+	int alloc(size_t n, T** dev) {
+		HIP_TRY(hipMalloc((void**)dev, std::max<size_t>(1, n) * sizeof(T)));
+		ptrs.push_back(*dev);
+		return TUTU_OK;
+	}
+};
+
+#define RC(x)                       \
+	do {                            \
+		int _r = (x);               \
+		if (_r != TUTU_OK) return _r; \
+	} while (0)
+
+}  // namespace
+
+extern "C" {
+
+int tutu_hip_trace_closest(TutuCtx* c, uint32_t n, const float* orig, const float* dir, TutuHit* hits) {
+	if (!c || !orig || !dir || !hits) return TUTU_E_INVALID;
+	if (n == 0) return TUTU_OK;
+	HIP_TRY(hipSetDevice(c->device));
+	Scratch sc;
+	float *d_o, *d_d;
+	TutuHit* d_h;
+	RC(sc.up(orig, 3 * (size_t)n, &d_o));
+	RC(sc.up(dir, 3 * (size_t)n, &d_d));
+	RC(sc.alloc((size_t)n, &d_h));
+	hipLaunchKernelGGL(k_test_closest, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->sc, d_o, d_d, n, d_h);
+	HIP_TRY(hipGetLastError());
+	HIP_TRY(hipStreamSynchronize(c->stream));
+	HIP_TRY(hipMemcpy(hits, d_h, sizeof(TutuHit) * (size_t)n, hipMemcpyDeviceToHost));
+	return TUTU_OK;
+}
+
+int tutu_hip_trace_any(TutuCtx* c, uint32_t n, const float* orig, const float* target, uint8_t* blocked) {
+	if (!c || !orig || !target || !blocked) return TUTU_E_INVALID;
+	if (n == 0) return TUTU_OK;
+	HIP_TRY(hipSetDevice(c->device));
+	Scratch sc;
+	float *d_o, *d_t;
+	uint8_t* d_b;
+	RC(sc.up(orig, 3 * (size_t)n, &d_o));
+	RC(sc.up(target, 3 * (size_t)n, &d_t));
+	RC(sc.alloc((size_t)n, &d_b));
+	hipLaunchKernelGGL(k_test_any, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->sc, d_o, d_t, n, d_b);
+	HIP_TRY(hipGetLastError());
+	HIP_TRY(hipStreamSynchronize(c->stream));
+	HIP_TRY(hipMemcpy(blocked, d_b, (size_t)n, hipMemcpyDeviceToHost));
+	return TUTU_OK;
+}
+
+int tutu_hip_eval_bxdf(TutuCtx* c, uint32_t n, const TutuMaterial* m, const float* wi, const float* wo, const float* Ng,
+                       const float* Ns, float eta_scene, const uint8_t* tir, float* out3) {
+	if (!c || !m || !wi || !wo || !Ng || !Ns || !out3) return TUTU_E_INVALID;
+	if (n == 0) return TUTU_OK;
+	HIP_TRY(hipSetDevice(c->device));
+	Scratch sc;
+	float *d_wi, *d_wo, *d_ng, *d_ns, *d_out;
+	uint8_t* d_tir;
+	RC(sc.up(wi, 3 * (size_t)n, &d_wi));
+	RC(sc.up(wo, 3 * (size_t)n, &d_wo));
+	RC(sc.up(Ng, 3 * (size_t)n, &d_ng));
+	RC(sc.up(Ns, 3 * (size_t)n, &d_ns));
+	RC(sc.up(tir, (size_t)n, &d_tir));
+	RC(sc.alloc(3 * (size_t)n, &d_out));
+	hipLaunchKernelGGL(k_test_bxdf, dim3((n + 255) / 256), dim3(256), 0, c->stream, *m, d_wi, d_wo, d_ng, d_ns, eta_scene, d_tir, n, d_out);
+	HIP_TRY(hipGetLastError());
+	HIP_TRY(hipStreamSynchronize(c->stream));
+	HIP_TRY(hipMemcpy(out3, d_out, sizeof(float) * 3 * (size_t)n, hipMemcpyDeviceToHost));
+	return TUTU_OK;
+}
+
+int tutu_hip_eval_pdf(TutuCtx* c, uint32_t n, const TutuMaterial* m, const float* wi, const float* wo, const float* N, float eta_i,
+                      float eta_t, float* out) {
+	if (!c || !m || !wi || !wo || !N || !out) return TUTU_E_INVALID;
+	if (n == 0) return TUTU_OK;
+	HIP_TRY(hipSetDevice(c->device));
+	Scratch sc;
+	float *d_wi, *d_wo, *d_n, *d_out;
+	RC(sc.up(wi, 3 * (size_t)n, &d_wi));
+	RC(sc.up(wo, 3 * (size_t)n, &d_wo));
+	RC(sc.up(N, 3 * (size_t)n, &d_n));
+	RC(sc.alloc((size_t)n, &d_out));
+	hipLaunchKernelGGL(k_test_pdf, dim3((n + 255) / 256), dim3(256), 0, c->stream, *m, d_wi, d_wo, d_n, eta_i, eta_t, n, d_out);
+	HIP_TRY(hipGetLastError());
+	HIP_TRY(hipStreamSynchronize(c->stream));
+	HIP_TRY(hipMemcpy(out, d_out, sizeof(float) * (size_t)n, hipMemcpyDeviceToHost));
+	return TUTU_OK;
+}
+
+int tutu_hip_eval_sample(TutuCtx* c, uint32_t n, const TutuMaterial* m, const float* wo, const float* N, float eta_i, const float* xi3,
+                         float* wi, uint8_t* ok, uint8_t* special, int32_t* ndraws) {
+	if (!c || !m || !wo || !N || !xi3 || !wi || !ok || !special || !ndraws) return TUTU_E_INVALID;
+	if (n == 0) return TUTU_OK;
+	HIP_TRY(hipSetDevice(c->device));
+	Scratch sc;
+	float *d_wo, *d_n, *d_xi, *d_wi;
+	uint8_t *d_ok, *d_sp;
+	int32_t* d_nd;
+	RC(sc.up(wo, 3 * (size_t)n, &d_wo));
+	RC(sc.up(N, 3 * (size_t)n, &d_n));
+	RC(sc.up(xi3, 3 * (size_t)n, &d_xi));
+	RC(sc.alloc(3 * (size_t)n, &d_wi));
+	RC(sc.alloc((size_t)n, &d_ok));
+	RC(sc.alloc((size_t)n, &d_sp));
+	RC(sc.alloc((size_t)n, &d_nd));
+	HIP_TRY(hipMemset(d_wi, 0, sizeof(float) * 3 * (size_t)n));
+	hipLaunchKernelGGL(k_test_sample, dim3((n + 255) / 256), dim3(256), 0, c->stream, *m, d_wo, d_n, eta_i, d_xi, n, d_wi, d_ok, d_sp, d_nd);
+	HIP_TRY(hipGetLastError());
+	HIP_TRY(hipStreamSynchronize(c->stream));
+	HIP_TRY(hipMemcpy(wi, d_wi, sizeof(float) * 3 * (size_t)n, hipMemcpyDeviceToHost));
+	HIP_TRY(hipMemcpy(ok, d_ok, (size_t)n, hipMemcpyDeviceToHost));
+	HIP_TRY(hipMemcpy(special, d_sp, (size_t)n, hipMemcpyDeviceToHost));
+	HIP_TRY(hipMemcpy(ndraws, d_nd, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost));
+	return TUTU_OK;
+}
+
+int tutu_hip_eval_sample_light(TutuCtx* c, uint32_t n, const float* xi3, int32_t* tri, float* pos, float* nrm, float* pdf) {
+	if (!c || !xi3 || !tri || !pos || !nrm || !pdf) return TUTU_E_INVALID;
+	if (n == 0) return TUTU_OK;
+	HIP_TRY(hipSetDevice(c->device));
+	Scratch sc;
+	float *d_xi, *d_pos, *d_nrm, *d_pdf;
+	int32_t* d_tri;
+	RC(sc.up(xi3, 3 * (size_t)n, &d_xi));
+	RC(sc.alloc((size_t)n, &d_tri));
+	RC(sc.alloc(3 * (size_t)n, &d_pos));
+	RC(sc.alloc(3 * (size_t)n, &d_nrm));
+	RC(sc.alloc((size_t)n, &d_pdf));
+	HIP_TRY(hipMemset(d_pos, 0, sizeof(float) * 3 * (size_t)n));
+	HIP_TRY(hipMemset(d_nrm, 0, sizeof(float) * 3 * (size_t)n));
+	hipLaunchKernelGGL(k_test_sample_light, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->sc, d_xi, n, d_tri, d_pos, d_nrm, d_pdf);
+	HIP_TRY(hipGetLastError());
+	HIP_TRY(hipStreamSynchronize(c->stream));
+	HIP_TRY(hipMemcpy(tri, d_tri, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost));
+	HIP_TRY(hipMemcpy(pos, d_pos, sizeof(float) * 3 * (size_t)n, hipMemcpyDeviceToHost));
+	HIP_TRY(hipMemcpy(nrm, d_nrm, sizeof(float) * 3 * (size_t)n, hipMemcpyDeviceToHost));
+	HIP_TRY(hipMemcpy(pdf, d_pdf, sizeof(float) * (size_t)n, hipMemcpyDeviceToHost));
+	return TUTU_OK;
+}
+
+}  // extern "C"
