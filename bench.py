@@ -1,0 +1,208 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the MI355X path-tracing integrator.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`)
+
+Workload (BASELINE.json configs[1]): Cornell box 800x800, 512 spp, PathTracing + NEE + MIS, synthetic scene data
+restated from the reference's scene program.  One "step" = one complete render of the frame: every pixel, all 512
+samples, plus (N > 1) the gather of the per-rank pixel sets to rank 0.  Scene, BVH and work buffers are resident in
+HBM before the timed region.  Pixel tiles (32x32, round-robin over ranks) shard the frame; the total work is
+fixed, so the scaling is "strong".
+
+Prints ONE JSON line on rank 0:  metric = Msamples/s (= width*height*spp / wall-seconds), plus
+  roofline     -- the dominant kernel, priced in ALGORITHMIC bytes (per ray = 32 B ray + 16 B hit
+                  + N*32 B nodes entered + T*48 B triangle tests, N and T from the CPU restatement's counters)
+                  over its average launch duration measured with HIP events on the library's stream;
+  cpu_baseline -- the reference's own integrator (oracle/_ref, kind "reference"; falls back to the CPU restatement,
+                  kind "port") timed on this box's host cores on a bounded sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+KEY0, KEY1 = 0x5EED0001, 2  # Philox key: (seed_lo, config id)
+TILE = 32
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def tile_pixel_lists(W, H, n_ranks, tile=TILE):
+    """Pixel indices (y*W+x) per rank: 32x32 tiles dealt round-robin; inside a tile, 8x8 blocks so that the 64
+    lanes of a wave cover a compact patch."""
+    lists = [[] for _ in range(n_ranks)]
+    t = 0
+    for ty in range(0, H, tile):
+        for tx in range(0, W, tile):
+            ys = np.arange(ty, min(ty + tile, H))
+            xs = np.arange(tx, min(tx + tile, W))
+            blk = []
+            for by in range(0, len(ys), 8):
+                for bx in range(0, len(xs), 8):
+                    yy, xx = np.meshgrid(ys[by:by + 8], xs[bx:bx + 8], indexing="ij")
+                    blk.append((yy * W + xx).ravel())
+            lists[t % n_ranks].append(np.concatenate(blk))
+            t += 1
+    return [np.concatenate(l).astype(np.int32) if l else np.zeros(0, np.int32) for l in lists]
+
+
+def cpu_baseline(scene, target_seconds=12.0):
+    """Time the reference integrator on the host cores: a first 4-spp frame calibrates, then one frame with as many
+    spp as fit ~target_seconds.  Only this function touches oracle/."""
+    from oracle.pyoracle import Oracle, available
+
+    kind = "reference" if available("reference") else "port"
+    S = Oracle(kind).scene(scene)
+    cores = os.cpu_count() or 1
+    W, H = int(scene["width"]), int(scene["height"])
+    t0 = time.perf_counter()
+    S.render(4, KEY0, KEY1, nthreads=cores)
+    t_cal = time.perf_counter() - t0
+    spp = int(max(4, min(512, round(4 * target_seconds / max(t_cal, 1e-3)))))
+    t0 = time.perf_counter()
+    S.render(spp, KEY0, KEY1, nthreads=cores)
+    dt = time.perf_counter() - t0
+    S.close()
+    return {"value": W * H * spp / dt / 1e6, "unit": "Msamples/s", "cores": cores, "kind": kind,
+            "sample": f"cornell box {W}x{H}, {spp} spp of 512 (same scene, camera and Philox key), {cores} host threads, "
+                      f"{dt:.1f} s; RNG = Philox stream injected into the reference's getRandomFloat"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--spp", type=int, default=512)
+    ap.add_argument("--width", type=int, default=800)
+    ap.add_argument("--height", type=int, default=800)
+    ap.add_argument("--max-paths", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dump", type=str, default="")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    import tuturenderer_amd as tr
+    from tuturenderer_amd import scenes
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N")
+    distributed = world > 1
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if distributed:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)
+
+    W, H, spp = args.width, args.height, args.spp
+    scene = scenes.cornell_box(W, H)
+    lists = tile_pixel_lists(W, H, world)
+    mine = lists[rank]
+    n_max = max(len(l) for l in lists)
+    ctx = tr.Context(scene, device=local_rank)
+    out = torch.zeros((n_max, 3), dtype=torch.float32, device=dev)
+    frame = torch.zeros((H * W, 3), dtype=torch.float32, device=dev) if rank == 0 else None
+    gather_list = [torch.zeros_like(out) for _ in range(world)] if (distributed and rank == 0) else None
+    idx_dev = [torch.from_numpy(l.astype(np.int64)).to(dev) for l in lists] if rank == 0 else None
+    torch.cuda.synchronize()  # the library renders on its own stream: torch's allocation fills must have landed
+
+    def step():
+        ctx.render_device(out.data_ptr(), spp, KEY0, KEY1, pixels=mine, max_paths=args.max_paths)
+        if distributed:
+            dist.gather(out, gather_list, dst=0)  # the one collective: RCCL gather of the framebuffer pieces
+            if rank == 0:
+                for r in range(world):
+                    frame.index_copy_(0, idx_dev[r], gather_list[r][: len(lists[r])])
+        else:
+            frame.index_copy_(0, idx_dev[0], out[: len(mine)])
+        return ctx.last_stats
+
+    def fence():
+        if distributed:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    agg = {"ms_trace_closest": 0.0, "ms_trace_any": 0.0, "ms_shade": 0.0, "ms_other": 0.0, "trace_launches": 0, "closest_rays": 0,
+           "shadow_rays": 0, "passes": 0}
+    for _ in range(args.steps):
+        st = step()
+        for k in agg:
+            agg[k] += st[k]
+    fence()
+    dt = time.perf_counter() - t0
+    if distributed:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+
+    if rank == 0:
+        total_samples = W * H * spp * args.steps
+        value = total_samples / dt / 1e6
+        counters = json.load(open(os.path.join(ROOT, "tuturenderer_amd", "scenes", "workload_counters.json")))
+        wc = counters.get(f"cornell_{W}x{H}", counters["cornell_800x800"])
+        # per-kernel algorithmic bytes per unit (the 288 B of state per segment split by stage)
+        per_unit = {
+            "k_trace_closest": 32 + 16 + wc["N_closest"] * 32 + wc["T_closest"] * 48,  # per closest-hit ray
+            "k_trace_any": 48 + wc["N_shadow"] * 32 + wc["T_shadow"] * 48,            # per shadow ray
+            "k_shade": 192.0,                                                          # per segment
+        }
+        prim = len(mine) * args.steps  # primary rays go through k_primary, not the queue kernel
+        units = {"k_trace_closest": agg["closest_rays"] - prim, "k_trace_any": agg["shadow_rays"], "k_shade": agg["closest_rays"]}
+        ms = {"k_trace_closest": agg["ms_trace_closest"], "k_trace_any": agg["ms_trace_any"], "k_shade": agg["ms_shade"]}
+        dom = max(ms, key=ms.get)
+        launches = agg["trace_launches"] if dom != "k_shade" else agg["trace_launches"] + agg["passes"]
+        achieved = units[dom] * per_unit[dom] / (ms[dom] * 1e-3) / 1e9  # GB/s
+        traffic = None
+        prof = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(prof):
+            traffic = json.load(open(prof)).get(dom)
+        roofline = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                    "algorithmic_bytes_per_unit": per_unit[dom], "units_per_launch": units[dom] / max(launches, 1),
+                    "avg_launch_ms": ms[dom] / max(launches, 1), "launches": launches,
+                    "kernel_ms_per_step": {k: v / args.steps for k, v in ms.items()},
+                    "pipeline_B_sample": wc["B_sample_bytes_at_512spp"],
+                    "pipeline_frac": value * 1e6 * wc["B_sample_bytes_at_512spp"] / (HBM_PEAK_GBS * 1e9)}
+        line = {
+            "metric": "Msamples/sec (rays traced/sec) + wall-clock to 512spp, Cornell box 800x800",
+            "value": value, "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"cornell box {W}x{H}, {spp} spp, PathTracing+NEE+MIS (BASELINE configs[1])",
+                       "pixel_tiles": f"{TILE}x{TILE} round-robin over {world} rank(s)", "philox_key": [KEY0, KEY1],
+                       "wall_clock_to_512spp_s": dt / args.steps if spp == 512 else None,
+                       "rays_per_s": (agg["closest_rays"] + agg["shadow_rays"]) * world / dt if world == 1 else None},
+            "roofline": roofline,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(scene)
+        else:
+            line["cpu_baseline"] = None
+        if args.dump:
+            np.save(args.dump, frame.cpu().numpy().reshape(H, W, 3))
+        print(json.dumps(line), flush=True)
+    ctx.close()
+    if distributed:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

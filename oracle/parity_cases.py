@@ -180,7 +180,7 @@ def material_inputs(n=6000, seed=104):
     return Ng, Ns, wo, wi, tir, xi
 
 
-def run_material(O, name, mat):
+def run_material(O, name, mat, s_wi_at=None):
     Ng, Ns, wo, wi, tir, xi = material_inputs()
     n = len(Ng)
     out = {}
@@ -204,7 +204,9 @@ def run_material(O, name, mat):
     out["s_special"] = sp
     out["s_ndraws"] = nd
     # pdf / bxdf at the sampled direction (what the integrator evaluates)
-    swi_n = O.normalized(out["s_wi"])
+    # (a device under test evaluates them at the GOLDEN sampled direction, s_wi_at, so that the comparison sees the
+    # function's own error and not the GGX lobe's huge sensitivity to a last-bit difference in its input)
+    swi_n = O.normalized(out["s_wi"] if s_wi_at is None else s_wi_at)
     out["s_pdf"] = O.mat_pdf(mat, swi_n, wo, Ns, 1.0, float(mat["eta"]))
     out["s_bxdf"] = O.mat_bxdf(mat, swi_n, wo, Ng, Ns, 1.0, tir=None)
     out["in_crc"] = checksum(Ng, Ns, wo, wi, tir, xi)

@@ -331,6 +331,22 @@ class OracleScene:
         self.lib.tor_trace_samples(self.h, C.c_int(n), _p(pix), _p(smp), C.c_uint32(key0), C.c_uint32(key1), _p(L), _p(nd), _p(nc))
         return (L, nd, nc) if stats else L
 
+    def path_stats(self, pix, smp, key0, key1, ordered=True):
+        """port only: work counters of the ordered, t-pruned traversal (the HIP kernels' algorithm) over the given
+        samples -- SURVEY.md 8(d)'s segs / rays / N / T."""
+        assert self.o.kind == "port"
+        pix = np.ascontiguousarray(pix, dtype=np.uint32)
+        smp = np.ascontiguousarray(smp, dtype=np.uint32)
+        out = np.zeros(8, np.int64)
+        self.lib.tor_port_set_ordered(self.h, C.c_int(1 if ordered else 0))
+        self.lib.tor_port_path_stats(self.h, C.c_int(len(pix)), _p(pix), _p(smp), C.c_uint32(key0), C.c_uint32(key1), _p(out))
+        self.lib.tor_port_set_ordered(self.h, C.c_int(0))
+        n, segs, closest, shadow, nodes, tris, nodes_sh, tris_sh = [int(x) for x in out]
+        return {"samples": n, "segs": segs / n, "closest": closest / n, "shadow": shadow / n,
+                "N_closest": (nodes - nodes_sh) / max(closest, 1), "T_closest": (tris - tris_sh) / max(closest, 1),
+                "N_shadow": nodes_sh / max(shadow, 1), "T_shadow": tris_sh / max(shadow, 1),
+                "N_all": nodes / max(closest + shadow, 1), "T_all": tris / max(closest + shadow, 1)}
+
     def render(self, spp, key0, key1, rect=None, nthreads=None):
         if rect is None:
             rect = (0, 0, self.W, self.H)

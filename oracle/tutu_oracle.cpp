@@ -551,6 +551,7 @@ struct Node { // BVH.hpp:15-23
 
 struct Counters {
 	int64_t segs = 0, closest = 0, shadow = 0, nodes = 0, tris = 0;
+	int64_t nodes_shadow = 0, tris_shadow = 0;  // the share of nodes/tris spent on shadow rays
 };
 
 struct Scene {
@@ -658,7 +659,6 @@ struct Scene {
 		Hit best;
 		int best_order = 0x7fffffff;
 		if (nodes.empty()) return best;
-		if (c) c->nodes++;
 		float te;
 		if (!box_intersect(nodes[0].bound, o, d, &te)) return best;
 		int stack[64];
@@ -666,6 +666,7 @@ struct Scene {
 		int cur = 0;
 		for (;;) {
 			const Node& n = nodes[cur];
+			if (c) c->nodes++;  // a node ENTERED (its box was hit and it survived pruning): SURVEY.md 8(d)'s N
 			if (n.left < 0 && n.right < 0) {
 				if (n.tri >= 0) {
 					if (c) c->tris++;
@@ -680,7 +681,6 @@ struct Scene {
 				}
 			} else {
 				float tl = 0.f, tr = 0.f;
-				if (c) c->nodes += 2;
 				bool hl = box_intersect(nodes[n.left].bound, o, d, &tl);
 				bool hr = box_intersect(nodes[n.right].bound, o, d, &tr);
 				const float lim = best.intersected ? prune_slack(best.t) : FLT_MAX;
@@ -710,13 +710,13 @@ struct Scene {
 	}
 	bool any_ordered(const V3& o, const V3& d, float dis, Counters* c) const {
 		if (nodes.empty()) return false;
-		if (c) c->nodes++;
 		if (!box_intersect(nodes[0].bound, o, d)) return false;
 		int stack[64];
 		int sp = 0;
 		int cur = 0;
 		for (;;) {
 			const Node& n = nodes[cur];
+			if (c) c->nodes++;  // a node ENTERED (its box was hit and it survived pruning): SURVEY.md 8(d)'s N
 			if (n.left < 0 && n.right < 0) {
 				if (n.tri >= 0) {
 					if (c) c->tris++;
@@ -726,7 +726,6 @@ struct Scene {
 				}
 			} else {
 				float tl = 0.f, tr = 0.f;
-				if (c) c->nodes += 2;
 				bool hl = box_intersect(nodes[n.left].bound, o, d, &tl);
 				bool hr = box_intersect(nodes[n.right].bound, o, d, &tr);
 				const float lim = prune_slack(dis);
@@ -759,7 +758,13 @@ struct Scene {
 		if (c) c->shadow++;
 		V3 raydir = normalized(lightPos - orig);
 		float distance = norm(lightPos - orig);
-		return ordered ? any_ordered(orig, raydir, distance, c) : hasIntersection(0, orig, raydir, distance, c);
+		const int64_t n0 = c ? c->nodes : 0, t0 = c ? c->tris : 0;
+		const bool blocked = ordered ? any_ordered(orig, raydir, distance, c) : hasIntersection(0, orig, raydir, distance, c);
+		if (c) {
+			c->nodes_shadow += c->nodes - n0;
+			c->tris_shadow += c->tris - t0;
+		}
+		return blocked;
 	}
 	// IIntegrator.hpp:155-168
 	float getLightPdf(const Hit& inter) const {
@@ -1297,7 +1302,8 @@ int tor_port_trace_samples_forward(void* h, int n, const uint32_t* pix, const ui
 	}
 	return 0;
 }
-// counters over n samples: out = {samples, segs, closest rays, shadow rays, nodes entered, triangle tests}
+// counters over n samples: out = {samples, segs, closest rays, shadow rays, nodes entered, triangle tests,
+// nodes entered by shadow rays, triangle tests by shadow rays}
 int tor_port_path_stats(void* h, int n, const uint32_t* pix, const uint32_t* smp, uint32_t key0, uint32_t key1,
                         int64_t* out6) {
 	Scene* s = (Scene*)h;
@@ -1309,6 +1315,7 @@ int tor_port_path_stats(void* h, int n, const uint32_t* pix, const uint32_t* smp
 		s->trace_sample(dir, r, &c);
 	}
 	out6[0] = n; out6[1] = c.segs; out6[2] = c.closest; out6[3] = c.shadow; out6[4] = c.nodes; out6[5] = c.tris;
+	out6[6] = c.nodes_shadow; out6[7] = c.tris_shadow;
 	return 0;
 }
 

@@ -678,7 +678,7 @@ int tutu_hip_eval_sample(TutuCtx* c, uint32_t n, const TutuMaterial* m, const fl
 	RC(sc.alloc((size_t)n, &d_ok));
 	RC(sc.alloc((size_t)n, &d_sp));
 	RC(sc.alloc((size_t)n, &d_nd));
-	HIP_TRY(hipMemset(d_wi, 0, sizeof(float) * 3 * (size_t)n));
+	HIP_TRY(hipMemsetAsync(d_wi, 0, sizeof(float) * 3 * (size_t)n, c->stream));
 	hipLaunchKernelGGL(k_test_sample, dim3((n + 255) / 256), dim3(256), 0, c->stream, *m, d_wo, d_n, eta_i, d_xi, n, d_wi, d_ok, d_sp, d_nd);
 	HIP_TRY(hipGetLastError());
 	HIP_TRY(hipStreamSynchronize(c->stream));
@@ -701,8 +701,8 @@ int tutu_hip_eval_sample_light(TutuCtx* c, uint32_t n, const float* xi3, int32_t
 	RC(sc.alloc(3 * (size_t)n, &d_pos));
 	RC(sc.alloc(3 * (size_t)n, &d_nrm));
 	RC(sc.alloc((size_t)n, &d_pdf));
-	HIP_TRY(hipMemset(d_pos, 0, sizeof(float) * 3 * (size_t)n));
-	HIP_TRY(hipMemset(d_nrm, 0, sizeof(float) * 3 * (size_t)n));
+	HIP_TRY(hipMemsetAsync(d_pos, 0, sizeof(float) * 3 * (size_t)n, c->stream));
+	HIP_TRY(hipMemsetAsync(d_nrm, 0, sizeof(float) * 3 * (size_t)n, c->stream));
 	hipLaunchKernelGGL(k_test_sample_light, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->sc, d_xi, n, d_tri, d_pos, d_nrm, d_pdf);
 	HIP_TRY(hipGetLastError());
 	HIP_TRY(hipStreamSynchronize(c->stream));
