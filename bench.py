@@ -30,27 +30,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 KEY0, KEY1 = 0x5EED0001, 2  # Philox key: (seed_lo, config id)
-TILE = 32
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
-
-
-def tile_pixel_lists(W, H, n_ranks, tile=TILE):
-    """Pixel indices (y*W+x) per rank: 32x32 tiles dealt round-robin; inside a tile, 8x8 blocks so that the 64
-    lanes of a wave cover a compact patch."""
-    lists = [[] for _ in range(n_ranks)]
-    t = 0
-    for ty in range(0, H, tile):
-        for tx in range(0, W, tile):
-            ys = np.arange(ty, min(ty + tile, H))
-            xs = np.arange(tx, min(tx + tile, W))
-            blk = []
-            for by in range(0, len(ys), 8):
-                for bx in range(0, len(xs), 8):
-                    yy, xx = np.meshgrid(ys[by:by + 8], xs[bx:bx + 8], indexing="ij")
-                    blk.append((yy * W + xx).ravel())
-            lists[t % n_ranks].append(np.concatenate(blk))
-            t += 1
-    return [np.concatenate(l).astype(np.int32) if l else np.zeros(0, np.int32) for l in lists]
 
 
 def cpu_baseline(scene, target_seconds=12.0):
@@ -109,25 +89,16 @@ def main():
 
     W, H, spp = args.width, args.height, args.spp
     scene = scenes.cornell_box(W, H)
-    lists = tile_pixel_lists(W, H, world)
-    mine = lists[rank]
-    n_max = max(len(l) for l in lists)
+    from tuturenderer_amd.dist import TILE, FrameGather
+
     ctx = tr.Context(scene, device=local_rank)
-    out = torch.zeros((n_max, 3), dtype=torch.float32, device=dev)
-    frame = torch.zeros((H * W, 3), dtype=torch.float32, device=dev) if rank == 0 else None
-    gather_list = [torch.zeros_like(out) for _ in range(world)] if (distributed and rank == 0) else None
-    idx_dev = [torch.from_numpy(l.astype(np.int64)).to(dev) for l in lists] if rank == 0 else None
+    fg = FrameGather(W, H, rank, world, dev)
+    mine = fg.mine
     torch.cuda.synchronize()  # the library renders on its own stream: torch's allocation fills must have landed
 
     def step():
-        ctx.render_device(out.data_ptr(), spp, KEY0, KEY1, pixels=mine, max_paths=args.max_paths)
-        if distributed:
-            dist.gather(out, gather_list, dst=0)  # the one collective: RCCL gather of the framebuffer pieces
-            if rank == 0:
-                for r in range(world):
-                    frame.index_copy_(0, idx_dev[r], gather_list[r][: len(lists[r])])
-        else:
-            frame.index_copy_(0, idx_dev[0], out[: len(mine)])
+        ctx.render_device(fg.piece.data_ptr(), spp, KEY0, KEY1, pixels=mine, max_paths=args.max_paths)
+        fg.assemble()  # N > 1: the one collective, an RCCL gather of the framebuffer pieces to rank 0
         return ctx.last_stats
 
     def fence():
@@ -196,7 +167,7 @@ def main():
         else:
             line["cpu_baseline"] = None
         if args.dump:
-            np.save(args.dump, frame.cpu().numpy().reshape(H, W, 3))
+            np.save(args.dump, fg.frame.cpu().numpy().reshape(H, W, 3))
         print(json.dumps(line), flush=True)
     ctx.close()
     if distributed:

@@ -1,0 +1,38 @@
+// Host-only check tool (no GPU call): parses a config with the front-end, loads the OBJ files named on the command
+// line with the front-end's OBJ reader + loadObj, and dumps what the integrator would hand to the GPU library, so
+// tests can compare it with the golden dumps of the reference's own loader.
+//   host_check <config.txt> <out.bin> [obj ...]
+// out.bin: int32 width,height,hfov,integrateType,n_tris ; float eye[3],viewdir[3],updir[3],bkg[3],eta ;
+//          n_tris*9 float verts ; n_tris*9 float normals ; 256 x int32 quantise() of a 0..1 ramp
+#include <cstdio>
+
+#include "../host/tutu_renderer.hpp"
+
+int main(int argc, char* argv[]) {
+	if (argc < 3) return 2;
+	PPMGenerator g(argv[1]);
+	Material m;
+	for (int i = 3; i < argc; i++) {
+		objl::Loader l;
+		if (l.LoadFile(argv[i])) g.loadObj(l, m);
+	}
+	FILE* f = fopen(argv[2], "wb");
+	if (!f) return 3;
+	const int32_t head[5] = {g.width, g.height, g.hfov, g.integrateType, (int32_t)g.scene.objList.size()};
+	fwrite(head, sizeof(head), 1, f);
+	const float cam[13] = {g.eyePos.x, g.eyePos.y, g.eyePos.z, g.viewdir.x, g.viewdir.y, g.viewdir.z, g.updir.x, g.updir.y, g.updir.z,
+	                       g.bkgcolor.x, g.bkgcolor.y, g.bkgcolor.z, g.eta};
+	fwrite(cam, sizeof(cam), 1, f);
+	for (int pass = 0; pass < 2; pass++)
+		for (auto& o : g.scene.objList) {
+			const Triangle* t = static_cast<const Triangle*>(o.get());
+			const Vector3f* p[3] = {pass == 0 ? &t->v0 : &t->n0, pass == 0 ? &t->v1 : &t->n1, pass == 0 ? &t->v2 : &t->n2};
+			for (int k = 0; k < 3; k++) fwrite(&p[k]->x, sizeof(float), 3, f);
+		}
+	for (int i = 0; i < 256; i++) {
+		const int32_t q = (int32_t)PPMGenerator::quantise(-0.1f + 1.3f * (float)i / 255.f);
+		fwrite(&q, sizeof(q), 1, f);
+	}
+	fclose(f);
+	return 0;
+}
