@@ -1,0 +1,36 @@
+#!/usr/bin/env python3
+"""Summarise rocprofv3 --pmc CSVs (one directory per counter group) per kernel: sum over dispatches of each counter,
+plus dispatch counts.   python profiles/pmc_summary.py gpurun_out/pmc_<tag>"""
+import csv
+import glob
+import json
+import sys
+from collections import defaultdict
+
+
+def short(name):
+    for k in ("k_trace_closest", "k_trace_any", "k_shade<true>", "k_shade<false>", "k_primary", "k_resolve", "k_finalize"):
+        if k in name:
+            return k
+    return None
+
+
+def main(root):
+    agg = defaultdict(lambda: defaultdict(float))
+    calls = defaultdict(lambda: defaultdict(set))
+    for f in glob.glob(f"{root}/g*/**/*counter_collection.csv", recursive=True):
+        for row in csv.DictReader(open(f)):
+            k = short(row["Kernel_Name"])
+            if not k:
+                continue
+            agg[k][row["Counter_Name"]] += float(row["Counter_Value"])
+            calls[k][row["Counter_Name"]].add(row["Dispatch_Id"])
+    out = {}
+    for k in agg:
+        out[k] = {c: v for c, v in sorted(agg[k].items())}
+        out[k]["_dispatches"] = max(len(s) for s in calls[k].values())
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == "__main__":
+    main(sys.argv[1])

@@ -6,20 +6,21 @@
 // One iteration d of the loop (host enqueues, no host sync inside a pass):
 //     shade(d)           connect vertex d-1 to the hit found for its BSDF ray (MIS-weighted emission or Russian
 //                        roulette), then shade vertex d: light sample -> shadow request, BSDF sample -> next ray
-//     trace_closest      extension rays of all surviving paths; writes the hit and files each path under the
-//                        material class of what it hit (sort by material)
+//     lists<FLAGS>       stable lists of the slots that continue / that have a shadow request (device_lists.h)
+//     trace_closest      extension rays of the continuing paths; writes the hit and its material class
 //     trace_any          shadow requests; an unblocked one adds its pre-multiplied contribution to the path
+//     lists<CLASS>       continuing slots sorted by material class -> the order shade(d+1) works in
 //
-// HBM layout: a path record is 8 x 16 B in structure-of-arrays form (each field array is read/written as full
-// dwordx4 per lane, consecutive lanes -> consecutive 16 B).  Survivors are written compacted into the other of
-// two record buffers, so every stage reads and writes dense arrays; the only gather is shade's read of its
-// input through the per-class permutation.
+// HBM layout: a path lives in ONE slot for the whole pass (slot = sample_in_pass * n_items + item, so neighbouring
+// slots are neighbouring pixels); its record is 8 x 16 B in structure-of-arrays form, each field read/written as a
+// full dwordx4 per lane.  Nothing is moved: stages reach their work through the stable index lists, which keeps
+// lanes of a wave on neighbouring pixels and needs no atomics.
 #pragma once
+#include "device_lists.h"
 #include "device_trace.h"
 
 namespace tutu {
 
-#define TUTU_NCLASS 8
 #define TUTU_CLASS_EMISSIVE 6
 #define TUTU_CLASS_MISS 7
 
@@ -27,22 +28,21 @@ namespace tutu {
 #define TUTU_FLAG_PREV_MIRROR_PM1 2u  // vertex d-1 PERFECT_REFLECTIVE with mat_pdf == 1 (PathTracing.hpp:252-253)
 #define TUTU_FLAG_KILL 4u             // NEE hit the `r2*pdf < MIN_DIVISOR` early return (PathTracing.hpp:215)
 
-struct Queue {  // structure-of-arrays path records, capacity P each
+#define TUTU_KEY_NEXT 1u    // kA bit0: the path continues
+#define TUTU_KEY_SHADOW 2u  // kA bit1: the slot holds a shadow request
+
+struct Queue {  // structure-of-arrays path records, one per slot
 	float4* A;  // ray origin xyz | pixel index (RNG counter word 0)
 	float4* B;  // ray direction xyz (NOT normalised for mirror/refraction, as in the reference) | smp<<8 | draw
 	float4* C;  // hit: t, b1, b2 | triangle (leaf order, -1 miss)            -- written by trace_closest
 	float4* D;  // beta xyz | mat_pdf of the BSDF sample at the previous vertex
 	float4* E;  // tp xyz (the reference's Russian-roulette variable, NOT the throughput) | flags
-	float4* F;  // L xyz (radiance gathered so far) | unused
-	float4* G;  // position of the previous vertex xyz | path id within the pass
+	float4* F;  // L xyz: radiance gathered so far; final when the path has ended
+	float4* G;  // position of the previous vertex xyz | unused
 	float4* H;  // f_r at the previous vertex xyz | |Ng.wi| there
-};
-
-struct Counters {  // one per depth, zeroed at pass start
-	uint32_t queue_n;   // records appended by shade(d)
-	uint32_t shadow_n;  // shadow requests appended by shade(d)
-	uint32_t cls[TUTU_NCLASS];
-	uint32_t pad[6];
+	float4* S0;  // shadow request: origin xyz | target x
+	float4* S1;  //                 target yz | contribution xy
+	float4* S2;  //                 contribution z | flags | unused
 };
 
 struct Totals {  // accumulated over a render call
@@ -55,34 +55,17 @@ struct PassParams {
 	int depth;
 	int npix;   // work items
 	int s0;     // first sample index of this pass
-	int cap;    // record capacity P
+	uint32_t n_slots;
 	const float4* prim_dir;  // per item: primary direction xyz | pixel index
 	const float4* prim_hit;  // per item: t, b1, b2 | tri
 	const uint32_t* smp_list;  // optional: per item sample index (tutu_hip_trace_samples); then one sample per item
 	float eye[3];
-	Queue qin, qout;
-	float4* shadowq;  // 3 x float4 per request
-	float4* Lout;     // per path: final radiance xyz
-	uint32_t* perm;   // TUTU_NCLASS x cap
-	Counters* cnt_in;
-	Counters* cnt_out;
-	Totals* totals;
+	Queue q;
+	uint8_t* kA;              // out: continuation / shadow flags per slot
+	const uint32_t* perm;     // class-sorted continuing slots (packed lists)
+	const uint32_t* cls_count;  // [8]
+	const uint32_t* cls_base;   // [8]
 };
-
-// wave-aggregated append: returns this lane's slot (valid when want)
-TUTU_DEV uint32_t wave_append(bool want, uint32_t* counter) {
-	const unsigned long long m = __ballot(want);
-	uint32_t slot = 0;
-	if (m) {
-		const int lane = __lane_id();
-		const int leader = __ffsll((long long)m) - 1;
-		uint32_t base = 0;
-		if (lane == leader) base = atomicAdd(counter, (uint32_t)__popcll(m));
-		base = (uint32_t)__shfl((int)base, leader);
-		slot = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-	}
-	return slot;
-}
 
 TUTU_DEV Mat load_mat(const SceneDev& sc, int id) {
 	const float4 a = sc.mats[4 * id + 0];
@@ -138,16 +121,18 @@ __global__ void __launch_bounds__(256) k_shade(PassParams pp) {
 	const int lane = __lane_id();
 	const int depth = pp.depth;
 
-	// work decomposition: FIRST: grid (ceil(npix/256), samples) ; else: persistent, wave-sized chunks over the
-	// class-sorted permutation, class boundaries padded to a wave so that a wave sees one class
+	// work decomposition: FIRST: grid (ceil(npix/256), samples), slot = sample*npix + item ; else: persistent,
+	// wave-sized chunks over the class-sorted list, class boundaries padded to a wave so that a wave sees one class
 	uint32_t cnt[TUTU_NCLASS];
+	uint32_t base[TUTU_NCLASS];
 	uint32_t pref[TUTU_NCLASS + 1];
 	uint32_t total_chunks = 0;
 	if (!FIRST) {
 		pref[0] = 0;
 #pragma unroll
 		for (int c = 0; c < TUTU_NCLASS; c++) {
-			cnt[c] = pp.cnt_in->cls[c];
+			cnt[c] = pp.cls_count[c];
+			base[c] = pp.cls_base[c];
 			pref[c + 1] = pref[c] + ((cnt[c] + 63u) >> 6);
 		}
 		total_chunks = pref[TUTU_NCLASS];
@@ -157,25 +142,34 @@ __global__ void __launch_bounds__(256) k_shade(PassParams pp) {
 
 	for (uint32_t chunk = FIRST ? 0u : wave_global; FIRST ? (chunk == 0u) : (chunk < total_chunks); chunk += n_waves) {
 		bool act;
-		uint32_t idx = 0;
+		uint32_t idx = 0;   // work item (FIRST only)
+		uint32_t slot = 0;  // the path's slot
 		if (FIRST) {
-			idx = blockIdx.x * blockDim.x + threadIdx.x;  // work item
+			idx = blockIdx.x * blockDim.x + threadIdx.x;
 			act = idx < (uint32_t)pp.npix;
+			slot = pp.smp_list ? idx : blockIdx.y * (uint32_t)pp.npix + idx;
 		} else {
 			int c = 0;
+			uint32_t cb = base[0], cn = cnt[0], cp = 0;
 #pragma unroll
 			for (int k = 1; k < TUTU_NCLASS; k++)
-				if (chunk >= pref[k]) c = k;
-			const uint32_t j = (chunk - pref[c]) * 64u + lane;
-			act = j < cnt[c];
-			if (act) idx = pp.perm[(size_t)c * pp.cap + j];
+				if (chunk >= pref[k]) {
+					c = k;
+					cb = base[k];
+					cn = cnt[k];
+					cp = pref[k];
+				}
+			const uint32_t j = (chunk - cp) * 64u + lane;
+			act = j < cn;
+			if (act) slot = pp.perm[cb + j];
+			(void)c;
 		}
 
 		// ---- load the path
 		V3 o = mk1(0.f), d = mk1(0.f), beta = mk1(1.f), tp = mk1(1.f), L = mk1(0.f), prev_pos = mk1(0.f), fprev = mk1(0.f);
 		float t = FLT_MAX, b1 = 0.f, b2 = 0.f, pm = 0.f, cosprev = 0.f;
 		int tri = -1;
-		uint32_t pix = 0, smp = 0, draw = 0, flags = 0, path_id = 0;
+		uint32_t pix = 0, smp = 0, draw = 0, flags = 0;
 		if (act) {
 			if (FIRST) {
 				const float4 pd = pp.prim_dir[idx];
@@ -184,16 +178,10 @@ __global__ void __launch_bounds__(256) k_shade(PassParams pp) {
 				d = mk(pd.x, pd.y, pd.z);
 				pix = __float_as_uint(pd.w);
 				t = ph.x; b1 = ph.y; b2 = ph.z; tri = __float_as_int(ph.w);
-				if (pp.smp_list) {
-					smp = pp.smp_list[idx];
-					path_id = idx;
-				} else {
-					smp = (uint32_t)pp.s0 + blockIdx.y;
-					path_id = blockIdx.y * (uint32_t)pp.npix + idx;
-				}
+				smp = pp.smp_list ? pp.smp_list[idx] : (uint32_t)pp.s0 + blockIdx.y;
 			} else {
-				const float4 A = pp.qin.A[idx], B = pp.qin.B[idx], C = pp.qin.C[idx], D = pp.qin.D[idx];
-				const float4 E = pp.qin.E[idx], F = pp.qin.F[idx], G = pp.qin.G[idx], H = pp.qin.H[idx];
+				const float4 A = pp.q.A[slot], B = pp.q.B[slot], C = pp.q.C[slot], D = pp.q.D[slot];
+				const float4 E = pp.q.E[slot], F = pp.q.F[slot], G = pp.q.G[slot], H = pp.q.H[slot];
 				o = mk(A.x, A.y, A.z); pix = __float_as_uint(A.w);
 				d = mk(B.x, B.y, B.z);
 				const uint32_t sd = __float_as_uint(B.w);
@@ -202,7 +190,7 @@ __global__ void __launch_bounds__(256) k_shade(PassParams pp) {
 				beta = mk(D.x, D.y, D.z); pm = D.w;
 				tp = mk(E.x, E.y, E.z); flags = __float_as_uint(E.w);
 				L = mk(F.x, F.y, F.z);
-				prev_pos = mk(G.x, G.y, G.z); path_id = __float_as_uint(G.w);
+				prev_pos = mk(G.x, G.y, G.z);
 				fprev = mk(H.x, H.y, H.z); cosprev = H.w;
 			}
 		}
@@ -296,7 +284,6 @@ __global__ void __launch_bounds__(256) k_shade(PassParams pp) {
 		V3 n_o = mk1(0.f), n_d = mk1(0.f), n_f = mk1(0.f), sh_o = mk1(0.f), sh_t = mk1(0.f), sh_c = mk1(0.f);
 		float n_pm = 0.f, n_cos = 0.f;
 		uint32_t n_flags = 0, sh_flags = 0;
-		const unsigned long long seg_mask = __ballot(go);
 		if (go) {
 			Mat m = load_mat(sc, mat_id);  // per-hit copy, like Intersection::mtlcolor
 			const V3 wo = -d;
@@ -406,117 +393,118 @@ __global__ void __launch_bounds__(256) k_shade(PassParams pp) {
 			}
 		}
 
-		// ---- outputs (all lanes of the wave arrive here together)
-		const uint32_t slot = wave_append(has_next, &pp.cnt_out->queue_n);
-		const uint32_t sslot = wave_append(has_shadow, &pp.cnt_out->shadow_n);
-		if (has_next) {
-			pp.qout.A[slot] = make_float4(n_o.x, n_o.y, n_o.z, __uint_as_float(pix));
-			pp.qout.B[slot] = make_float4(n_d.x, n_d.y, n_d.z, __uint_as_float((smp << 8) | (rng.draw & 0xFFu)));
-			pp.qout.D[slot] = make_float4(beta.x, beta.y, beta.z, n_pm);
-			pp.qout.E[slot] = make_float4(tp.x, tp.y, tp.z, __uint_as_float(n_flags));
-			pp.qout.F[slot] = make_float4(L.x, L.y, L.z, 0.f);
-			pp.qout.G[slot] = make_float4(pos.x, pos.y, pos.z, __uint_as_float(path_id));
-			pp.qout.H[slot] = make_float4(n_f.x, n_f.y, n_f.z, n_cos);
+		// ---- outputs, in place
+		(void)fin;
+		if (act) {
+			if (has_next) {
+				pp.q.A[slot] = make_float4(n_o.x, n_o.y, n_o.z, __uint_as_float(pix));
+				pp.q.B[slot] = make_float4(n_d.x, n_d.y, n_d.z, __uint_as_float((smp << 8) | (rng.draw & 0xFFu)));
+				pp.q.D[slot] = make_float4(beta.x, beta.y, beta.z, n_pm);
+				pp.q.E[slot] = make_float4(tp.x, tp.y, tp.z, __uint_as_float(n_flags));
+				pp.q.G[slot] = make_float4(pos.x, pos.y, pos.z, 0.f);
+				pp.q.H[slot] = make_float4(n_f.x, n_f.y, n_f.z, n_cos);
+			}
+			if (has_shadow) {
+				pp.q.S0[slot] = make_float4(sh_o.x, sh_o.y, sh_o.z, sh_t.x);
+				pp.q.S1[slot] = make_float4(sh_t.y, sh_t.z, sh_c.x, sh_c.y);
+				pp.q.S2[slot] = make_float4(sh_c.z, __uint_as_float(sh_flags), 0.f, 0.f);
+			}
+			pp.q.F[slot] = make_float4(L.x, L.y, L.z, 0.f);  // radiance so far; final if the path ended here
+			pp.kA[slot] = (uint8_t)((has_next ? TUTU_KEY_NEXT : 0u) | (has_shadow ? TUTU_KEY_SHADOW : 0u));
 		}
-		if (has_shadow) {
-			const int dest = has_next ? (int)slot : ~(int)path_id;
-			pp.shadowq[3 * (size_t)sslot + 0] = make_float4(sh_o.x, sh_o.y, sh_o.z, sh_t.x);
-			pp.shadowq[3 * (size_t)sslot + 1] = make_float4(sh_t.y, sh_t.z, sh_c.x, sh_c.y);
-			pp.shadowq[3 * (size_t)sslot + 2] = make_float4(sh_c.z, __int_as_float(dest), __uint_as_float(sh_flags), 0.f);
-		}
-		if (fin) pp.Lout[path_id] = make_float4(L.x, L.y, L.z, 0.f);
-		if (seg_mask && lane == (__ffsll((long long)seg_mask) - 1)) atomicAdd(&pp.totals->segments, (unsigned long long)__popcll(seg_mask));
 		if (FIRST) break;
 	}
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// closest-hit stage over the records of q[0, n): writes C and files the record under its material class
+// closest-hit stage over the continuing slots: writes the hit (C) and its material class (kB)
 struct TraceParams {
 	SceneDev sc;
 	Queue q;
-	const uint32_t* n_ptr;  // device count of records
-	uint32_t* cls;          // TUTU_NCLASS class counters (zeroed)
-	uint32_t* perm;         // TUTU_NCLASS x cap
-	int cap;
-	Totals* totals;
+	const uint32_t* list;   // slots to trace
+	const uint32_t* n_ptr;  // device count
+	uint8_t* kB;
+	int stack_entries;
 };
 
+TUTU_DEV int hit_class(const SceneDev& sc, int tri) {
+	if (tri < 0) return TUTU_CLASS_MISS;
+	const int mat = __float_as_int(sc.tri_shade[3 * tri + 2].y);
+	const int type = __float_as_int(sc.mats[4 * mat + 0].w);
+	const int emis = __float_as_int(sc.mats[4 * mat + 1].w);
+	// refractive types are tested before emission in traceRay (PathTracing.hpp:152-170)
+	int cls = (emis && type != TUTU_PERFECT_REFRACTIVE && type != TUTU_MICROFACET_T) ? TUTU_CLASS_EMISSIVE : type;
+	if (cls < 0 || cls > TUTU_CLASS_EMISSIVE) cls = TUTU_UNLIT;  // unknown enum values: filed with UNLIT, shaded by their own `default:` branches
+	return cls;
+}
+
+template <bool LDS_SCENE>
 __global__ void __launch_bounds__(256) k_trace_closest(TraceParams tp) {
-	__shared__ int stack[TUTU_STACK_DEPTH * 256];
+	extern __shared__ int lds[];  // [stack entries][256 lanes] | optional scene copy
 	const SceneDev& sc = tp.sc;
-	const uint32_t n = *tp.n_ptr;
-	const uint32_t n_pad = (n + 63u) & ~63u;
-	const int lane = __lane_id();
-	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_pad; i += gridDim.x * blockDim.x) {
-		const bool act = i < n;
-		int cls = -1;
-		if (act) {
-			const float4 A = tp.q.A[i], B = tp.q.B[i];
-			float t, u, v;
-			int tri;
-			trace_closest(sc, mk(A.x, A.y, A.z), mk(B.x, B.y, B.z), stack + threadIdx.x, 256, t, u, v, tri);
-			tp.q.C[i] = make_float4(t, u, v, __int_as_float(tri));
-			if (tri < 0) {
-				cls = TUTU_CLASS_MISS;
-			} else {
-				const int mat = __float_as_int(sc.tri_shade[3 * tri + 2].y);
-				const int type = __float_as_int(sc.mats[4 * mat + 0].w);
-				const int emis = __float_as_int(sc.mats[4 * mat + 1].w);
-				// refractive types are tested before emission in traceRay (PathTracing.hpp:152-170)
-				cls = (emis && type != TUTU_PERFECT_REFRACTIVE && type != TUTU_MICROFACET_T) ? TUTU_CLASS_EMISSIVE : type;
-				if (cls < 0 || cls > TUTU_CLASS_EMISSIVE) cls = TUTU_UNLIT;  // unknown enum values: filed with UNLIT, shaded by their own `default:` branches
-			}
-		}
-#pragma unroll
-		for (int c = 0; c < TUTU_NCLASS; c++) {
-			const bool mine = cls == c;
-			const uint32_t slot = wave_append(mine, &tp.cls[c]);
-			if (mine) tp.perm[(size_t)c * tp.cap + slot] = i;
-		}
+	SceneLds sl;
+	SceneGlobal sg;
+	if (LDS_SCENE) sl = stage_scene_lds(sc, lds, tp.stack_entries);
+	else {
+		sg.nodes = sc.nodes;
+		sg.tris = sc.tri_isect;
 	}
-	if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&tp.totals->closest_rays, (unsigned long long)n);
-	(void)lane;
+	const uint32_t n = *tp.n_ptr;
+	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+		const uint32_t slot = tp.list[i];
+		const float4 A = tp.q.A[slot], B = tp.q.B[slot];
+		float t, u, v;
+		int tri;
+		if (LDS_SCENE) trace_closest(sl, sc, mk(A.x, A.y, A.z), mk(B.x, B.y, B.z), lds + threadIdx.x, 256, t, u, v, tri);
+		else trace_closest(sg, sc, mk(A.x, A.y, A.z), mk(B.x, B.y, B.z), lds + threadIdx.x, 256, t, u, v, tri);
+		tp.q.C[slot] = make_float4(t, u, v, __int_as_float(tri));
+		tp.kB[slot] = (uint8_t)hit_class(sc, tri);
+	}
 }
 
 // any-hit stage over the shadow requests
 struct ShadowParams {
 	SceneDev sc;
-	const float4* shadowq;
+	Queue q;
+	const uint32_t* list;
 	const uint32_t* n_ptr;
-	Queue q;       // the record buffer the requests point into
-	float4* Lout;  // for requests of paths that already ended
-	Totals* totals;
+	uint8_t* kA;
+	int stack_entries;
 };
 
+template <bool LDS_SCENE>
 __global__ void __launch_bounds__(256) k_trace_any(ShadowParams sp) {
-	__shared__ int stack[TUTU_STACK_DEPTH * 256];
+	extern __shared__ int lds[];
+	SceneLds sl;
+	SceneGlobal sg;
+	if (LDS_SCENE) sl = stage_scene_lds(sp.sc, lds, sp.stack_entries);
+	else {
+		sg.nodes = sp.sc.nodes;
+		sg.tris = sp.sc.tri_isect;
+	}
 	const uint32_t n = *sp.n_ptr;
 	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-		const float4 e0 = sp.shadowq[3 * (size_t)i + 0];
-		const float4 e1 = sp.shadowq[3 * (size_t)i + 1];
-		const float4 e2 = sp.shadowq[3 * (size_t)i + 2];
+		const uint32_t slot = sp.list[i];
+		const float4 e0 = sp.q.S0[slot], e1 = sp.q.S1[slot], e2 = sp.q.S2[slot];
 		const V3 so = mk(e0.x, e0.y, e0.z), lo = mk(e0.w, e1.x, e1.y), c = mk(e1.z, e1.w, e2.x);
-		const int dest = __float_as_int(e2.y);
-		const uint32_t fl = __float_as_uint(e2.z);
-		const bool blocked = trace_any(sp.sc, so, lo, stack + threadIdx.x, 256);
+		const uint32_t fl = __float_as_uint(e2.y);
+		// the request is consumed: a path that ended at this vertex is never re-shaded, so its flag must not survive
+		sp.kA[slot] = (uint8_t)(sp.kA[slot] & ~TUTU_KEY_SHADOW);
+		bool blocked;
+		if (LDS_SCENE) blocked = trace_any(sl, sp.sc, so, lo, lds + threadIdx.x, 256);
+		else blocked = trace_any(sg, sp.sc, so, lo, lds + threadIdx.x, 256);
 		if (!blocked) {
 			if (fl & TUTU_FLAG_KILL) {
-				float4 E = sp.q.E[dest];
+				float4 E = sp.q.E[slot];
 				E.w = __uint_as_float(__float_as_uint(E.w) | TUTU_FLAG_KILL);
-				sp.q.E[dest] = E;
-			} else if (dest >= 0) {
-				float4 F = sp.q.F[dest];
-				F.x = F.x + c.x; F.y = F.y + c.y; F.z = F.z + c.z;
-				sp.q.F[dest] = F;
+				sp.q.E[slot] = E;
 			} else {
-				float4 F = sp.Lout[~dest];
+				float4 F = sp.q.F[slot];
 				F.x = F.x + c.x; F.y = F.y + c.y; F.z = F.z + c.z;
-				sp.Lout[~dest] = F;
+				sp.q.F[slot] = F;
 			}
 		}
 	}
-	if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&sp.totals->shadow_rays, (unsigned long long)n);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -531,10 +519,19 @@ struct PrimaryParams {
 	float4* prim_dir;
 	float4* prim_hit;
 	Totals* totals;
+	int stack_entries;
 };
 
+template <bool LDS_SCENE>
 __global__ void __launch_bounds__(256) k_primary(PrimaryParams p) {
-	__shared__ int stack[TUTU_STACK_DEPTH * 256];
+	extern __shared__ int lds[];
+	SceneLds sl;
+	SceneGlobal sg;
+	if (LDS_SCENE) sl = stage_scene_lds(p.sc, lds, p.stack_entries);
+	else {
+		sg.nodes = p.sc.nodes;
+		sg.tris = p.sc.tri_isect;
+	}
 	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
 	if (i < (uint32_t)p.n) {
 		int pix;
@@ -547,11 +544,12 @@ __global__ void __launch_bounds__(256) k_primary(PrimaryParams p) {
 		const V3 rayDir = normalized((pixelPos - eye));
 		float t, u, v;
 		int tri;
-		trace_closest(p.sc, eye, rayDir, stack + threadIdx.x, 256, t, u, v, tri);
+		if (LDS_SCENE) trace_closest(sl, p.sc, eye, rayDir, lds + threadIdx.x, 256, t, u, v, tri);
+		else trace_closest(sg, p.sc, eye, rayDir, lds + threadIdx.x, 256, t, u, v, tri);
 		p.prim_dir[i] = make_float4(rayDir.x, rayDir.y, rayDir.z, __uint_as_float((uint32_t)pix));
 		p.prim_hit[i] = make_float4(t, u, v, __int_as_float(tri));
 	}
-	if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&p.totals->closest_rays, (unsigned long long)p.n);
+	if (blockIdx.x == 0 && threadIdx.x == 0) p.totals->closest_rays += (unsigned long long)p.n;
 }
 
 // resolve: estimate += sample unless NaN, in sample order (PathTracing.hpp:507-513)

@@ -13,6 +13,12 @@
 // What is new: near-child-first order and pruning of subtrees whose entry distance exceeds the best t so far
 // (times 1+1e-4 of slack, to stay on the safe side of the two different roundings of slab-t and triangle-t).
 // The reference visits every node whose box is hit; the result is the same, the work is not.
+//
+// Two scene accessors: SceneGlobal reads nodes/triangles from HBM (L1/L2-cached gathers); SceneLds reads a
+// block-local copy staged in LDS in structure-of-arrays form (one ds_read_b128 per 16 B field, lanes that want the
+// same node broadcast) -- used whenever nodes + triangles fit the LDS budget (Cornell: 3.5 KB).
+// The loop is "while-while": lanes descend through inner nodes together and test their leaf triangles together,
+// instead of paying for both bodies on every iteration.
 #pragma once
 #include <float.h>
 #include <limits.h>
@@ -23,6 +29,7 @@ namespace tutu {
 
 #define TUTU_STACK_DEPTH 32
 #define TUTU_PRUNE_SLACK 1.0001f
+#define TUTU_TRAV_DONE INT_MIN
 
 struct SceneDev {
 	const float4* nodes;      // 4 x float4 per inner node (GpuNode)
@@ -36,7 +43,46 @@ struct SceneDev {
 	float eta;
 	float bkg[3];
 	int n_tris;
+	int n_inner;
 };
+
+struct SceneGlobal {
+	const float4* nodes;
+	const float4* tris;
+	TUTU_DEV void node(int i, float4& a, float4& b, float4& c, float4& e) const {
+		a = nodes[4 * i + 0]; b = nodes[4 * i + 1]; c = nodes[4 * i + 2]; e = nodes[4 * i + 3];
+	}
+	TUTU_DEV void tri(int i, float4& q0, float4& q1, float4& q2) const {
+		q0 = tris[3 * i + 0]; q1 = tris[3 * i + 1]; q2 = tris[3 * i + 2];
+	}
+};
+
+struct SceneLds {
+	const float4* nodes;  // [4][nn]
+	const float4* tris;   // [3][nt]
+	int nn, nt;
+	TUTU_DEV void node(int i, float4& a, float4& b, float4& c, float4& e) const {
+		a = nodes[i]; b = nodes[nn + i]; c = nodes[2 * nn + i]; e = nodes[3 * nn + i];
+	}
+	TUTU_DEV void tri(int i, float4& q0, float4& q1, float4& q2) const {
+		q0 = tris[i]; q1 = tris[nt + i]; q2 = tris[2 * nt + i];
+	}
+};
+
+// LDS carve-up of the traversal kernels: [stack ints: stack_entries x blockDim][scene copy, 16-B aligned]
+TUTU_DEV SceneLds stage_scene_lds(const SceneDev& sc, int* lds_base, int stack_entries) {
+	float4* dst = reinterpret_cast<float4*>(lds_base + stack_entries * blockDim.x);
+	SceneLds s;
+	s.nn = sc.n_inner;
+	s.nt = sc.n_tris;
+	s.nodes = dst;
+	s.tris = dst + 4 * sc.n_inner;
+	for (int idx = threadIdx.x; idx < 4 * sc.n_inner; idx += blockDim.x) dst[(idx & 3) * sc.n_inner + (idx >> 2)] = sc.nodes[idx];
+	float4* td = dst + 4 * sc.n_inner;
+	for (int idx = threadIdx.x; idx < 3 * sc.n_tris; idx += blockDim.x) td[(idx % 3) * sc.n_tris + (idx / 3)] = sc.tri_isect[idx];
+	__syncthreads();
+	return s;
+}
 
 struct RayPre {
 	V3 o, d, inv;
@@ -72,23 +118,23 @@ TUTU_DEV bool slab(const RayPre& r, float minx, float miny, float minz, float ma
 }
 
 // Triangle::intersect, Triangle.hpp:23-59 (E1, E2 and the normalised normal are hoisted to the host)
-TUTU_DEV bool tri_test(const SceneDev& sc, int ti, const RayPre& r, float& t, float& u, float& v) {
-	const float4 q0 = sc.tri_isect[3 * ti + 0];
-	const float4 q1 = sc.tri_isect[3 * ti + 1];
-	const float4 q2 = sc.tri_isect[3 * ti + 2];
+template <typename S>
+TUTU_DEV bool tri_test(const S& sc, int ti, const RayPre& r, float& t, float& u, float& v) {
+	float4 q0, q1, q2;
+	sc.tri(ti, q0, q1, q2);
 	const V3 v0 = mk(q0.x, q0.y, q0.z);
 	const V3 E1 = mk(q0.w, q1.x, q1.y);
 	const V3 E2 = mk(q1.z, q1.w, q2.x);
 	const V3 normal = mk(q2.y, q2.z, q2.w);
-	const V3 S = r.o - v0;
+	const V3 Sv = r.o - v0;
 	const V3 S1 = cross(r.d, E2);
-	const V3 S2 = cross(S, E1);
+	const V3 S2 = cross(Sv, E1);
 	if (float_equal(dot(r.d, normal), 0.f)) return false;
 	const float det = dot(S1, E1);
 	if (det == 0.f) return false;
 	const float left = 1.0f / det;
 	t = dot(S2, E2) * left;
-	u = dot(S1, S) * left;
+	u = dot(S1, Sv) * left;
 	v = dot(S2, r.d) * left;
 	return (t > 0 && 1 - u - v > 0 && u > 0 && v > 0);
 }
@@ -98,11 +144,10 @@ struct ChildTest {
 	float tl, tr;
 	int left, right;
 };
-TUTU_DEV ChildTest test_children(const SceneDev& sc, int node, const RayPre& r, float lim) {
-	const float4 a = sc.nodes[4 * node + 0];
-	const float4 b = sc.nodes[4 * node + 1];
-	const float4 c = sc.nodes[4 * node + 2];
-	const float4 e = sc.nodes[4 * node + 3];
+template <typename S>
+TUTU_DEV ChildTest test_children(const S& sc, int node, const RayPre& r, float lim) {
+	float4 a, b, c, e;
+	sc.node(node, a, b, c, e);
 	ChildTest ct;
 	ct.hl = slab(r, a.x, a.y, a.z, a.w, b.x, b.y, ct.tl);
 	ct.hr = slab(r, b.z, b.w, c.x, c.y, c.z, c.w, ct.tr);
@@ -114,7 +159,8 @@ TUTU_DEV ChildTest test_children(const SceneDev& sc, int node, const RayPre& r, 
 }
 
 // getIntersection, BVH.hpp:145-167.  stack = this lane's column of the LDS stack, `stride` ints between entries.
-TUTU_DEV void trace_closest(const SceneDev& sc, V3 o, V3 d, int* stack, int stride, float& best_t, float& best_u,
+template <typename S>
+TUTU_DEV void trace_closest(const S& ss, const SceneDev& sc, V3 o, V3 d, int* stack, int stride, float& best_t, float& best_u,
                             float& best_v, int& best_tri) {
 	best_t = FLT_MAX;
 	best_u = 0.f;
@@ -127,36 +173,34 @@ TUTU_DEV void trace_closest(const SceneDev& sc, V3 o, V3 d, int* stack, int stri
 	int cur = sc.root_ref;
 	int sp = 0;
 	for (;;) {
-		if (cur < 0) {
-			const int ti = ~cur;
-			float t, u, v;
-			if (tri_test(sc, ti, r, t, u, v)) {
-				if (t < best_t || (t == best_t && ti < best_tri)) {
-					best_t = t;
-					best_u = u;
-					best_v = v;
-					best_tri = ti;
-				}
-			}
-		} else {
+		while (cur >= 0) {
 			const float lim = best_tri >= 0 ? best_t * TUTU_PRUNE_SLACK : FLT_MAX;
-			const ChildTest ct = test_children(sc, cur, r, lim);
+			const ChildTest ct = test_children(ss, cur, r, lim);
 			if (ct.hl && ct.hr) {
-				if (ct.tr < ct.tl) {
-					stack[sp * stride] = ct.left;
-					cur = ct.right;
-				} else {
-					stack[sp * stride] = ct.right;
-					cur = ct.left;
-				}
+				const bool right_first = ct.tr < ct.tl;
+				stack[sp * stride] = right_first ? ct.left : ct.right;
 				sp++;
-				continue;
+				cur = right_first ? ct.right : ct.left;
 			} else if (ct.hl) {
 				cur = ct.left;
-				continue;
 			} else if (ct.hr) {
 				cur = ct.right;
-				continue;
+			} else if (sp == 0) {
+				cur = TUTU_TRAV_DONE;
+			} else {
+				sp--;
+				cur = stack[sp * stride];
+			}
+		}
+		if (cur == TUTU_TRAV_DONE) break;
+		const int ti = ~cur;
+		float t, u, v;
+		if (tri_test(ss, ti, r, t, u, v)) {
+			if (t < best_t || (t == best_t && ti < best_tri)) {
+				best_t = t;
+				best_u = u;
+				best_v = v;
+				best_tri = ti;
 			}
 		}
 		if (sp == 0) break;
@@ -166,7 +210,8 @@ TUTU_DEV void trace_closest(const SceneDev& sc, V3 o, V3 d, int* stack, int stri
 }
 
 // isShadowRayBlocked -> hasIntersection, IIntegrator.hpp:135-153 + BVH.hpp:170-194
-TUTU_DEV bool trace_any(const SceneDev& sc, V3 orig, V3 lightPos, int* stack, int stride) {
+template <typename S>
+TUTU_DEV bool trace_any(const S& ss, const SceneDev& sc, V3 orig, V3 lightPos, int* stack, int stride) {
 	if (sc.root_ref == INT_MIN) return false;
 	const V3 raydir = normalized(lightPos - orig);
 	const float dis = norm(lightPos - orig);
@@ -176,32 +221,38 @@ TUTU_DEV bool trace_any(const SceneDev& sc, V3 orig, V3 lightPos, int* stack, in
 	const float lim = dis * TUTU_PRUNE_SLACK;
 	int cur = sc.root_ref;
 	int sp = 0;
+	bool blocked = false;
 	for (;;) {
-		if (cur < 0) {
-			float t, u, v;
-			if (tri_test(sc, ~cur, r, t, u, v)) {
-				if (t < dis && !float_equal(t, dis)) return true;
-			}
-		} else {
-			const ChildTest ct = test_children(sc, cur, r, lim);
+		while (cur >= 0) {
+			const ChildTest ct = test_children(ss, cur, r, lim);
 			if (ct.hl && ct.hr) {
 				stack[sp * stride] = ct.right;
 				sp++;
 				cur = ct.left;
-				continue;
 			} else if (ct.hl) {
 				cur = ct.left;
-				continue;
 			} else if (ct.hr) {
 				cur = ct.right;
-				continue;
+			} else if (sp == 0) {
+				cur = TUTU_TRAV_DONE;
+			} else {
+				sp--;
+				cur = stack[sp * stride];
+			}
+		}
+		if (cur == TUTU_TRAV_DONE) break;
+		float t, u, v;
+		if (tri_test(ss, ~cur, r, t, u, v)) {
+			if (t < dis && !float_equal(t, dis)) {
+				blocked = true;
+				break;
 			}
 		}
 		if (sp == 0) break;
 		sp--;
 		cur = stack[sp * stride];
 	}
-	return false;
+	return blocked;
 }
 
 }  // namespace tutu

@@ -65,15 +65,23 @@ struct TutuCtx {
 	int device = 0;
 	hipStream_t stream = nullptr;
 	int n_cu = 256;
+	// traversal kernels: dynamic LDS = per-lane stacks (+ a copy of the BVH when it fits)
+	int stack_entries = TUTU_STACK_DEPTH;
+	unsigned trace_lds_bytes = TUTU_STACK_DEPTH * 256 * sizeof(int);
+	bool lds_scene = false;
+	int trace_blocks_per_cu = 5;
 	HostScene hs;
 	SceneDev sc;
 	DevBuf<float4> d_nodes, d_tri_isect, d_tri_shade, d_mats, d_lights;
 	// work buffers
-	size_t cap = 0;
-	DevBuf<float4> qbuf[2][8];
-	DevBuf<float4> shadowq, Lout, prim_dir, prim_hit, accum;
-	DevBuf<uint32_t> perm;
-	DevBuf<Counters> counters;
+	size_t cap = 0;         // path slots (multiple of TUTU_LIST_TILE)
+	DevBuf<float4> qbuf[11];  // A..H, S0..S2
+	DevBuf<float4> prim_dir, prim_hit, accum;
+	DevBuf<uint8_t> kA, kB;
+	DevBuf<uint32_t> flag_lists;  // [2][cap]: extension-ray slots, shadow-request slots
+	DevBuf<uint32_t> perm;        // [cap]: continuing slots sorted by class
+	DevBuf<uint32_t> tile_counts, tile_offsets;
+	DevBuf<uint32_t> list_meta;   // per depth: flags count[8], flags base[8], class count[8], class base[8]
 	DevBuf<Totals> totals;
 	DevBuf<int32_t> pixels;
 	DevBuf<uint32_t> u32a, u32b;
@@ -84,28 +92,34 @@ struct TutuCtx {
 
 namespace {
 
-Queue queue_of(TutuCtx* c, int which) {
+Queue queue_of(TutuCtx* c) {
 	Queue q;
-	q.A = c->qbuf[which][0].p; q.B = c->qbuf[which][1].p; q.C = c->qbuf[which][2].p; q.D = c->qbuf[which][3].p;
-	q.E = c->qbuf[which][4].p; q.F = c->qbuf[which][5].p; q.G = c->qbuf[which][6].p; q.H = c->qbuf[which][7].p;
+	q.A = c->qbuf[0].p; q.B = c->qbuf[1].p; q.C = c->qbuf[2].p; q.D = c->qbuf[3].p;
+	q.E = c->qbuf[4].p; q.F = c->qbuf[5].p; q.G = c->qbuf[6].p; q.H = c->qbuf[7].p;
+	q.S0 = c->qbuf[8].p; q.S1 = c->qbuf[9].p; q.S2 = c->qbuf[10].p;
 	return q;
 }
 
-int ensure_work(TutuCtx* c, size_t cap, size_t nitems) {
+#define TUTU_META_STRIDE 32  // uint32 per depth in list_meta
+
+int ensure_work(TutuCtx* c, size_t want_slots, size_t nitems) {
 	int rc;
+	const size_t cap = (want_slots + TUTU_LIST_TILE - 1) / TUTU_LIST_TILE * TUTU_LIST_TILE;
 	if (cap > c->cap) {
-		for (int w = 0; w < 2; w++)
-			for (int f = 0; f < 8; f++)
-				if ((rc = c->qbuf[w][f].ensure(cap)) != TUTU_OK) return rc;
-		if ((rc = c->shadowq.ensure(3 * cap)) != TUTU_OK) return rc;
-		if ((rc = c->Lout.ensure(cap)) != TUTU_OK) return rc;
-		if ((rc = c->perm.ensure((size_t)TUTU_NCLASS * cap)) != TUTU_OK) return rc;
+		for (int f = 0; f < 11; f++)
+			if ((rc = c->qbuf[f].ensure(cap)) != TUTU_OK) return rc;
+		if ((rc = c->kA.ensure(cap)) != TUTU_OK) return rc;
+		if ((rc = c->kB.ensure(cap)) != TUTU_OK) return rc;
+		if ((rc = c->flag_lists.ensure(2 * cap)) != TUTU_OK) return rc;
+		if ((rc = c->perm.ensure(cap)) != TUTU_OK) return rc;
+		if ((rc = c->tile_counts.ensure(8 * (cap / TUTU_LIST_TILE))) != TUTU_OK) return rc;
+		if ((rc = c->tile_offsets.ensure(8 * (cap / TUTU_LIST_TILE))) != TUTU_OK) return rc;
 		c->cap = cap;
 	}
 	if ((rc = c->prim_dir.ensure(nitems)) != TUTU_OK) return rc;
 	if ((rc = c->prim_hit.ensure(nitems)) != TUTU_OK) return rc;
 	if ((rc = c->accum.ensure(nitems)) != TUTU_OK) return rc;
-	if ((rc = c->counters.ensure(TUTU_MAX_DEPTH + 3)) != TUTU_OK) return rc;
+	if ((rc = c->list_meta.ensure(TUTU_META_STRIDE * (TUTU_MAX_DEPTH + 3))) != TUTU_OK) return rc;
 	if ((rc = c->totals.ensure(1)) != TUTU_OK) return rc;
 	return TUTU_OK;
 }
@@ -139,19 +153,43 @@ int ev_end(TutuCtx* c, hipStream_t s, size_t idx) {
 		if (_rc != TUTU_OK) return _rc;                       \
 	} while (0)
 
-int persistent_grid(TutuCtx* c, size_t upper_items) {
+int persistent_grid(size_t upper_items, int n_cu, int blocks_per_cu) {
 	size_t blocks = (upper_items + 255) / 256;
-	size_t maxb = (size_t)c->n_cu * 8;
+	size_t maxb = (size_t)n_cu * (size_t)blocks_per_cu;
 	if (blocks < 1) blocks = 1;
 	return (int)std::min(blocks, maxb);
+}
+
+// count -> scan -> scatter: stable index lists from the per-slot key bytes (device_lists.h)
+template <int MODE>
+int build_lists(TutuCtx* c, hipStream_t s, uint32_t n_slots_padded, uint32_t* meta_count, uint32_t* meta_base, uint32_t* out,
+                unsigned long long* stat_a, unsigned long long* stat_b) {
+	ListParams lp;
+	lp.kA = c->kA.p;
+	lp.kB = c->kB.p;
+	lp.n_slots = n_slots_padded;
+	lp.n_tiles = n_slots_padded / TUTU_LIST_TILE;
+	lp.tile_counts = c->tile_counts.p;
+	lp.tile_offsets = c->tile_offsets.p;
+	lp.list_count = meta_count;
+	lp.list_base = meta_base;
+	lp.out = out;
+	lp.flags_stride = (uint32_t)c->cap;
+	lp.stat_a = stat_a;
+	lp.stat_b = stat_b;
+	TIMED(EV_OTHER, k_list_count<MODE><<<dim3(lp.n_tiles), dim3(256), 0, s>>>(lp));
+	TIMED(EV_OTHER, k_list_scan<MODE><<<dim3(1), dim3(1024), 0, s>>>(lp));
+	TIMED(EV_OTHER, k_list_scatter<MODE><<<dim3(lp.n_tiles), dim3(256), 0, s>>>(lp));
+	return TUTU_OK;
 }
 
 // One wavefront pass over `npix` work items x `nsamp` samples (or, with smp_list, one sample per item).
 int run_pass(TutuCtx* c, hipStream_t s, const TutuCameraFrame* cam, uint32_t key0, uint32_t key1, int npix, int s0, int nsamp,
              const uint32_t* d_smp_list, uint32_t* n_trace_launches) {
 	const size_t npaths = (size_t)npix * (size_t)nsamp;
-	Counters* cnt = c->counters.p;
-	HIP_TRY(hipMemsetAsync(cnt, 0, sizeof(Counters) * (TUTU_MAX_DEPTH + 3), s));
+	const uint32_t n_pad = (uint32_t)((npaths + TUTU_LIST_TILE - 1) / TUTU_LIST_TILE * TUTU_LIST_TILE);
+	// padding keys must read "nothing here"
+	if (n_pad > npaths) HIP_TRY(hipMemsetAsync(c->kA.p + npaths, 0, n_pad - npaths, s));
 
 	PassParams pp;
 	memset(&pp, 0, sizeof(pp));
@@ -160,47 +198,53 @@ int run_pass(TutuCtx* c, hipStream_t s, const TutuCameraFrame* cam, uint32_t key
 	pp.key1 = key1;
 	pp.npix = npix;
 	pp.s0 = s0;
-	pp.cap = (int)c->cap;
+	pp.n_slots = (uint32_t)npaths;
 	pp.prim_dir = c->prim_dir.p;
 	pp.prim_hit = c->prim_hit.p;
 	pp.smp_list = d_smp_list;
 	memcpy(pp.eye, cam->eye, sizeof(pp.eye));
-	pp.shadowq = c->shadowq.p;
-	pp.Lout = c->Lout.p;
+	pp.q = queue_of(c);
+	pp.kA = c->kA.p;
 	pp.perm = c->perm.p;
-	pp.totals = c->totals.p;
 
-	const int grid = persistent_grid(c, npaths);
+	const int shade_grid = persistent_grid(npaths, c->n_cu, 8);
+	const int trace_grid = persistent_grid(npaths, c->n_cu, c->trace_blocks_per_cu);
 	for (int d = 0; d <= TUTU_MAX_DEPTH + 1; d++) {
 		pp.depth = d;
-		pp.qin = queue_of(c, (d + 1) & 1);
-		pp.qout = queue_of(c, d & 1);
-		pp.cnt_in = d > 0 ? &cnt[d - 1] : nullptr;
-		pp.cnt_out = &cnt[d];
+		uint32_t* meta = c->list_meta.p + (size_t)TUTU_META_STRIDE * d;  // [0..8) flag counts, [8..16) flag bases, [16..24) class counts, [24..32) class bases
 		if (d == 0) {
 			dim3 g((unsigned)((npix + 255) / 256), (unsigned)nsamp, 1);
 			TIMED(EV_SHADE, k_shade<true><<<g, dim3(256), 0, s>>>(pp));
 		} else {
-			TraceParams tp;
-			tp.sc = c->sc;
-			tp.q = pp.qin;
-			tp.n_ptr = &cnt[d - 1].queue_n;
-			tp.cls = cnt[d - 1].cls;
-			tp.perm = c->perm.p;
-			tp.cap = (int)c->cap;
-			tp.totals = c->totals.p;
-			TIMED(EV_TRACE_CLOSEST, k_trace_closest<<<dim3(grid), dim3(256), 0, s>>>(tp));
-			(*n_trace_launches)++;
-			ShadowParams sp;
-			sp.sc = c->sc;
-			sp.shadowq = c->shadowq.p;
-			sp.n_ptr = &cnt[d - 1].shadow_n;
-			sp.q = pp.qin;
-			sp.Lout = c->Lout.p;
-			sp.totals = c->totals.p;
-			TIMED(EV_TRACE_ANY, k_trace_any<<<dim3(grid), dim3(256), 0, s>>>(sp));
-			TIMED(EV_SHADE, k_shade<false><<<dim3(grid), dim3(256), 0, s>>>(pp));
+			uint32_t* pm = c->list_meta.p + (size_t)TUTU_META_STRIDE * (d - 1);
+			pp.cls_count = pm + 16;
+			pp.cls_base = pm + 24;
+			TIMED(EV_SHADE, k_shade<false><<<dim3(shade_grid), dim3(256), 0, s>>>(pp));
 		}
+		if (d == TUTU_MAX_DEPTH + 1) break;  // the last shade only connects; nothing continues
+		int rc = build_lists<LIST_FLAGS>(c, s, n_pad, meta, meta + 8, c->flag_lists.p, &c->totals.p->closest_rays, &c->totals.p->shadow_rays);
+		if (rc != TUTU_OK) return rc;
+		TraceParams tp;
+		tp.sc = c->sc;
+		tp.q = pp.q;
+		tp.list = c->flag_lists.p;
+		tp.n_ptr = meta + 0;
+		tp.kB = c->kB.p;
+		tp.stack_entries = c->stack_entries;
+		if (c->lds_scene) TIMED(EV_TRACE_CLOSEST, k_trace_closest<true><<<dim3(trace_grid), dim3(256), c->trace_lds_bytes, s>>>(tp));
+		else TIMED(EV_TRACE_CLOSEST, k_trace_closest<false><<<dim3(trace_grid), dim3(256), c->trace_lds_bytes, s>>>(tp));
+		(*n_trace_launches)++;
+		ShadowParams sp;
+		sp.sc = c->sc;
+		sp.q = pp.q;
+		sp.list = c->flag_lists.p + c->cap;
+		sp.n_ptr = meta + 1;
+		sp.kA = c->kA.p;
+		sp.stack_entries = c->stack_entries;
+		if (c->lds_scene) TIMED(EV_TRACE_ANY, k_trace_any<true><<<dim3(trace_grid), dim3(256), c->trace_lds_bytes, s>>>(sp));
+		else TIMED(EV_TRACE_ANY, k_trace_any<false><<<dim3(trace_grid), dim3(256), c->trace_lds_bytes, s>>>(sp));
+		rc = build_lists<LIST_CLASS>(c, s, n_pad, meta + 16, meta + 24, c->perm.p, nullptr, nullptr);
+		if (rc != TUTU_OK) return rc;
 	}
 	return TUTU_OK;
 }
@@ -220,7 +264,9 @@ int launch_primary(TutuCtx* c, hipStream_t s, const TutuCameraFrame* cam, int n,
 	p.prim_dir = c->prim_dir.p;
 	p.prim_hit = c->prim_hit.p;
 	p.totals = c->totals.p;
-	TIMED(EV_OTHER, k_primary<<<dim3((n + 255) / 256), dim3(256), 0, s>>>(p));
+	p.stack_entries = c->stack_entries;
+	if (c->lds_scene) TIMED(EV_OTHER, k_primary<true><<<dim3((n + 255) / 256), dim3(256), c->trace_lds_bytes, s>>>(p));
+	else TIMED(EV_OTHER, k_primary<false><<<dim3((n + 255) / 256), dim3(256), c->trace_lds_bytes, s>>>(p));
 	return TUTU_OK;
 }
 
@@ -236,7 +282,7 @@ int collect_stats(TutuCtx* c, hipStream_t s, TutuStats* st, uint64_t samples, ui
 	st->samples = samples;
 	st->closest_rays = t.closest_rays;
 	st->shadow_rays = t.shadow_rays;
-	st->segments = t.segments;
+	st->segments = samples + (t.closest_rays > (uint64_t)0 ? t.closest_rays : 0) - 0;  // vertices reached: depth-0 of every sample + every extension ray
 	st->passes = passes;
 	st->trace_launches = trace_launches;
 	float ms[EV_NKIND] = {0, 0, 0, 0};
@@ -297,7 +343,7 @@ int render_impl(TutuCtx* c, const TutuCameraFrame* cam, const TutuRenderParams* 
 	for (int s0 = 0; s0 < rp->spp; s0 += spp_pass) {
 		const int ns = std::min(spp_pass, rp->spp - s0);
 		if ((rc = run_pass(c, s, cam, rp->key0, rp->key1, npix, s0, ns, nullptr, &trace_launches)) != TUTU_OK) return rc;
-		TIMED(EV_OTHER, k_resolve<<<dim3((npix + 255) / 256), dim3(256), 0, s>>>(c->Lout.p, c->accum.p, npix, ns));
+		TIMED(EV_OTHER, k_resolve<<<dim3((npix + 255) / 256), dim3(256), 0, s>>>(c->qbuf[5].p, c->accum.p, npix, ns));
 		passes++;
 	}
 	const float spp_inv = 1.f / rp->spp;  // SPP_inv, global.hpp:20
@@ -374,6 +420,15 @@ int tutu_hip_create(const TutuSceneDesc* scene, int device, TutuCtx** out) {
 	sc.eta = c->hs.eta;
 	memcpy(sc.bkg, c->hs.bkg, 12);
 	sc.n_tris = (int)c->hs.tri_isect.size();
+	sc.n_inner = (int)c->hs.nodes.size();
+	// per-lane traversal stack: at most one push per inner node on a root-to-leaf path.  When nodes + triangles are
+	// small enough, every block also keeps a copy of them in LDS (160 KB per CU).
+	c->stack_entries = (int)c->hs.depth + 1;
+	const size_t stack_bytes = (size_t)c->stack_entries * 256 * sizeof(int);
+	const size_t scene_bytes = c->hs.nodes.size() * sizeof(GpuNode) + c->hs.tri_isect.size() * sizeof(GpuTriIsect);
+	c->lds_scene = scene_bytes > 0 && scene_bytes <= 24 * 1024;
+	c->trace_lds_bytes = (unsigned)(stack_bytes + (c->lds_scene ? scene_bytes : 0));
+	c->trace_blocks_per_cu = (int)std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / std::max<size_t>(c->trace_lds_bytes, 1)));
 	*out = c;
 	return TUTU_OK;
 }
@@ -387,10 +442,10 @@ int tutu_hip_destroy(TutuCtx* c) {
 		(void)hipEventDestroy(e.b);
 	}
 	c->d_nodes.release(); c->d_tri_isect.release(); c->d_tri_shade.release(); c->d_mats.release(); c->d_lights.release();
-	for (int w = 0; w < 2; w++)
-		for (int f = 0; f < 8; f++) c->qbuf[w][f].release();
-	c->shadowq.release(); c->Lout.release(); c->prim_dir.release(); c->prim_hit.release(); c->accum.release();
-	c->perm.release(); c->counters.release(); c->totals.release(); c->pixels.release(); c->u32a.release(); c->u32b.release();
+	for (int f = 0; f < 11; f++) c->qbuf[f].release();
+	c->prim_dir.release(); c->prim_hit.release(); c->accum.release(); c->kA.release(); c->kB.release();
+	c->flag_lists.release(); c->perm.release(); c->tile_counts.release(); c->tile_offsets.release(); c->list_meta.release();
+	c->totals.release(); c->pixels.release(); c->u32a.release(); c->u32b.release();
 	c->out_stage.release();
 	if (c->stream) (void)hipStreamDestroy(c->stream);
 	delete c;
@@ -451,7 +506,7 @@ int tutu_hip_trace_samples(TutuCtx* c, const TutuCameraFrame* cam, uint32_t n, c
 	if ((rc = launch_primary(c, s, cam, (int)n, nullptr, c->u32a.p, 0, 0, 1)) != TUTU_OK) return rc;
 	uint32_t tl = 0;
 	if ((rc = run_pass(c, s, cam, key0, key1, (int)n, 0, 1, c->u32b.p, &tl)) != TUTU_OK) return rc;
-	hipLaunchKernelGGL(k_copy_L, dim3((n + 255) / 256), dim3(256), 0, s, c->Lout.p, c->out_stage.p, (int)n);
+	hipLaunchKernelGGL(k_copy_L, dim3((n + 255) / 256), dim3(256), 0, s, c->qbuf[5].p, c->out_stage.p, (int)n);
 	HIP_TRY(hipGetLastError());
 	HIP_TRY(hipStreamSynchronize(s));
 	c->ev_used = 0;
@@ -465,13 +520,22 @@ int tutu_hip_trace_samples(TutuCtx* c, const TutuCameraFrame* cam, uint32_t n, c
 // kernel-level parity entry points
 namespace {
 
-__global__ void __launch_bounds__(256) k_test_closest(SceneDev sc, const float* o, const float* d, uint32_t n, TutuHit* hits) {
-	__shared__ int stack[TUTU_STACK_DEPTH * 256];
+template <bool LDS_SCENE>
+__global__ void __launch_bounds__(256) k_test_closest(SceneDev sc, int stack_entries, const float* o, const float* d, uint32_t n, TutuHit* hits) {
+	extern __shared__ int lds[];
+	SceneLds sl;
+	SceneGlobal sg;
+	if (LDS_SCENE) sl = stage_scene_lds(sc, lds, stack_entries);
+	else {
+		sg.nodes = sc.nodes;
+		sg.tris = sc.tri_isect;
+	}
 	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
 	if (i >= n) return;
 	float t, u, v;
 	int tri;
-	trace_closest(sc, ld3(o + 3 * (size_t)i), ld3(d + 3 * (size_t)i), stack + threadIdx.x, 256, t, u, v, tri);
+	if (LDS_SCENE) trace_closest(sl, sc, ld3(o + 3 * (size_t)i), ld3(d + 3 * (size_t)i), lds + threadIdx.x, 256, t, u, v, tri);
+	else trace_closest(sg, sc, ld3(o + 3 * (size_t)i), ld3(d + 3 * (size_t)i), lds + threadIdx.x, 256, t, u, v, tri);
 	TutuHit h;
 	h.t = t;
 	h.b1 = u;
@@ -480,11 +544,22 @@ __global__ void __launch_bounds__(256) k_test_closest(SceneDev sc, const float* 
 	hits[i] = h;
 }
 
-__global__ void __launch_bounds__(256) k_test_any(SceneDev sc, const float* o, const float* tgt, uint32_t n, uint8_t* blocked) {
-	__shared__ int stack[TUTU_STACK_DEPTH * 256];
+template <bool LDS_SCENE>
+__global__ void __launch_bounds__(256) k_test_any(SceneDev sc, int stack_entries, const float* o, const float* tgt, uint32_t n, uint8_t* blocked) {
+	extern __shared__ int lds[];
+	SceneLds sl;
+	SceneGlobal sg;
+	if (LDS_SCENE) sl = stage_scene_lds(sc, lds, stack_entries);
+	else {
+		sg.nodes = sc.nodes;
+		sg.tris = sc.tri_isect;
+	}
 	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
 	if (i >= n) return;
-	blocked[i] = trace_any(sc, ld3(o + 3 * (size_t)i), ld3(tgt + 3 * (size_t)i), stack + threadIdx.x, 256) ? 1 : 0;
+	bool b;
+	if (LDS_SCENE) b = trace_any(sl, sc, ld3(o + 3 * (size_t)i), ld3(tgt + 3 * (size_t)i), lds + threadIdx.x, 256);
+	else b = trace_any(sg, sc, ld3(o + 3 * (size_t)i), ld3(tgt + 3 * (size_t)i), lds + threadIdx.x, 256);
+	blocked[i] = b ? 1 : 0;
 }
 
 TUTU_DEV Mat mat_from_abi(const TutuMaterial& m) {
@@ -599,7 +674,8 @@ int tutu_hip_trace_closest(TutuCtx* c, uint32_t n, const float* orig, const floa
 	RC(sc.up(orig, 3 * (size_t)n, &d_o));
 	RC(sc.up(dir, 3 * (size_t)n, &d_d));
 	RC(sc.alloc((size_t)n, &d_h));
-	hipLaunchKernelGGL(k_test_closest, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->sc, d_o, d_d, n, d_h);
+	if (c->lds_scene) k_test_closest<true><<<dim3((n + 255) / 256), dim3(256), c->trace_lds_bytes, c->stream>>>(c->sc, c->stack_entries, d_o, d_d, n, d_h);
+	else k_test_closest<false><<<dim3((n + 255) / 256), dim3(256), c->trace_lds_bytes, c->stream>>>(c->sc, c->stack_entries, d_o, d_d, n, d_h);
 	HIP_TRY(hipGetLastError());
 	HIP_TRY(hipStreamSynchronize(c->stream));
 	HIP_TRY(hipMemcpy(hits, d_h, sizeof(TutuHit) * (size_t)n, hipMemcpyDeviceToHost));
@@ -616,7 +692,8 @@ int tutu_hip_trace_any(TutuCtx* c, uint32_t n, const float* orig, const float* t
 	RC(sc.up(orig, 3 * (size_t)n, &d_o));
 	RC(sc.up(target, 3 * (size_t)n, &d_t));
 	RC(sc.alloc((size_t)n, &d_b));
-	hipLaunchKernelGGL(k_test_any, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->sc, d_o, d_t, n, d_b);
+	if (c->lds_scene) k_test_any<true><<<dim3((n + 255) / 256), dim3(256), c->trace_lds_bytes, c->stream>>>(c->sc, c->stack_entries, d_o, d_t, n, d_b);
+	else k_test_any<false><<<dim3((n + 255) / 256), dim3(256), c->trace_lds_bytes, c->stream>>>(c->sc, c->stack_entries, d_o, d_t, n, d_b);
 	HIP_TRY(hipGetLastError());
 	HIP_TRY(hipStreamSynchronize(c->stream));
 	HIP_TRY(hipMemcpy(blocked, d_b, (size_t)n, hipMemcpyDeviceToHost));
