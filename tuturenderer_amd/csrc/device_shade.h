@@ -33,17 +33,19 @@ namespace tutu {
 
 struct Queue {  // structure-of-arrays path records, one per slot
 	float4* A;  // ray origin xyz | pixel index (RNG counter word 0)
-	float4* B;  // ray direction xyz (NOT normalised for mirror/refraction, as in the reference) | smp<<8 | draw
-	float4* C;  // hit: t, b1, b2 | triangle (leaf order, -1 miss)            -- written by trace_closest
+	float4* B;  // ray direction xyz (NOT normalised for mirror/refraction, as in the reference) | smp<<8 | vertex flags<<6 | draw
+	float4* C;  // hit: t, b1, b2 | triangle (leaf order, -1 miss, -2 killed by its shadow ray)   -- written by the trace stages
 	float4* D;  // beta xyz | mat_pdf of the BSDF sample at the previous vertex
-	float4* E;  // tp xyz (the reference's Russian-roulette variable, NOT the throughput) | flags
-	float4* F;  // L xyz: radiance gathered so far; final when the path has ended
-	float4* G;  // position of the previous vertex xyz | unused
+	float4* E;  // tp xyz: the reference's Russian-roulette variable (NOT the throughput); only live from depth 4 on
+	float4* F;  // L xyz: radiance gathered so far (touched only when something is added); final when the path has ended
+	float4* G;  // position of the previous vertex xyz (read only when a BSDF ray lands on a light)
 	float4* H;  // f_r at the previous vertex xyz | |Ng.wi| there
 	float4* S0;  // shadow request: origin xyz | target x
 	float4* S1;  //                 target yz | contribution xy
 	float4* S2;  //                 contribution z | flags | unused
 };
+
+#define TUTU_TRI_KILLED (-2)
 
 struct Totals {  // accumulated over a render call
 	unsigned long long closest_rays, shadow_rays, segments, pad;
@@ -65,6 +67,7 @@ struct PassParams {
 	const uint32_t* perm;     // class-sorted continuing slots (packed lists)
 	const uint32_t* cls_count;  // [8]
 	const uint32_t* cls_base;   // [8]
+	uint32_t class_mask;        // classes this launch shades
 };
 
 TUTU_DEV Mat load_mat(const SceneDev& sc, int id) {
@@ -113,16 +116,26 @@ TUTU_DEV LightSample sample_light(const SceneDev& sc, Rng& rng) {
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// shade stage.  FIRST = depth 0: paths are created from the per-pixel primary hit (all spp of a pixel share one
-// primary ray -- there is no pixel jitter in the reference, PathTracing.hpp:503-509).
-template <bool FIRST>
+// shade stage, specialised by material class ("sort by material": trace_closest files every continuing path under
+// the class of what it hit, lists<CLASS> sorts them, and each class group gets its own launch of its own kernel).
+//   SHADE_FIRST       depth 0: paths are created from the per-pixel primary hit (all spp of a pixel share one
+//                     primary ray -- no pixel jitter in the reference, PathTracing.hpp:503-509); any material
+//   SHADE_LAMBERT     LAMBERTIAN                      SHADE_MIRROR   PERFECT_REFLECTIVE
+//   SHADE_REFRACT     PERFECT_REFRACTIVE, MICROFACET_T (calcForRefractive)
+//   SHADE_GGXR        MICROFACET_R                    SHADE_TERMINAL UNLIT, emissive hit, miss: connect + end
+// Specialisation removes the other materials' code (and registers) from each kernel; results are written to the
+// path's slot as soon as they exist, so few values stay live across the BSDF code.
+enum ShadeMode { SHADE_FIRST = 0, SHADE_LAMBERT = 1, SHADE_MIRROR = 2, SHADE_REFRACT = 3, SHADE_GGXR = 4, SHADE_TERMINAL = 5 };
+
+template <int MODE>
 __global__ void __launch_bounds__(256) k_shade(PassParams pp) {
+	constexpr bool FIRST = MODE == SHADE_FIRST;
 	const SceneDev& sc = pp.sc;
 	const int lane = __lane_id();
 	const int depth = pp.depth;
 
 	// work decomposition: FIRST: grid (ceil(npix/256), samples), slot = sample*npix + item ; else: persistent,
-	// wave-sized chunks over the class-sorted list, class boundaries padded to a wave so that a wave sees one class
+	// wave-sized chunks over this launch's classes of the class-sorted list, class boundaries padded to a wave
 	uint32_t cnt[TUTU_NCLASS];
 	uint32_t base[TUTU_NCLASS];
 	uint32_t pref[TUTU_NCLASS + 1];
@@ -131,7 +144,7 @@ __global__ void __launch_bounds__(256) k_shade(PassParams pp) {
 		pref[0] = 0;
 #pragma unroll
 		for (int c = 0; c < TUTU_NCLASS; c++) {
-			cnt[c] = pp.cls_count[c];
+			cnt[c] = ((pp.class_mask >> c) & 1u) ? pp.cls_count[c] : 0u;
 			base[c] = pp.cls_base[c];
 			pref[c + 1] = pref[c] + ((cnt[c] + 63u) >> 6);
 		}
@@ -149,12 +162,10 @@ __global__ void __launch_bounds__(256) k_shade(PassParams pp) {
 			act = idx < (uint32_t)pp.npix;
 			slot = pp.smp_list ? idx : blockIdx.y * (uint32_t)pp.npix + idx;
 		} else {
-			int c = 0;
 			uint32_t cb = base[0], cn = cnt[0], cp = 0;
 #pragma unroll
 			for (int k = 1; k < TUTU_NCLASS; k++)
 				if (chunk >= pref[k]) {
-					c = k;
 					cb = base[k];
 					cn = cnt[k];
 					cp = pref[k];
@@ -162,50 +173,53 @@ __global__ void __launch_bounds__(256) k_shade(PassParams pp) {
 			const uint32_t j = (chunk - cp) * 64u + lane;
 			act = j < cn;
 			if (act) slot = pp.perm[cb + j];
-			(void)c;
+		}
+		if (!act) {
+			if (FIRST) break;
+			continue;
 		}
 
-		// ---- load the path
-		V3 o = mk1(0.f), d = mk1(0.f), beta = mk1(1.f), tp = mk1(1.f), L = mk1(0.f), prev_pos = mk1(0.f), fprev = mk1(0.f);
-		float t = FLT_MAX, b1 = 0.f, b2 = 0.f, pm = 0.f, cosprev = 0.f;
-		int tri = -1;
-		uint32_t pix = 0, smp = 0, draw = 0, flags = 0;
-		if (act) {
-			if (FIRST) {
-				const float4 pd = pp.prim_dir[idx];
-				const float4 ph = pp.prim_hit[idx];
-				o = mk(pp.eye[0], pp.eye[1], pp.eye[2]);
-				d = mk(pd.x, pd.y, pd.z);
-				pix = __float_as_uint(pd.w);
-				t = ph.x; b1 = ph.y; b2 = ph.z; tri = __float_as_int(ph.w);
-				smp = pp.smp_list ? pp.smp_list[idx] : (uint32_t)pp.s0 + blockIdx.y;
-			} else {
-				const float4 A = pp.q.A[slot], B = pp.q.B[slot], C = pp.q.C[slot], D = pp.q.D[slot];
-				const float4 E = pp.q.E[slot], F = pp.q.F[slot], G = pp.q.G[slot], H = pp.q.H[slot];
-				o = mk(A.x, A.y, A.z); pix = __float_as_uint(A.w);
-				d = mk(B.x, B.y, B.z);
-				const uint32_t sd = __float_as_uint(B.w);
-				smp = sd >> 8; draw = sd & 0xFFu;
-				t = C.x; b1 = C.y; b2 = C.z; tri = __float_as_int(C.w);
-				beta = mk(D.x, D.y, D.z); pm = D.w;
-				tp = mk(E.x, E.y, E.z); flags = __float_as_uint(E.w);
-				L = mk(F.x, F.y, F.z);
-				prev_pos = mk(G.x, G.y, G.z);
-				fprev = mk(H.x, H.y, H.z); cosprev = H.w;
+		// ---- load the path (only the fields this depth needs)
+		V3 o, d, beta = mk1(1.f), tp = mk1(1.f), fprev = mk1(0.f);
+		V3 Ladd = mk1(0.f);  // radiance this stage adds to the path
+		bool added = false;
+		float t, b1, b2, pm = 0.f, cosprev = 0.f;
+		int tri;
+		uint32_t pix, smp, draw = 0, flags = 0;
+		if (FIRST) {
+			const float4 pd = pp.prim_dir[idx];
+			const float4 ph = pp.prim_hit[idx];
+			o = mk(pp.eye[0], pp.eye[1], pp.eye[2]);
+			d = mk(pd.x, pd.y, pd.z);
+			pix = __float_as_uint(pd.w);
+			t = ph.x; b1 = ph.y; b2 = ph.z; tri = __float_as_int(ph.w);
+			smp = pp.smp_list ? pp.smp_list[idx] : (uint32_t)pp.s0 + blockIdx.y;
+		} else {
+			const float4 A = pp.q.A[slot], B = pp.q.B[slot], C = pp.q.C[slot], D = pp.q.D[slot], H = pp.q.H[slot];
+			o = mk(A.x, A.y, A.z); pix = __float_as_uint(A.w);
+			d = mk(B.x, B.y, B.z);
+			const uint32_t sd = __float_as_uint(B.w);
+			smp = sd >> 8; draw = sd & 0x3Fu; flags = (sd >> 6) & 3u;
+			t = C.x; b1 = C.y; b2 = C.z; tri = __float_as_int(C.w);
+			if (tri == TUTU_TRI_KILLED) flags |= TUTU_FLAG_KILL;
+			beta = mk(D.x, D.y, D.z); pm = D.w;
+			if ((depth - 1) > TUTU_MIN_DEPTH) {  // tp is reset to 1 for shallower vertices (PathTracing.hpp:265)
+				const float4 E = pp.q.E[slot];
+				tp = mk(E.x, E.y, E.z);
 			}
+			fprev = mk(H.x, H.y, H.z); cosprev = H.w;
 		}
 
 		Rng rng;
 		rng.init(pix, smp, draw, pp.key0, pp.key1);
-		const bool hit = tri >= 0;
-		bool fin = false;  // path ends here: write its radiance
-		bool go = act;     // proceed to shading of the vertex at `depth`
+		const bool hit = tri >= 0;  // (a killed path keeps go = false below)
+		bool go = true;  // proceed to shading of the vertex at `depth`
 
 		// hit-point data (Triangle.hpp:50-57)
 		V3 pos = mk1(0.f), Ns = mk1(0.f), Ng = mk1(0.f);
 		int mat_id = 0;
 		float hit_light_pdf = 0.f;
-		if (act && hit) {
+		if (hit) {
 			const float4 s0 = sc.tri_shade[3 * tri + 0];
 			const float4 s1 = sc.tri_shade[3 * tri + 1];
 			const float4 s2 = sc.tri_shade[3 * tri + 2];
@@ -219,75 +233,70 @@ __global__ void __launch_bounds__(256) k_shade(PassParams pp) {
 		}
 
 		// ---- connect: finish vertex depth-1 now that the hit of its BSDF ray is known (PathTracing.hpp:234-278)
-		if (act) {
-			if (FIRST) {
-				if (!hit) {  // :150
-					L = L + beta * mk(sc.bkg[0], sc.bkg[1], sc.bkg[2]);
-					fin = true;
-					go = false;
-				}
-			} else if (flags & TUTU_FLAG_KILL) {
-				fin = true;
+		if (FIRST) {
+			if (!hit) {  // :150
+				Ladd = beta * mk(sc.bkg[0], sc.bkg[1], sc.bkg[2]);
+				added = true;
 				go = false;
-			} else if (flags & TUTU_FLAG_PREV_REFRACTIVE) {
-				if (!hit) {  // :150 reached through calcForRefractive's recursive call
-					L = L + beta * mk(sc.bkg[0], sc.bkg[1], sc.bkg[2]);
-					fin = true;
-					go = false;
-				}
-			} else if (!hit) {  // :234 -- background is NOT added for secondary misses
-				fin = true;
+			}
+		} else if (flags & TUTU_FLAG_KILL) {
+			go = false;
+		} else if (flags & TUTU_FLAG_PREV_REFRACTIVE) {
+			if (!hit) {  // :150 reached through calcForRefractive's recursive call
+				Ladd = beta * mk(sc.bkg[0], sc.bkg[1], sc.bkg[2]);
+				added = true;
 				go = false;
-			} else {
-				bool indirect = true;
-				if (hit_light_pdf) {  // getLightPdf > 0 (:239-240); non-zero test, as there
-					const V3 light_N = normalized(Ns);
-					const float cos_theta_prime = dot(light_N, -d);
-					if (!(cos_theta_prime <= 0)) {  // else: back of a light, falls into the indirect branch (:243-244)
-						indirect = false;
-						const float r2 = norm2(pos - prev_pos);
-						const float l_pdf_transformed = hit_light_pdf * r2 / cos_theta_prime;
-						float mis_weight_m = getMisWeight(pm, l_pdf_transformed);
-						if (flags & TUTU_FLAG_PREV_MIRROR_PM1) mis_weight_m = 1.f;
-						const Mat lm = load_mat(sc, mat_id);
-						if (!(pm < TUTU_MIN_DIVISOR)) L = L + beta * (mis_weight_m * lm.emission * fprev * cosprev / pm);
-						fin = true;
-						go = false;
+			}
+		} else if (!hit) {  // :234 -- background is NOT added for secondary misses
+			go = false;
+		} else {
+			bool indirect = true;
+			if (hit_light_pdf) {  // getLightPdf > 0 (:239-240); non-zero test, as there
+				const V3 light_N = normalized(Ns);
+				const float cos_theta_prime = dot(light_N, -d);
+				if (!(cos_theta_prime <= 0)) {  // else: back of a light, falls into the indirect branch (:243-244)
+					indirect = false;
+					const float4 G = pp.q.G[slot];
+					const float r2 = norm2(pos - mk(G.x, G.y, G.z));
+					const float l_pdf_transformed = hit_light_pdf * r2 / cos_theta_prime;
+					float mis_weight_m = getMisWeight(pm, l_pdf_transformed);
+					if (flags & TUTU_FLAG_PREV_MIRROR_PM1) mis_weight_m = 1.f;
+					const float4 em = sc.mats[4 * mat_id + 1];
+					if (!(pm < TUTU_MIN_DIVISOR)) {
+						Ladd = beta * (mis_weight_m * mk(em.x, em.y, em.z) * fprev * cosprev / pm);
+						added = true;
 					}
+					go = false;
 				}
-				if (indirect) {  // :264-277
-					tp = (depth - 1) > TUTU_MIN_DEPTH ? tp : mk1(1.f);
-					const float rr_prob = std_max(tp.x, std_max(tp.y, tp.z));
-					if (rng.next() > rr_prob) {
-						fin = true;
+			}
+			if (indirect) {  // :264-277
+				tp = (depth - 1) > TUTU_MIN_DEPTH ? tp : mk1(1.f);
+				const float rr_prob = std_max(tp.x, std_max(tp.y, tp.z));
+				if (rng.next() > rr_prob) {
+					go = false;
+				} else {
+					const V3 coe = fprev * cosprev / (pm * rr_prob);
+					if (pm * rr_prob < TUTU_MIN_DIVISOR) {
 						go = false;
 					} else {
-						const V3 coe = fprev * cosprev / (pm * rr_prob);
-						if (pm * rr_prob < TUTU_MIN_DIVISOR) {
-							fin = true;
-							go = false;
-						} else {
-							tp = tp * coe;
-							beta = beta * coe;
-						}
+						tp = tp * coe;
+						beta = beta * coe;
 					}
 				}
 			}
-			if (go && depth > TUTU_MAX_DEPTH) {  // :140 / :82
-				fin = true;
-				go = false;
-			}
 		}
+		if (go && depth > TUTU_MAX_DEPTH) go = false;  // :140 / :82
 
-		// ---- shade the vertex at `depth`
-		bool has_next = false, has_shadow = false;
-		V3 n_o = mk1(0.f), n_d = mk1(0.f), n_f = mk1(0.f), sh_o = mk1(0.f), sh_t = mk1(0.f), sh_c = mk1(0.f);
-		float n_pm = 0.f, n_cos = 0.f;
-		uint32_t n_flags = 0, sh_flags = 0;
+		// ---- shade the vertex at `depth`; every result goes to the slot as soon as it exists
+		uint32_t key = 0;
 		if (go) {
 			Mat m = load_mat(sc, mat_id);  // per-hit copy, like Intersection::mtlcolor
+			if (MODE == SHADE_LAMBERT) m.type = TUTU_LAMBERTIAN;  // class-sorted: known at compile time
+			if (MODE == SHADE_MIRROR) m.type = TUTU_PERFECT_REFLECTIVE;
+			if (MODE == SHADE_GGXR) m.type = TUTU_MICROFACET_R;
 			const V3 wo = -d;
-			if (m.type == TUTU_PERFECT_REFRACTIVE || m.type == TUTU_MICROFACET_T) {
+			const bool refractive = m.type == TUTU_PERFECT_REFRACTIVE || m.type == TUTU_MICROFACET_T;
+			if ((FIRST || MODE == SHADE_REFRACT) && refractive) {
 				// calcForRefractive, PathTracing.hpp:80-134
 				float eta_i = sc.eta, eta_t = m.eta;
 				V3 wi = mk1(0.f);
@@ -321,32 +330,27 @@ __global__ void __launch_bounds__(256) k_shade(PassParams pp) {
 					cosv = fabsf(dot(-Ng, wi));
 				}
 				// :128-133 -- the reference traces the continuation and then drops it when pdf < MIN_DIVISOR
-				if (p < TUTU_MIN_DIVISOR || depth + 1 > TUTU_MAX_DEPTH) {
-					fin = true;
-				} else {
+				if (!(p < TUTU_MIN_DIVISOR || depth + 1 > TUTU_MAX_DEPTH)) {
 					beta = ((beta * cosv) * f_r) / p;
-					tp = mk1(1.f);
-					n_o = rayOrig;
-					n_d = wi;
-					n_flags = TUTU_FLAG_PREV_REFRACTIVE;
-					has_next = true;
+					pp.q.A[slot] = make_float4(rayOrig.x, rayOrig.y, rayOrig.z, __uint_as_float(pix));
+					pp.q.B[slot] = make_float4(wi.x, wi.y, wi.z, __uint_as_float((smp << 8) | (TUTU_FLAG_PREV_REFRACTIVE << 6) | (rng.draw & 0x3Fu)));
+					pp.q.D[slot] = make_float4(beta.x, beta.y, beta.z, 0.f);
+					if (depth >= TUTU_MIN_DEPTH + 1) pp.q.E[slot] = make_float4(1.f, 1.f, 1.f, 0.f);  // tp = 1
+					key = TUTU_KEY_NEXT;
 				}
-			} else if (m.type == TUTU_UNLIT) {  // :161
-				L = L + beta * m.diffuse;
-				fin = true;
-			} else if (m.has_emission) {  // :164-170
-				if (depth == 0) L = L + beta * m.emission;
-				fin = true;
-			} else {
+			} else if ((FIRST || MODE == SHADE_TERMINAL) && m.type == TUTU_UNLIT) {  // :161
+				Ladd = beta * m.diffuse;
+				added = true;
+			} else if ((FIRST || MODE == SHADE_TERMINAL) && m.has_emission) {  // :164-170
+				if (depth == 0) {
+					Ladd = beta * m.emission;
+					added = true;
+				}
+			} else if (MODE != SHADE_TERMINAL && MODE != SHADE_REFRACT) {
 				// ---- light sampling, :180-219
+				bool kill_req = false;
 				if (sc.n_lights > 0) {
 					const LightSample ls = sample_light(sc, rng);
-					const bool rayInside = dot(Ns, wo) < 0;
-					V3 shadowRayOrig = pos;
-					V3 lightPos = ls.pos;
-					if (rayInside) shadowRayOrig = shadowRayOrig - Ns * TUTU_EPSILON;
-					else shadowRayOrig = shadowRayOrig + Ns * TUTU_EPSILON;
-					lightPos = lightPos + ls.N * TUTU_EPSILON;
 					V3 wi = ls.pos - pos;
 					const float r2 = norm2(wi);
 					wi = normalized(wi);
@@ -360,14 +364,23 @@ __global__ void __launch_bounds__(256) k_shade(PassParams pp) {
 							const float light_pdf = pdfl * r2 / cos_theta_prime;
 							const float mis_weight_l = getMisWeight(light_pdf, mpdf);
 							const V3 f_r = BxDF(m, wi, wo, Ng, Ns, sc.eta, false);
-							sh_o = shadowRayOrig;
-							sh_t = lightPos;
-							has_shadow = true;
+							const bool rayInside = dot(Ns, wo) < 0;
+							V3 shadowRayOrig = pos;
+							if (rayInside) shadowRayOrig = shadowRayOrig - Ns * TUTU_EPSILON;
+							else shadowRayOrig = shadowRayOrig + Ns * TUTU_EPSILON;
+							const V3 lightPos = ls.pos + ls.N * TUTU_EPSILON;
+							V3 sh_c = mk1(0.f);
+							uint32_t sh_flags = 0;
 							if (r2 * pdfl < TUTU_MIN_DIVISOR) {
 								sh_flags = TUTU_FLAG_KILL;  // :215: an UNBLOCKED shadow ray ends the whole path here
+								kill_req = true;
 							} else {
 								sh_c = beta * (mis_weight_l * ls.emission * f_r * cos_theta * cos_theta_prime / (r2 * pdfl));
 							}
+							pp.q.S0[slot] = make_float4(shadowRayOrig.x, shadowRayOrig.y, shadowRayOrig.z, lightPos.x);
+							pp.q.S1[slot] = make_float4(lightPos.y, lightPos.z, sh_c.x, sh_c.y);
+							pp.q.S2[slot] = make_float4(sh_c.z, __uint_as_float(sh_flags), 0.f, 0.f);
+							key |= TUTU_KEY_SHADOW;
 						}
 					}
 				}
@@ -375,43 +388,36 @@ __global__ void __launch_bounds__(256) k_shade(PassParams pp) {
 				V3 wi = mk1(0.f);
 				bool ok, special;
 				sampleDirection(m, wo, Ns, wi, sc.eta, rng, ok, special);
-				if (!ok) {
-					fin = true;  // :225-226
-				} else {
-					n_pm = mat_pdf(m, wi, wo, Ns, sc.eta, m.eta);
+				if (ok) {  // else :225-226
+					const float n_pm = mat_pdf(m, wi, wo, Ns, sc.eta, m.eta);
 					V3 rayOrig = pos;
 					if (dot(wi, Ns) < 0) rayOrig = rayOrig - Ns * TUTU_EPSILON;
 					else rayOrig = rayOrig + Ns * TUTU_EPSILON;
-					n_f = BxDF(m, wi, wo, Ng, Ns, sc.eta, false);
-					n_cos = fabsf(dot(Ng, wi));
-					n_o = rayOrig;
-					n_d = wi;
-					n_flags = (m.type == TUTU_PERFECT_REFLECTIVE && n_pm == 1.f) ? TUTU_FLAG_PREV_MIRROR_PM1 : 0u;
-					has_next = true;
+					const V3 n_f = BxDF(m, wi, wo, Ng, Ns, sc.eta, false);
+					const float n_cos = fabsf(dot(Ng, wi));
+					const uint32_t n_flags = (m.type == TUTU_PERFECT_REFLECTIVE && n_pm == 1.f) ? TUTU_FLAG_PREV_MIRROR_PM1 : 0u;
+					pp.q.A[slot] = make_float4(rayOrig.x, rayOrig.y, rayOrig.z, __uint_as_float(pix));
+					pp.q.B[slot] = make_float4(wi.x, wi.y, wi.z, __uint_as_float((smp << 8) | (n_flags << 6) | (rng.draw & 0x3Fu)));
+					pp.q.D[slot] = make_float4(beta.x, beta.y, beta.z, n_pm);
+					if (depth >= TUTU_MIN_DEPTH + 1) pp.q.E[slot] = make_float4(tp.x, tp.y, tp.z, 0.f);
+					pp.q.G[slot] = make_float4(pos.x, pos.y, pos.z, 0.f);
+					pp.q.H[slot] = make_float4(n_f.x, n_f.y, n_f.z, n_cos);
+					key |= TUTU_KEY_NEXT;
+				} else if (kill_req) {
+					key &= ~TUTU_KEY_SHADOW;  // the path ends here anyway: nothing left for the shadow ray to kill
 				}
-				if (has_shadow && (sh_flags & TUTU_FLAG_KILL) && !has_next) has_shadow = false;  // nothing left to kill
 			}
 		}
-
-		// ---- outputs, in place
-		(void)fin;
-		if (act) {
-			if (has_next) {
-				pp.q.A[slot] = make_float4(n_o.x, n_o.y, n_o.z, __uint_as_float(pix));
-				pp.q.B[slot] = make_float4(n_d.x, n_d.y, n_d.z, __uint_as_float((smp << 8) | (rng.draw & 0xFFu)));
-				pp.q.D[slot] = make_float4(beta.x, beta.y, beta.z, n_pm);
-				pp.q.E[slot] = make_float4(tp.x, tp.y, tp.z, __uint_as_float(n_flags));
-				pp.q.G[slot] = make_float4(pos.x, pos.y, pos.z, 0.f);
-				pp.q.H[slot] = make_float4(n_f.x, n_f.y, n_f.z, n_cos);
-			}
-			if (has_shadow) {
-				pp.q.S0[slot] = make_float4(sh_o.x, sh_o.y, sh_o.z, sh_t.x);
-				pp.q.S1[slot] = make_float4(sh_t.y, sh_t.z, sh_c.x, sh_c.y);
-				pp.q.S2[slot] = make_float4(sh_c.z, __uint_as_float(sh_flags), 0.f, 0.f);
-			}
-			pp.q.F[slot] = make_float4(L.x, L.y, L.z, 0.f);  // radiance so far; final if the path ended here
-			pp.kA[slot] = (uint8_t)((has_next ? TUTU_KEY_NEXT : 0u) | (has_shadow ? TUTU_KEY_SHADOW : 0u));
+		// radiance: depth 0 initialises the accumulator; later stages touch it only when they add something.
+		// (a path always has at most one such term per stage: background, UNLIT, emission or MIS-weighted emission)
+		if (FIRST) {
+			pp.q.F[slot] = make_float4(Ladd.x, Ladd.y, Ladd.z, 0.f);  // 0 + term
+		} else if (added) {
+			float4 F = pp.q.F[slot];
+			F.x = F.x + Ladd.x; F.y = F.y + Ladd.y; F.z = F.z + Ladd.z;
+			pp.q.F[slot] = F;
 		}
+		pp.kA[slot] = (uint8_t)key;
 		if (FIRST) break;
 	}
 }
@@ -495,9 +501,7 @@ __global__ void __launch_bounds__(256) k_trace_any(ShadowParams sp) {
 		else blocked = trace_any(sg, sp.sc, so, lo, lds + threadIdx.x, 256);
 		if (!blocked) {
 			if (fl & TUTU_FLAG_KILL) {
-				float4 E = sp.q.E[slot];
-				E.w = __uint_as_float(__float_as_uint(E.w) | TUTU_FLAG_KILL);
-				sp.q.E[slot] = E;
+				reinterpret_cast<int*>(&sp.q.C[slot])[3] = TUTU_TRI_KILLED;  // the hit of the (speculative) extension ray is void
 			} else {
 				float4 F = sp.q.F[slot];
 				F.x = F.x + c.x; F.y = F.y + c.y; F.z = F.z + c.z;

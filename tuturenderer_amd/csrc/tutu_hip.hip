@@ -69,6 +69,7 @@ struct TutuCtx {
 	int stack_entries = TUTU_STACK_DEPTH;
 	unsigned trace_lds_bytes = TUTU_STACK_DEPTH * 256 * sizeof(int);
 	bool lds_scene = false;
+	uint32_t type_mask = 0;  // MaterialType values present among the non-emissive materials
 	int trace_blocks_per_cu = 5;
 	HostScene hs;
 	SceneDev sc;
@@ -214,12 +215,31 @@ int run_pass(TutuCtx* c, hipStream_t s, const TutuCameraFrame* cam, uint32_t key
 		uint32_t* meta = c->list_meta.p + (size_t)TUTU_META_STRIDE * d;  // [0..8) flag counts, [8..16) flag bases, [16..24) class counts, [24..32) class bases
 		if (d == 0) {
 			dim3 g((unsigned)((npix + 255) / 256), (unsigned)nsamp, 1);
-			TIMED(EV_SHADE, k_shade<true><<<g, dim3(256), 0, s>>>(pp));
+			TIMED(EV_SHADE, k_shade<SHADE_FIRST><<<g, dim3(256), 0, s>>>(pp));
 		} else {
+			// one launch per material class group that exists in the scene (sort-by-material pipeline)
 			uint32_t* pm = c->list_meta.p + (size_t)TUTU_META_STRIDE * (d - 1);
 			pp.cls_count = pm + 16;
 			pp.cls_base = pm + 24;
-			TIMED(EV_SHADE, k_shade<false><<<dim3(shade_grid), dim3(256), 0, s>>>(pp));
+			const uint32_t types = c->type_mask;
+			if (types & (1u << TUTU_LAMBERTIAN)) {
+				pp.class_mask = 1u << TUTU_LAMBERTIAN;
+				TIMED(EV_SHADE, k_shade<SHADE_LAMBERT><<<dim3(shade_grid), dim3(256), 0, s>>>(pp));
+			}
+			if (types & (1u << TUTU_PERFECT_REFLECTIVE)) {
+				pp.class_mask = 1u << TUTU_PERFECT_REFLECTIVE;
+				TIMED(EV_SHADE, k_shade<SHADE_MIRROR><<<dim3(shade_grid), dim3(256), 0, s>>>(pp));
+			}
+			if (types & ((1u << TUTU_PERFECT_REFRACTIVE) | (1u << TUTU_MICROFACET_T))) {
+				pp.class_mask = (1u << TUTU_PERFECT_REFRACTIVE) | (1u << TUTU_MICROFACET_T);
+				TIMED(EV_SHADE, k_shade<SHADE_REFRACT><<<dim3(shade_grid), dim3(256), 0, s>>>(pp));
+			}
+			if (types & (1u << TUTU_MICROFACET_R)) {
+				pp.class_mask = 1u << TUTU_MICROFACET_R;
+				TIMED(EV_SHADE, k_shade<SHADE_GGXR><<<dim3(shade_grid), dim3(256), 0, s>>>(pp));
+			}
+			pp.class_mask = (1u << TUTU_UNLIT) | (1u << TUTU_CLASS_EMISSIVE) | (1u << TUTU_CLASS_MISS);
+			TIMED(EV_SHADE, k_shade<SHADE_TERMINAL><<<dim3(std::max(1, shade_grid / 4)), dim3(256), 0, s>>>(pp));
 		}
 		if (d == TUTU_MAX_DEPTH + 1) break;  // the last shade only connects; nothing continues
 		int rc = build_lists<LIST_FLAGS>(c, s, n_pad, meta, meta + 8, c->flag_lists.p, &c->totals.p->closest_rays, &c->totals.p->shadow_rays);
@@ -421,6 +441,9 @@ int tutu_hip_create(const TutuSceneDesc* scene, int device, TutuCtx** out) {
 	memcpy(sc.bkg, c->hs.bkg, 12);
 	sc.n_tris = (int)c->hs.tri_isect.size();
 	sc.n_inner = (int)c->hs.nodes.size();
+	c->type_mask = 0;
+	for (const GpuMaterial& m : c->hs.mats)
+		if (m.type >= 0 && m.type <= TUTU_UNLIT) c->type_mask |= 1u << m.type;
 	// per-lane traversal stack: at most one push per inner node on a root-to-leaf path.  When nodes + triangles are
 	// small enough, every block also keeps a copy of them in LDS (160 KB per CU).
 	c->stack_entries = (int)c->hs.depth + 1;
