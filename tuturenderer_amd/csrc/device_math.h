@@ -79,8 +79,11 @@ struct Rng {
 		uint32_t c0 = pix, c1 = smp, c2 = block, c3 = 0u, k0 = key0, k1 = key1;
 #pragma unroll
 		for (int r = 0; r < 10; r++) {
-			const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
-			const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+			// one 32x32->64 multiply per product (v_mad_u64_u32) instead of separate mul_lo / mul_hi
+			const unsigned long long p0 = (unsigned long long)0xD2511F53u * c0;
+			const unsigned long long p1 = (unsigned long long)0xCD9E8D57u * c2;
+			const uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0;
+			const uint32_t hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
 			const uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
 			c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
 			k0 += 0x9E3779B9u;

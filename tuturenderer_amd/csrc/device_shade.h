@@ -423,91 +423,170 @@ __global__ void __launch_bounds__(256) k_shade(PassParams pp) {
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// closest-hit stage over the continuing slots: writes the hit (C) and its material class (kB)
+// Traversal stages: persistent waves with per-lane ray refill.
+//
+// Every wave owns a contiguous range of the work list.  A lane keeps one ray in flight; the wave alternates
+//   refill  -- idle lanes (found with __ballot, ranked with __popcll) take the next rays of the wave's range,
+//   inner   -- up to TUTU_INNER_STEPS node visits for the lanes that sit on an inner node,
+//   leaf    -- one triangle test for the lanes that sit on a leaf,
+//   finish  -- lanes whose traversal ended write their result and become idle,
+// so a lane whose ray ends early is given new work instead of waiting for the slowest ray of its wave (the plain
+// one-ray-per-lane loop ran with ~26 % of its lanes active on the Cornell box).  The loop ends when the range is
+// exhausted and every lane is idle: an exit condition every wave reaches.
+#define TUTU_INNER_STEPS 3
+#define TUTU_TRAV_IDLE (INT_MIN + 1)
+
 struct TraceParams {
 	SceneDev sc;
 	Queue q;
 	const uint32_t* list;   // slots to trace
 	const uint32_t* n_ptr;  // device count
-	uint8_t* kB;
+	uint8_t* kA;            // any-hit: the consumed request's flag is cleared
+	uint8_t* kB;            // closest-hit: material class of the hit
+	const uint8_t* tri_class;  // per triangle (leaf order): class of its material
 	int stack_entries;
 };
 
-TUTU_DEV int hit_class(const SceneDev& sc, int tri) {
-	if (tri < 0) return TUTU_CLASS_MISS;
-	const int mat = __float_as_int(sc.tri_shade[3 * tri + 2].y);
-	const int type = __float_as_int(sc.mats[4 * mat + 0].w);
-	const int emis = __float_as_int(sc.mats[4 * mat + 1].w);
-	// refractive types are tested before emission in traceRay (PathTracing.hpp:152-170)
-	int cls = (emis && type != TUTU_PERFECT_REFRACTIVE && type != TUTU_MICROFACET_T) ? TUTU_CLASS_EMISSIVE : type;
-	if (cls < 0 || cls > TUTU_CLASS_EMISSIVE) cls = TUTU_UNLIT;  // unknown enum values: filed with UNLIT, shaded by their own `default:` branches
-	return cls;
-}
-
-template <bool LDS_SCENE>
-__global__ void __launch_bounds__(256) k_trace_closest(TraceParams tp) {
-	extern __shared__ int lds[];  // [stack entries][256 lanes] | optional scene copy
+template <typename S, bool ANY>
+TUTU_DEV void trace_persistent(const S& ss, const TraceParams& tp, int* stack, const uint8_t* tri_class) {
 	const SceneDev& sc = tp.sc;
-	SceneLds sl;
-	SceneGlobal sg;
-	if (LDS_SCENE) sl = stage_scene_lds(sc, lds, tp.stack_entries);
-	else {
-		sg.nodes = sc.nodes;
-		sg.tris = sc.tri_isect;
-	}
+	const int lane = __lane_id();
+	const unsigned long long lt_mask = (1ull << lane) - 1ull;
 	const uint32_t n = *tp.n_ptr;
-	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-		const uint32_t slot = tp.list[i];
-		const float4 A = tp.q.A[slot], B = tp.q.B[slot];
-		float t, u, v;
-		int tri;
-		if (LDS_SCENE) trace_closest(sl, sc, mk(A.x, A.y, A.z), mk(B.x, B.y, B.z), lds + threadIdx.x, 256, t, u, v, tri);
-		else trace_closest(sg, sc, mk(A.x, A.y, A.z), mk(B.x, B.y, B.z), lds + threadIdx.x, 256, t, u, v, tri);
-		tp.q.C[slot] = make_float4(t, u, v, __int_as_float(tri));
-		tp.kB[slot] = (uint8_t)hit_class(sc, tri);
-	}
-}
+	const uint32_t n_waves = (gridDim.x * blockDim.x) >> 6;
+	const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+	const uint32_t per = (n + n_waves - 1) / n_waves;
+	const uint32_t begin = min(n, wave * per), end = min(n, begin + per);
+	uint32_t next = begin;
 
-// any-hit stage over the shadow requests
-struct ShadowParams {
-	SceneDev sc;
-	Queue q;
-	const uint32_t* list;
-	const uint32_t* n_ptr;
-	uint8_t* kA;
-	int stack_entries;
-};
+	int cur = TUTU_TRAV_IDLE;
+	int sp = 0;
+	uint32_t slot = 0;
+	RayPre r = make_ray(mk1(0.f), mk1(1.f));
+	float best_t = FLT_MAX, best_u = 0.f, best_v = 0.f;
+	int best_tri = -1;
+	// any-hit only
+	float dis = 0.f;
+	V3 contrib = mk1(0.f);
+	uint32_t fl = 0;
+	bool blocked = false;
 
-template <bool LDS_SCENE>
-__global__ void __launch_bounds__(256) k_trace_any(ShadowParams sp) {
-	extern __shared__ int lds[];
-	SceneLds sl;
-	SceneGlobal sg;
-	if (LDS_SCENE) sl = stage_scene_lds(sp.sc, lds, sp.stack_entries);
-	else {
-		sg.nodes = sp.sc.nodes;
-		sg.tris = sp.sc.tri_isect;
-	}
-	const uint32_t n = *sp.n_ptr;
-	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-		const uint32_t slot = sp.list[i];
-		const float4 e0 = sp.q.S0[slot], e1 = sp.q.S1[slot], e2 = sp.q.S2[slot];
-		const V3 so = mk(e0.x, e0.y, e0.z), lo = mk(e0.w, e1.x, e1.y), c = mk(e1.z, e1.w, e2.x);
-		const uint32_t fl = __float_as_uint(e2.y);
-		// the request is consumed: a path that ended at this vertex is never re-shaded, so its flag must not survive
-		sp.kA[slot] = (uint8_t)(sp.kA[slot] & ~TUTU_KEY_SHADOW);
-		bool blocked;
-		if (LDS_SCENE) blocked = trace_any(sl, sp.sc, so, lo, lds + threadIdx.x, 256);
-		else blocked = trace_any(sg, sp.sc, so, lo, lds + threadIdx.x, 256);
-		if (!blocked) {
-			if (fl & TUTU_FLAG_KILL) {
-				reinterpret_cast<int*>(&sp.q.C[slot])[3] = TUTU_TRI_KILLED;  // the hit of the (speculative) extension ray is void
-			} else {
-				float4 F = sp.q.F[slot];
-				F.x = F.x + c.x; F.y = F.y + c.y; F.z = F.z + c.z;
-				sp.q.F[slot] = F;
+	for (;;) {
+		// ---- refill
+		const unsigned long long idle = __ballot(cur == TUTU_TRAV_IDLE);
+		if (idle != 0ull && next < end) {
+			const uint32_t i = next + (uint32_t)__popcll(idle & lt_mask);
+			if (cur == TUTU_TRAV_IDLE && i < end) {
+				slot = tp.list[i];
+				if (!ANY) {
+					const float4 A = tp.q.A[slot], B = tp.q.B[slot];
+					r = make_ray(mk(A.x, A.y, A.z), mk(B.x, B.y, B.z));
+					best_t = FLT_MAX; best_u = 0.f; best_v = 0.f; best_tri = -1;
+				} else {
+					const float4 e0 = tp.q.S0[slot], e1 = tp.q.S1[slot], e2 = tp.q.S2[slot];
+					const V3 so = mk(e0.x, e0.y, e0.z), lo = mk(e0.w, e1.x, e1.y);
+					contrib = mk(e1.z, e1.w, e2.x);
+					fl = __float_as_uint(e2.y);
+					// isShadowRayBlocked, IIntegrator.hpp:135-137
+					const V3 raydir = normalized(lo - so);
+					dis = norm(lo - so);
+					r = make_ray(so, raydir);
+					blocked = false;
+					// the request is consumed: a path that ended at this vertex is never re-shaded, so its flag must not survive
+					tp.kA[slot] = (uint8_t)(tp.kA[slot] & ~TUTU_KEY_SHADOW);
+				}
+				sp = 0;
+				float te;
+				if (sc.root_ref == INT_MIN ||
+				    !slab(r, sc.root_min[0], sc.root_min[1], sc.root_min[2], sc.root_max[0], sc.root_max[1], sc.root_max[2], te))
+					cur = TUTU_TRAV_DONE;
+				else cur = sc.root_ref;
+			}
+			next += (uint32_t)__popcll(idle);
+		}
+		if (__ballot(cur != TUTU_TRAV_IDLE) == 0ull) break;
+
+		// ---- inner nodes
+#pragma unroll 1
+		for (int k = 0; k < TUTU_INNER_STEPS; k++) {
+			if (__ballot(cur >= 0) == 0ull) break;
+			if (cur >= 0) {
+				float lim;
+				if (ANY) lim = dis * TUTU_PRUNE_SLACK;
+				else lim = best_tri >= 0 ? best_t * TUTU_PRUNE_SLACK : FLT_MAX;
+				const ChildTest ct = test_children(ss, cur, r, lim);
+				if (ct.hl && ct.hr) {
+					const bool right_first = !ANY && ct.tr < ct.tl;
+					stack[sp * 256] = right_first ? ct.left : ct.right;
+					sp++;
+					cur = right_first ? ct.right : ct.left;
+				} else if (ct.hl) {
+					cur = ct.left;
+				} else if (ct.hr) {
+					cur = ct.right;
+				} else if (sp == 0) {
+					cur = TUTU_TRAV_DONE;
+				} else {
+					sp--;
+					cur = stack[sp * 256];
+				}
 			}
 		}
+
+		// ---- leaf
+		if (cur < 0 && cur > TUTU_TRAV_IDLE) {
+			const int ti = ~cur;
+			float t, u, v;
+			const bool h = tri_test(ss, ti, r, t, u, v);
+			if (ANY) {
+				if (h && t < dis && !float_equal(t, dis)) blocked = true;  // BVH.hpp:186
+			} else if (h && (t < best_t || (t == best_t && ti < best_tri))) {
+				best_t = t; best_u = u; best_v = v; best_tri = ti;
+			}
+			if ((ANY && blocked) || sp == 0) {
+				cur = TUTU_TRAV_DONE;
+			} else {
+				sp--;
+				cur = stack[sp * 256];
+			}
+		}
+
+		// ---- finish
+		if (cur == TUTU_TRAV_DONE) {
+			if (!ANY) {
+				tp.q.C[slot] = make_float4(best_t, best_u, best_v, __int_as_float(best_tri));
+				tp.kB[slot] = best_tri >= 0 ? tri_class[best_tri] : (uint8_t)TUTU_CLASS_MISS;
+			} else if (!blocked) {
+				if (fl & TUTU_FLAG_KILL) {
+					reinterpret_cast<int*>(&tp.q.C[slot])[3] = TUTU_TRI_KILLED;  // the hit of the (speculative) extension ray is void
+				} else {
+					float4 F = tp.q.F[slot];
+					F.x = F.x + contrib.x; F.y = F.y + contrib.y; F.z = F.z + contrib.z;
+					tp.q.F[slot] = F;
+				}
+			}
+			cur = TUTU_TRAV_IDLE;
+		}
+	}
+}
+
+// LDS carve-up with the per-triangle class table appended to the staged scene
+template <bool LDS_SCENE, bool ANY>
+__global__ void __launch_bounds__(256) k_trace(TraceParams tp) {
+	extern __shared__ int lds[];  // [stack entries][256 lanes] | optional scene copy | optional class table
+	if (LDS_SCENE) {
+		const SceneLds sl = stage_scene_lds(tp.sc, lds, tp.stack_entries);
+		uint8_t* cls = reinterpret_cast<uint8_t*>(const_cast<float4*>(sl.tris + 3 * tp.sc.n_tris));
+		if (!ANY) {
+			for (int i = threadIdx.x; i < tp.sc.n_tris; i += blockDim.x) cls[i] = tp.tri_class[i];
+			__syncthreads();
+		}
+		trace_persistent<SceneLds, ANY>(sl, tp, lds + threadIdx.x, cls);
+	} else {
+		SceneGlobal sg;
+		sg.nodes = tp.sc.nodes;
+		sg.tris = tp.sc.tri_isect;
+		trace_persistent<SceneGlobal, ANY>(sg, tp, lds + threadIdx.x, tp.tri_class);
 	}
 }
 

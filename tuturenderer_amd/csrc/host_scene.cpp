@@ -228,6 +228,7 @@ int build_host_scene(const TutuSceneDesc* d, HostScene& hs) {
 
 	hs.tri_isect.resize(n);
 	hs.tri_shade.resize(n);
+	hs.tri_class.assign(n, 0);
 	std::vector<float> area(n, 0.f);
 	for (uint32_t li = 0; li < n; li++) {
 		const int32_t o = order[li];
@@ -248,6 +249,14 @@ int build_host_scene(const TutuSceneDesc* d, HostScene& hs) {
 		s.mat = d->mat_id[o];
 		s.orig = o;
 		s.light_pdf = hs.mats[s.mat].has_emission ? 1 / (size * area[li]) : 0.f;  // getLightPdf  IIntegrator.hpp:166-167
+		{
+			// class the shade stage files this triangle's hits under.  traceRay tests the refractive types before
+			// emission (PathTracing.hpp:152-170), so an emissive refractive material shades as refractive.
+			const GpuMaterial& gm = hs.mats[s.mat];
+			int cls = (gm.has_emission && gm.type != TUTU_PERFECT_REFRACTIVE && gm.type != TUTU_MICROFACET_T) ? 6 : gm.type;
+			if (cls < 0 || cls > 6) cls = TUTU_UNLIT;  // unknown enum values: filed with UNLIT, shaded by their own `default:` branches
+			hs.tri_class[li] = (uint8_t)cls;
+		}
 	}
 	hs.lights.resize(light_orig.size());
 	for (size_t k = 0; k < light_orig.size(); k++) {

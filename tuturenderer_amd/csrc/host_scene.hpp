@@ -66,6 +66,7 @@ struct HostScene {
 	std::vector<GpuNode> nodes;       // inner nodes; nodes[0] is the root when n_tris >= 2
 	std::vector<GpuTriIsect> tri_isect;  // leaf order
 	std::vector<GpuTriShade> tri_shade;  // leaf order
+	std::vector<uint8_t> tri_class;      // leaf order: material class of the triangle (0..5 MaterialType, 6 emissive)
 	std::vector<GpuMaterial> mats;
 	std::vector<GpuLight> lights;
 	std::vector<int32_t> leaf_of_orig;  // original triangle index -> leaf-order index

@@ -6,6 +6,7 @@
 #include <algorithm>
 #include <climits>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -74,6 +75,7 @@ struct TutuCtx {
 	HostScene hs;
 	SceneDev sc;
 	DevBuf<float4> d_nodes, d_tri_isect, d_tri_shade, d_mats, d_lights;
+	DevBuf<uint8_t> d_tri_class;
 	// work buffers
 	size_t cap = 0;         // path slots (multiple of TUTU_LIST_TILE)
 	DevBuf<float4> qbuf[11];  // A..H, S0..S2
@@ -208,7 +210,10 @@ int run_pass(TutuCtx* c, hipStream_t s, const TutuCameraFrame* cam, uint32_t key
 	pp.kA = c->kA.p;
 	pp.perm = c->perm.p;
 
-	const int shade_grid = persistent_grid(npaths, c->n_cu, 8);
+	// shade: one wave-sized chunk per wave (grid covers the worst case; surplus waves exit at once).  A persistent
+	// loop serialises on the in-order vmcnt counter: the next chunk's loads would wait for this chunk's stores.
+	static const bool shade_persistent = getenv("TUTU_SHADE_PERSISTENT") != nullptr;
+	const int shade_grid = shade_persistent ? persistent_grid(npaths, c->n_cu, 8) : (int)((npaths + 64 * TUTU_NCLASS + 255) / 256);
 	const int trace_grid = persistent_grid(npaths, c->n_cu, c->trace_blocks_per_cu);
 	for (int d = 0; d <= TUTU_MAX_DEPTH + 1; d++) {
 		pp.depth = d;
@@ -249,20 +254,17 @@ int run_pass(TutuCtx* c, hipStream_t s, const TutuCameraFrame* cam, uint32_t key
 		tp.q = pp.q;
 		tp.list = c->flag_lists.p;
 		tp.n_ptr = meta + 0;
+		tp.kA = c->kA.p;
 		tp.kB = c->kB.p;
+		tp.tri_class = c->d_tri_class.p;
 		tp.stack_entries = c->stack_entries;
-		if (c->lds_scene) TIMED(EV_TRACE_CLOSEST, k_trace_closest<true><<<dim3(trace_grid), dim3(256), c->trace_lds_bytes, s>>>(tp));
-		else TIMED(EV_TRACE_CLOSEST, k_trace_closest<false><<<dim3(trace_grid), dim3(256), c->trace_lds_bytes, s>>>(tp));
+		if (c->lds_scene) TIMED(EV_TRACE_CLOSEST, k_trace<true, false><<<dim3(trace_grid), dim3(256), c->trace_lds_bytes, s>>>(tp));
+		else TIMED(EV_TRACE_CLOSEST, k_trace<false, false><<<dim3(trace_grid), dim3(256), c->trace_lds_bytes, s>>>(tp));
 		(*n_trace_launches)++;
-		ShadowParams sp;
-		sp.sc = c->sc;
-		sp.q = pp.q;
-		sp.list = c->flag_lists.p + c->cap;
-		sp.n_ptr = meta + 1;
-		sp.kA = c->kA.p;
-		sp.stack_entries = c->stack_entries;
-		if (c->lds_scene) TIMED(EV_TRACE_ANY, k_trace_any<true><<<dim3(trace_grid), dim3(256), c->trace_lds_bytes, s>>>(sp));
-		else TIMED(EV_TRACE_ANY, k_trace_any<false><<<dim3(trace_grid), dim3(256), c->trace_lds_bytes, s>>>(sp));
+		tp.list = c->flag_lists.p + c->cap;
+		tp.n_ptr = meta + 1;
+		if (c->lds_scene) TIMED(EV_TRACE_ANY, k_trace<true, true><<<dim3(trace_grid), dim3(256), c->trace_lds_bytes, s>>>(tp));
+		else TIMED(EV_TRACE_ANY, k_trace<false, true><<<dim3(trace_grid), dim3(256), c->trace_lds_bytes, s>>>(tp));
 		rc = build_lists<LIST_CLASS>(c, s, n_pad, meta + 16, meta + 24, c->perm.p, nullptr, nullptr);
 		if (rc != TUTU_OK) return rc;
 	}
@@ -426,6 +428,9 @@ int tutu_hip_create(const TutuSceneDesc* scene, int device, TutuCtx** out) {
 	if ((rc = upload(c->d_tri_shade, c->hs.tri_shade, s)) != TUTU_OK) return fail(rc);
 	if ((rc = upload(c->d_mats, c->hs.mats, s)) != TUTU_OK) return fail(rc);
 	if ((rc = upload(c->d_lights, c->hs.lights, s)) != TUTU_OK) return fail(rc);
+	if ((rc = c->d_tri_class.ensure(std::max<size_t>(16, c->hs.tri_class.size()))) != TUTU_OK) return fail(rc);
+	if (!c->hs.tri_class.empty() && hipMemcpyAsync(c->d_tri_class.p, c->hs.tri_class.data(), c->hs.tri_class.size(), hipMemcpyHostToDevice, s) != hipSuccess)
+		return fail(TUTU_E_HIP);
 	if (hipStreamSynchronize(s) != hipSuccess) return fail(TUTU_E_HIP);
 	SceneDev& sc = c->sc;
 	sc.nodes = c->d_nodes.p;
@@ -448,7 +453,8 @@ int tutu_hip_create(const TutuSceneDesc* scene, int device, TutuCtx** out) {
 	// small enough, every block also keeps a copy of them in LDS (160 KB per CU).
 	c->stack_entries = (int)c->hs.depth + 1;
 	const size_t stack_bytes = (size_t)c->stack_entries * 256 * sizeof(int);
-	const size_t scene_bytes = c->hs.nodes.size() * sizeof(GpuNode) + c->hs.tri_isect.size() * sizeof(GpuTriIsect);
+	const size_t scene_bytes = c->hs.nodes.size() * sizeof(GpuNode) + c->hs.tri_isect.size() * sizeof(GpuTriIsect) +
+	                           ((c->hs.tri_class.size() + 15) / 16) * 16;  // + class table
 	c->lds_scene = scene_bytes > 0 && scene_bytes <= 24 * 1024;
 	c->trace_lds_bytes = (unsigned)(stack_bytes + (c->lds_scene ? scene_bytes : 0));
 	c->trace_blocks_per_cu = (int)std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / std::max<size_t>(c->trace_lds_bytes, 1)));
@@ -464,7 +470,7 @@ int tutu_hip_destroy(TutuCtx* c) {
 		(void)hipEventDestroy(e.a);
 		(void)hipEventDestroy(e.b);
 	}
-	c->d_nodes.release(); c->d_tri_isect.release(); c->d_tri_shade.release(); c->d_mats.release(); c->d_lights.release();
+	c->d_tri_class.release(); c->d_nodes.release(); c->d_tri_isect.release(); c->d_tri_shade.release(); c->d_mats.release(); c->d_lights.release();
 	for (int f = 0; f < 11; f++) c->qbuf[f].release();
 	c->prim_dir.release(); c->prim_hit.release(); c->accum.release(); c->kA.release(); c->kB.release();
 	c->flag_lists.release(); c->perm.release(); c->tile_counts.release(); c->tile_offsets.release(); c->list_meta.release();
@@ -542,48 +548,6 @@ int tutu_hip_trace_samples(TutuCtx* c, const TutuCameraFrame* cam, uint32_t n, c
 // ---------------------------------------------------------------------------------------------------------
 // kernel-level parity entry points
 namespace {
-
-template <bool LDS_SCENE>
-__global__ void __launch_bounds__(256) k_test_closest(SceneDev sc, int stack_entries, const float* o, const float* d, uint32_t n, TutuHit* hits) {
-	extern __shared__ int lds[];
-	SceneLds sl;
-	SceneGlobal sg;
-	if (LDS_SCENE) sl = stage_scene_lds(sc, lds, stack_entries);
-	else {
-		sg.nodes = sc.nodes;
-		sg.tris = sc.tri_isect;
-	}
-	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-	if (i >= n) return;
-	float t, u, v;
-	int tri;
-	if (LDS_SCENE) trace_closest(sl, sc, ld3(o + 3 * (size_t)i), ld3(d + 3 * (size_t)i), lds + threadIdx.x, 256, t, u, v, tri);
-	else trace_closest(sg, sc, ld3(o + 3 * (size_t)i), ld3(d + 3 * (size_t)i), lds + threadIdx.x, 256, t, u, v, tri);
-	TutuHit h;
-	h.t = t;
-	h.b1 = u;
-	h.b2 = v;
-	h.tri = tri >= 0 ? __float_as_int(sc.tri_shade[3 * tri + 2].z) : -1;  // back to the caller's triangle index
-	hits[i] = h;
-}
-
-template <bool LDS_SCENE>
-__global__ void __launch_bounds__(256) k_test_any(SceneDev sc, int stack_entries, const float* o, const float* tgt, uint32_t n, uint8_t* blocked) {
-	extern __shared__ int lds[];
-	SceneLds sl;
-	SceneGlobal sg;
-	if (LDS_SCENE) sl = stage_scene_lds(sc, lds, stack_entries);
-	else {
-		sg.nodes = sc.nodes;
-		sg.tris = sc.tri_isect;
-	}
-	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-	if (i >= n) return;
-	bool b;
-	if (LDS_SCENE) b = trace_any(sl, sc, ld3(o + 3 * (size_t)i), ld3(tgt + 3 * (size_t)i), lds + threadIdx.x, 256);
-	else b = trace_any(sg, sc, ld3(o + 3 * (size_t)i), ld3(tgt + 3 * (size_t)i), lds + threadIdx.x, 256);
-	blocked[i] = b ? 1 : 0;
-}
 
 TUTU_DEV Mat mat_from_abi(const TutuMaterial& m) {
 	Mat r;
@@ -687,21 +651,61 @@ struct Scratch {
 
 extern "C" {
 
+// Both kernel-level entry points run the PRODUCTION traversal kernel (k_trace) on a throw-away work list, so the
+// parity tests exercise exactly the code the renderer uses.
+static int run_trace_kernel(TutuCtx* c, uint32_t n, bool any) {
+	hipStream_t s = c->stream;
+	std::vector<uint32_t> iota(n);
+	for (uint32_t i = 0; i < n; i++) iota[i] = i;
+	uint32_t* list = any ? c->flag_lists.p + c->cap : c->flag_lists.p;
+	HIP_TRY(hipMemcpyAsync(list, iota.data(), sizeof(uint32_t) * n, hipMemcpyHostToDevice, s));
+	HIP_TRY(hipMemcpyAsync(c->list_meta.p + (any ? 1 : 0), &n, sizeof(uint32_t), hipMemcpyHostToDevice, s));
+	TraceParams tp;
+	tp.sc = c->sc;
+	tp.q = queue_of(c);
+	tp.list = list;
+	tp.n_ptr = c->list_meta.p + (any ? 1 : 0);
+	tp.kA = c->kA.p;
+	tp.kB = c->kB.p;
+	tp.tri_class = c->d_tri_class.p;
+	tp.stack_entries = c->stack_entries;
+	const int grid = persistent_grid(n, c->n_cu, c->trace_blocks_per_cu);
+	if (any) {
+		if (c->lds_scene) k_trace<true, true><<<dim3(grid), dim3(256), c->trace_lds_bytes, s>>>(tp);
+		else k_trace<false, true><<<dim3(grid), dim3(256), c->trace_lds_bytes, s>>>(tp);
+	} else {
+		if (c->lds_scene) k_trace<true, false><<<dim3(grid), dim3(256), c->trace_lds_bytes, s>>>(tp);
+		else k_trace<false, false><<<dim3(grid), dim3(256), c->trace_lds_bytes, s>>>(tp);
+	}
+	HIP_TRY(hipGetLastError());
+	HIP_TRY(hipStreamSynchronize(s));
+	return TUTU_OK;
+}
+
 int tutu_hip_trace_closest(TutuCtx* c, uint32_t n, const float* orig, const float* dir, TutuHit* hits) {
 	if (!c || !orig || !dir || !hits) return TUTU_E_INVALID;
 	if (n == 0) return TUTU_OK;
 	HIP_TRY(hipSetDevice(c->device));
-	Scratch sc;
-	float *d_o, *d_d;
-	TutuHit* d_h;
-	RC(sc.up(orig, 3 * (size_t)n, &d_o));
-	RC(sc.up(dir, 3 * (size_t)n, &d_d));
-	RC(sc.alloc((size_t)n, &d_h));
-	if (c->lds_scene) k_test_closest<true><<<dim3((n + 255) / 256), dim3(256), c->trace_lds_bytes, c->stream>>>(c->sc, c->stack_entries, d_o, d_d, n, d_h);
-	else k_test_closest<false><<<dim3((n + 255) / 256), dim3(256), c->trace_lds_bytes, c->stream>>>(c->sc, c->stack_entries, d_o, d_d, n, d_h);
-	HIP_TRY(hipGetLastError());
-	HIP_TRY(hipStreamSynchronize(c->stream));
-	HIP_TRY(hipMemcpy(hits, d_h, sizeof(TutuHit) * (size_t)n, hipMemcpyDeviceToHost));
+	int rc = ensure_work(c, n, 1);
+	if (rc != TUTU_OK) return rc;
+	std::vector<float4> A(n), B(n);
+	for (uint32_t i = 0; i < n; i++) {
+		A[i] = make_float4(orig[3 * (size_t)i], orig[3 * (size_t)i + 1], orig[3 * (size_t)i + 2], 0.f);
+		B[i] = make_float4(dir[3 * (size_t)i], dir[3 * (size_t)i + 1], dir[3 * (size_t)i + 2], 0.f);
+	}
+	HIP_TRY(hipMemcpyAsync(c->qbuf[0].p, A.data(), sizeof(float4) * n, hipMemcpyHostToDevice, c->stream));
+	HIP_TRY(hipMemcpyAsync(c->qbuf[1].p, B.data(), sizeof(float4) * n, hipMemcpyHostToDevice, c->stream));
+	rc = run_trace_kernel(c, n, false);
+	if (rc != TUTU_OK) return rc;
+	HIP_TRY(hipMemcpy(A.data(), c->qbuf[2].p, sizeof(float4) * n, hipMemcpyDeviceToHost));
+	for (uint32_t i = 0; i < n; i++) {
+		int tri;
+		memcpy(&tri, &A[i].w, 4);
+		hits[i].t = A[i].x;
+		hits[i].b1 = A[i].y;
+		hits[i].b2 = A[i].z;
+		hits[i].tri = tri >= 0 ? c->hs.tri_shade[(size_t)tri].orig : -1;  // back to the caller's triangle index
+	}
 	return TUTU_OK;
 }
 
@@ -709,17 +713,27 @@ int tutu_hip_trace_any(TutuCtx* c, uint32_t n, const float* orig, const float* t
 	if (!c || !orig || !target || !blocked) return TUTU_E_INVALID;
 	if (n == 0) return TUTU_OK;
 	HIP_TRY(hipSetDevice(c->device));
-	Scratch sc;
-	float *d_o, *d_t;
-	uint8_t* d_b;
-	RC(sc.up(orig, 3 * (size_t)n, &d_o));
-	RC(sc.up(target, 3 * (size_t)n, &d_t));
-	RC(sc.alloc((size_t)n, &d_b));
-	if (c->lds_scene) k_test_any<true><<<dim3((n + 255) / 256), dim3(256), c->trace_lds_bytes, c->stream>>>(c->sc, c->stack_entries, d_o, d_t, n, d_b);
-	else k_test_any<false><<<dim3((n + 255) / 256), dim3(256), c->trace_lds_bytes, c->stream>>>(c->sc, c->stack_entries, d_o, d_t, n, d_b);
-	HIP_TRY(hipGetLastError());
-	HIP_TRY(hipStreamSynchronize(c->stream));
-	HIP_TRY(hipMemcpy(blocked, d_b, (size_t)n, hipMemcpyDeviceToHost));
+	int rc = ensure_work(c, n, 1);
+	if (rc != TUTU_OK) return rc;
+	// a shadow request with contribution (1,0,0): unblocked rays add it to the (zeroed) radiance field
+	std::vector<float4> S0(n), S1(n), S2(n);
+	for (uint32_t i = 0; i < n; i++) {
+		const float* o = orig + 3 * (size_t)i;
+		const float* t = target + 3 * (size_t)i;
+		S0[i] = make_float4(o[0], o[1], o[2], t[0]);
+		S1[i] = make_float4(t[1], t[2], 1.f, 0.f);
+		S2[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+	}
+	hipStream_t s = c->stream;
+	HIP_TRY(hipMemcpyAsync(c->qbuf[8].p, S0.data(), sizeof(float4) * n, hipMemcpyHostToDevice, s));
+	HIP_TRY(hipMemcpyAsync(c->qbuf[9].p, S1.data(), sizeof(float4) * n, hipMemcpyHostToDevice, s));
+	HIP_TRY(hipMemcpyAsync(c->qbuf[10].p, S2.data(), sizeof(float4) * n, hipMemcpyHostToDevice, s));
+	HIP_TRY(hipMemsetAsync(c->qbuf[5].p, 0, sizeof(float4) * n, s));
+	HIP_TRY(hipMemsetAsync(c->kA.p, 0, n, s));
+	rc = run_trace_kernel(c, n, true);
+	if (rc != TUTU_OK) return rc;
+	HIP_TRY(hipMemcpy(S0.data(), c->qbuf[5].p, sizeof(float4) * n, hipMemcpyDeviceToHost));
+	for (uint32_t i = 0; i < n; i++) blocked[i] = S0[i].x == 0.f ? 1 : 0;
 	return TUTU_OK;
 }
 
