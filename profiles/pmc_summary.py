@@ -9,10 +9,10 @@ from collections import defaultdict
 
 
 def short(name):
-    for k in ("k_trace_closest", "k_trace_any", "k_shade<true>", "k_shade<false>", "k_primary", "k_resolve", "k_finalize"):
-        if k in name:
-            return k
-    return None
+    if "tutu::" not in name:
+        return None
+    n = name.split("(")[0].replace("void ", "").replace("tutu::", "")
+    return n
 
 
 def main(root):

@@ -68,12 +68,47 @@ struct PassParams {
 	const uint32_t* cls_count;  // [8]
 	const uint32_t* cls_base;   // [8]
 	uint32_t class_mask;        // classes this launch shades
+	int n_mats;
 };
 
-TUTU_DEV Mat load_mat(const SceneDev& sc, int id) {
-	const float4 a = sc.mats[4 * id + 0];
-	const float4 b = sc.mats[4 * id + 1];
-	const float4 c = sc.mats[4 * id + 2];
+// Small read-only tables of the shade stage.  TAB selects where they live:
+//   0  all in HBM (L2-cached gathers)
+//   1  materials + lights staged in LDS by every block
+//   2  materials + lights + per-triangle shading records staged in LDS (small scenes, e.g. the Cornell box: 2.5 KB)
+// Staging removes two to three dependent memory round trips from every vertex.
+struct ShadeTabs {
+	const float4* mats;    // 4 x float4 per material
+	const float4* lights;  // 6 x float4 per light
+	const float4* tris;    // 4 x float4 per triangle (GpuTriShade)
+};
+
+template <int TAB>
+TUTU_DEV ShadeTabs stage_shade_tabs(const SceneDev& sc, float4* lds, int n_mats) {
+	ShadeTabs t;
+	t.mats = sc.mats;
+	t.lights = sc.lights;
+	t.tris = sc.tri_shade;
+	if (TAB >= 1) {
+		float4* lm = lds;
+		float4* ll = lm + 4 * n_mats;
+		float4* lt = ll + 6 * sc.n_lights;
+		for (int i = threadIdx.x; i < 4 * n_mats; i += blockDim.x) lm[i] = sc.mats[i];
+		for (int i = threadIdx.x; i < 6 * sc.n_lights; i += blockDim.x) ll[i] = sc.lights[i];
+		t.mats = lm;
+		t.lights = ll;
+		if (TAB >= 2) {
+			for (int i = threadIdx.x; i < 4 * sc.n_tris; i += blockDim.x) lt[i] = sc.tri_shade[i];
+			t.tris = lt;
+		}
+		__syncthreads();
+	}
+	return t;
+}
+
+TUTU_DEV Mat load_mat(const ShadeTabs& tb, int id) {
+	const float4 a = tb.mats[4 * id + 0];
+	const float4 b = tb.mats[4 * id + 1];
+	const float4 c = tb.mats[4 * id + 2];
 	Mat m;
 	m.diffuse = mk(a.x, a.y, a.z);
 	m.type = __float_as_int(a.w);
@@ -92,16 +127,15 @@ struct LightSample {
 	float pdf;
 	int tri;
 };
-TUTU_DEV LightSample sample_light(const SceneDev& sc, Rng& rng) {
-	const int size = sc.n_lights;
+TUTU_DEV LightSample sample_light(const ShadeTabs& tb, int size, Rng& rng) {
 	int index = (int)(rng.next() * (size - 1) + 0.4999f);  // drawn even when size == 1; not uniform for size > 2 [sic]
 	if (size == 1) index = 0;
-	const float4 a = sc.lights[6 * index + 0];
-	const float4 b = sc.lights[6 * index + 1];
-	const float4 c = sc.lights[6 * index + 2];
-	const float4 d = sc.lights[6 * index + 3];
-	const float4 e = sc.lights[6 * index + 4];
-	const float4 f = sc.lights[6 * index + 5];
+	const float4 a = tb.lights[6 * index + 0];
+	const float4 b = tb.lights[6 * index + 1];
+	const float4 c = tb.lights[6 * index + 2];
+	const float4 d = tb.lights[6 * index + 3];
+	const float4 e = tb.lights[6 * index + 4];
+	const float4 f = tb.lights[6 * index + 5];
 	const V3 v0 = mk(a.x, a.y, a.z), v1 = mk(a.w, b.x, b.y), v2 = mk(b.z, b.w, c.x);
 	const V3 n0 = mk(c.y, c.z, c.w), n1 = mk(d.x, d.y, d.z), n2 = mk(d.w, e.x, e.y);
 	float u = rng.next();
@@ -127,10 +161,12 @@ TUTU_DEV LightSample sample_light(const SceneDev& sc, Rng& rng) {
 // path's slot as soon as they exist, so few values stay live across the BSDF code.
 enum ShadeMode { SHADE_FIRST = 0, SHADE_LAMBERT = 1, SHADE_MIRROR = 2, SHADE_REFRACT = 3, SHADE_GGXR = 4, SHADE_TERMINAL = 5 };
 
-template <int MODE>
+template <int MODE, int TAB>
 __global__ void __launch_bounds__(256) k_shade(PassParams pp) {
 	constexpr bool FIRST = MODE == SHADE_FIRST;
 	const SceneDev& sc = pp.sc;
+	extern __shared__ float4 shade_lds[];
+	const ShadeTabs tb = stage_shade_tabs<TAB>(sc, shade_lds, pp.n_mats);
 	const int lane = __lane_id();
 	const int depth = pp.depth;
 
@@ -155,6 +191,7 @@ __global__ void __launch_bounds__(256) k_shade(PassParams pp) {
 
 	for (uint32_t chunk = FIRST ? 0u : wave_global; FIRST ? (chunk == 0u) : (chunk < total_chunks); chunk += n_waves) {
 		bool act;
+		int chunk_class = 0;  // wave-uniform (class boundaries are padded to a wave)
 		uint32_t idx = 0;   // work item (FIRST only)
 		uint32_t slot = 0;  // the path's slot
 		if (FIRST) {
@@ -169,6 +206,7 @@ __global__ void __launch_bounds__(256) k_shade(PassParams pp) {
 					cb = base[k];
 					cn = cnt[k];
 					cp = pref[k];
+					chunk_class = k;
 				}
 			const uint32_t j = (chunk - cp) * 64u + lane;
 			act = j < cn;
@@ -220,16 +258,16 @@ __global__ void __launch_bounds__(256) k_shade(PassParams pp) {
 		int mat_id = 0;
 		float hit_light_pdf = 0.f;
 		if (hit) {
-			const float4 s0 = sc.tri_shade[3 * tri + 0];
-			const float4 s1 = sc.tri_shade[3 * tri + 1];
-			const float4 s2 = sc.tri_shade[3 * tri + 2];
-			const float4 q2 = sc.tri_isect[3 * tri + 2];
+			const float4 s0 = tb.tris[4 * tri + 0];
+			const float4 s1 = tb.tris[4 * tri + 1];
+			const float4 s2 = tb.tris[4 * tri + 2];
+			const float4 s3 = tb.tris[4 * tri + 3];
 			const V3 n0 = mk(s0.x, s0.y, s0.z), n1 = mk(s0.w, s1.x, s1.y), n2 = mk(s1.z, s1.w, s2.x);
-			mat_id = __float_as_int(s2.y);
-			hit_light_pdf = s2.w;
+			Ng = mk(s2.y, s2.z, s2.w);
+			mat_id = __float_as_int(s3.x);
+			hit_light_pdf = s3.z;
 			pos = o + t * d;
 			Ns = normalized((n0 * (1 - b1 - b2)) + n1 * b1 + n2 * b2);
-			Ng = mk(q2.y, q2.z, q2.w);
 		}
 
 		// ---- connect: finish vertex depth-1 now that the hit of its BSDF ray is known (PathTracing.hpp:234-278)
@@ -261,7 +299,7 @@ __global__ void __launch_bounds__(256) k_shade(PassParams pp) {
 					const float l_pdf_transformed = hit_light_pdf * r2 / cos_theta_prime;
 					float mis_weight_m = getMisWeight(pm, l_pdf_transformed);
 					if (flags & TUTU_FLAG_PREV_MIRROR_PM1) mis_weight_m = 1.f;
-					const float4 em = sc.mats[4 * mat_id + 1];
+					const float4 em = tb.mats[4 * mat_id + 1];
 					if (!(pm < TUTU_MIN_DIVISOR)) {
 						Ladd = beta * (mis_weight_m * mk(em.x, em.y, em.z) * fprev * cosprev / pm);
 						added = true;
@@ -290,13 +328,23 @@ __global__ void __launch_bounds__(256) k_shade(PassParams pp) {
 		// ---- shade the vertex at `depth`; every result goes to the slot as soon as it exists
 		uint32_t key = 0;
 		if (go) {
-			Mat m = load_mat(sc, mat_id);  // per-hit copy, like Intersection::mtlcolor
-			if (MODE == SHADE_LAMBERT) m.type = TUTU_LAMBERTIAN;  // class-sorted: known at compile time
-			if (MODE == SHADE_MIRROR) m.type = TUTU_PERFECT_REFLECTIVE;
-			if (MODE == SHADE_GGXR) m.type = TUTU_MICROFACET_R;
+			Mat m = load_mat(tb, mat_id);  // per-hit copy, like Intersection::mtlcolor
+			// classes 5..7 (UNLIT, emissive hit, miss) only connect and end; they ride along with the first material
+			// launch of the depth.  The chunk's class is wave-uniform.
+			const bool terminal = !FIRST && chunk_class >= TUTU_UNLIT;
+			if (!terminal) {
+				if (MODE == SHADE_LAMBERT) m.type = TUTU_LAMBERTIAN;  // class-sorted: known at compile time
+				if (MODE == SHADE_MIRROR) m.type = TUTU_PERFECT_REFLECTIVE;
+				if (MODE == SHADE_GGXR) m.type = TUTU_MICROFACET_R;
+			}
 			const V3 wo = -d;
 			const bool refractive = m.type == TUTU_PERFECT_REFRACTIVE || m.type == TUTU_MICROFACET_T;
-			if ((FIRST || MODE == SHADE_REFRACT) && refractive) {
+			if (terminal) {
+				if (m.type == TUTU_UNLIT) {  // :161
+					Ladd = beta * m.diffuse;
+					added = true;
+				}  // emissive at depth > 0 adds nothing (:164-165); unknown material types end like their `default:` branches
+			} else if ((FIRST || MODE == SHADE_REFRACT) && refractive) {
 				// calcForRefractive, PathTracing.hpp:80-134
 				float eta_i = sc.eta, eta_t = m.eta;
 				V3 wi = mk1(0.f);
@@ -338,10 +386,10 @@ __global__ void __launch_bounds__(256) k_shade(PassParams pp) {
 					if (depth >= TUTU_MIN_DEPTH + 1) pp.q.E[slot] = make_float4(1.f, 1.f, 1.f, 0.f);  // tp = 1
 					key = TUTU_KEY_NEXT;
 				}
-			} else if ((FIRST || MODE == SHADE_TERMINAL) && m.type == TUTU_UNLIT) {  // :161
+			} else if (FIRST && m.type == TUTU_UNLIT) {  // :161
 				Ladd = beta * m.diffuse;
 				added = true;
-			} else if ((FIRST || MODE == SHADE_TERMINAL) && m.has_emission) {  // :164-170
+			} else if (FIRST && m.has_emission) {  // :164-170
 				if (depth == 0) {
 					Ladd = beta * m.emission;
 					added = true;
@@ -350,7 +398,7 @@ __global__ void __launch_bounds__(256) k_shade(PassParams pp) {
 				// ---- light sampling, :180-219
 				bool kill_req = false;
 				if (sc.n_lights > 0) {
-					const LightSample ls = sample_light(sc, rng);
+					const LightSample ls = sample_light(tb, sc.n_lights, rng);
 					V3 wi = ls.pos - pos;
 					const float r2 = norm2(wi);
 					wi = normalized(wi);
@@ -433,7 +481,7 @@ __global__ void __launch_bounds__(256) k_shade(PassParams pp) {
 // so a lane whose ray ends early is given new work instead of waiting for the slowest ray of its wave (the plain
 // one-ray-per-lane loop ran with ~26 % of its lanes active on the Cornell box).  The loop ends when the range is
 // exhausted and every lane is idle: an exit condition every wave reaches.
-#define TUTU_INNER_STEPS 3
+#define TUTU_INNER_STEPS 4
 #define TUTU_TRAV_IDLE (INT_MIN + 1)
 
 struct TraceParams {

@@ -246,6 +246,7 @@ int build_host_scene(const TutuSceneDesc* d, HostScene& hs) {
 		memcpy(s.n0, nn, 12);
 		memcpy(s.n1, nn + 3, 12);
 		memcpy(s.n2, nn + 6, 12);
+		memcpy(s.ng, t.n, 12);
 		s.mat = d->mat_id[o];
 		s.orig = o;
 		s.light_pdf = hs.mats[s.mat].has_emission ? 1 / (size * area[li]) : 0.f;  // getLightPdf  IIntegrator.hpp:166-167
@@ -256,6 +257,7 @@ int build_host_scene(const TutuSceneDesc* d, HostScene& hs) {
 			int cls = (gm.has_emission && gm.type != TUTU_PERFECT_REFRACTIVE && gm.type != TUTU_MICROFACET_T) ? 6 : gm.type;
 			if (cls < 0 || cls > 6) cls = TUTU_UNLIT;  // unknown enum values: filed with UNLIT, shaded by their own `default:` branches
 			hs.tri_class[li] = (uint8_t)cls;
+			s.cls = cls;
 		}
 	}
 	hs.lights.resize(light_orig.size());

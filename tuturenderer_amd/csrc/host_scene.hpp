@@ -31,14 +31,18 @@ struct GpuTriIsect {
 };
 static_assert(sizeof(GpuTriIsect) == 48, "GpuTriIsect must be 48 B");
 
-// Triangle as shading reads it (48 B): vertex normals, material, original index, light pdf.
+// Triangle as shading reads it (64 B = 4 x dwordx4): vertex normals, geometric normal, material, original index,
+// light pdf, material class.  One fetch per hit gives everything Triangle::intersect puts into the Intersection
+// besides t and the barycentrics (Triangle.hpp:50-57).
 struct GpuTriShade {
 	float n0[3], n1[3], n2[3];
+	float ng[3];      // normalized(E1 x E2), the same bits as GpuTriIsect::n
 	int32_t mat;      // index into materials
 	int32_t orig;     // index in the caller's triangle list
 	float light_pdf;  // 1/(n_lights*area) when the material is emissive, else 0   (IIntegrator.hpp:155-168)
+	int32_t cls;      // material class (0..5 MaterialType, 6 emissive)
 };
-static_assert(sizeof(GpuTriShade) == 48, "GpuTriShade must be 48 B");
+static_assert(sizeof(GpuTriShade) == 64, "GpuTriShade must be 64 B");
 
 // Material as the kernels read it (64 B)
 struct GpuMaterial {

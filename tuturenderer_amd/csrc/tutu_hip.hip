@@ -71,6 +71,8 @@ struct TutuCtx {
 	unsigned trace_lds_bytes = TUTU_STACK_DEPTH * 256 * sizeof(int);
 	bool lds_scene = false;
 	uint32_t type_mask = 0;  // MaterialType values present among the non-emissive materials
+	int shade_tab = 0;       // 0: shade tables in HBM, 1: materials+lights in LDS, 2: + per-triangle shading records
+	unsigned shade_lds_bytes = 0;
 	int trace_blocks_per_cu = 5;
 	HostScene hs;
 	SceneDev sc;
@@ -186,6 +188,26 @@ int build_lists(TutuCtx* c, hipStream_t s, uint32_t n_slots_padded, uint32_t* me
 	return TUTU_OK;
 }
 
+template <int MODE>
+int launch_shade_tab(TutuCtx* c, hipStream_t s, dim3 grid, const PassParams& pp) {
+	switch (c->shade_tab) {
+	case 2: TIMED(EV_SHADE, k_shade<MODE, 2><<<grid, dim3(256), c->shade_lds_bytes, s>>>(pp)); break;
+	case 1: TIMED(EV_SHADE, k_shade<MODE, 1><<<grid, dim3(256), c->shade_lds_bytes, s>>>(pp)); break;
+	default: TIMED(EV_SHADE, k_shade<MODE, 0><<<grid, dim3(256), 0, s>>>(pp)); break;
+	}
+	return TUTU_OK;
+}
+int launch_shade(TutuCtx* c, hipStream_t s, int mode, dim3 grid, const PassParams& pp) {
+	switch (mode) {
+	case SHADE_FIRST: return launch_shade_tab<SHADE_FIRST>(c, s, grid, pp);
+	case SHADE_LAMBERT: return launch_shade_tab<SHADE_LAMBERT>(c, s, grid, pp);
+	case SHADE_MIRROR: return launch_shade_tab<SHADE_MIRROR>(c, s, grid, pp);
+	case SHADE_REFRACT: return launch_shade_tab<SHADE_REFRACT>(c, s, grid, pp);
+	case SHADE_GGXR: return launch_shade_tab<SHADE_GGXR>(c, s, grid, pp);
+	default: return launch_shade_tab<SHADE_TERMINAL>(c, s, grid, pp);
+	}
+}
+
 // One wavefront pass over `npix` work items x `nsamp` samples (or, with smp_list, one sample per item).
 int run_pass(TutuCtx* c, hipStream_t s, const TutuCameraFrame* cam, uint32_t key0, uint32_t key1, int npix, int s0, int nsamp,
              const uint32_t* d_smp_list, uint32_t* n_trace_launches) {
@@ -210,44 +232,45 @@ int run_pass(TutuCtx* c, hipStream_t s, const TutuCameraFrame* cam, uint32_t key
 	pp.kA = c->kA.p;
 	pp.perm = c->perm.p;
 
-	// shade: one wave-sized chunk per wave (grid covers the worst case; surplus waves exit at once).  A persistent
-	// loop serialises on the in-order vmcnt counter: the next chunk's loads would wait for this chunk's stores.
-	static const bool shade_persistent = getenv("TUTU_SHADE_PERSISTENT") != nullptr;
-	const int shade_grid = shade_persistent ? persistent_grid(npaths, c->n_cu, 8) : (int)((npaths + 64 * TUTU_NCLASS + 255) / 256);
+	const int shade_grid = persistent_grid(npaths, c->n_cu, 8);  // persistent blocks: the table staging is paid once per block
 	const int trace_grid = persistent_grid(npaths, c->n_cu, c->trace_blocks_per_cu);
+	int rc = TUTU_OK;
+	pp.n_mats = (int)c->hs.mats.size();
 	for (int d = 0; d <= TUTU_MAX_DEPTH + 1; d++) {
 		pp.depth = d;
 		uint32_t* meta = c->list_meta.p + (size_t)TUTU_META_STRIDE * d;  // [0..8) flag counts, [8..16) flag bases, [16..24) class counts, [24..32) class bases
 		if (d == 0) {
 			dim3 g((unsigned)((npix + 255) / 256), (unsigned)nsamp, 1);
-			TIMED(EV_SHADE, k_shade<SHADE_FIRST><<<g, dim3(256), 0, s>>>(pp));
+			rc = launch_shade(c, s, SHADE_FIRST, g, pp);
+			if (rc != TUTU_OK) return rc;
 		} else {
-			// one launch per material class group that exists in the scene (sort-by-material pipeline)
+			// one launch per material class group that exists in the scene (sort-by-material pipeline); the classes
+			// that only connect and end (UNLIT, emissive hit, miss) ride along with the first launch
 			uint32_t* pm = c->list_meta.p + (size_t)TUTU_META_STRIDE * (d - 1);
 			pp.cls_count = pm + 16;
 			pp.cls_base = pm + 24;
 			const uint32_t types = c->type_mask;
-			if (types & (1u << TUTU_LAMBERTIAN)) {
-				pp.class_mask = 1u << TUTU_LAMBERTIAN;
-				TIMED(EV_SHADE, k_shade<SHADE_LAMBERT><<<dim3(shade_grid), dim3(256), 0, s>>>(pp));
+			uint32_t extra = (1u << TUTU_UNLIT) | (1u << TUTU_CLASS_EMISSIVE) | (1u << TUTU_CLASS_MISS);
+			const struct { int mode; uint32_t mask; } groups[4] = {
+			    {SHADE_LAMBERT, 1u << TUTU_LAMBERTIAN},
+			    {SHADE_MIRROR, 1u << TUTU_PERFECT_REFLECTIVE},
+			    {SHADE_REFRACT, (1u << TUTU_PERFECT_REFRACTIVE) | (1u << TUTU_MICROFACET_T)},
+			    {SHADE_GGXR, 1u << TUTU_MICROFACET_R}};
+			for (int gi = 0; gi < 4; gi++) {
+				if (!(types & groups[gi].mask)) continue;
+				pp.class_mask = groups[gi].mask | extra;
+				extra = 0;
+				rc = launch_shade(c, s, groups[gi].mode, dim3(shade_grid), pp);
+				if (rc != TUTU_OK) return rc;
 			}
-			if (types & (1u << TUTU_PERFECT_REFLECTIVE)) {
-				pp.class_mask = 1u << TUTU_PERFECT_REFLECTIVE;
-				TIMED(EV_SHADE, k_shade<SHADE_MIRROR><<<dim3(shade_grid), dim3(256), 0, s>>>(pp));
+			if (extra) {  // a scene without any scattering material
+				pp.class_mask = extra;
+				rc = launch_shade(c, s, SHADE_TERMINAL, dim3(shade_grid), pp);
+				if (rc != TUTU_OK) return rc;
 			}
-			if (types & ((1u << TUTU_PERFECT_REFRACTIVE) | (1u << TUTU_MICROFACET_T))) {
-				pp.class_mask = (1u << TUTU_PERFECT_REFRACTIVE) | (1u << TUTU_MICROFACET_T);
-				TIMED(EV_SHADE, k_shade<SHADE_REFRACT><<<dim3(shade_grid), dim3(256), 0, s>>>(pp));
-			}
-			if (types & (1u << TUTU_MICROFACET_R)) {
-				pp.class_mask = 1u << TUTU_MICROFACET_R;
-				TIMED(EV_SHADE, k_shade<SHADE_GGXR><<<dim3(shade_grid), dim3(256), 0, s>>>(pp));
-			}
-			pp.class_mask = (1u << TUTU_UNLIT) | (1u << TUTU_CLASS_EMISSIVE) | (1u << TUTU_CLASS_MISS);
-			TIMED(EV_SHADE, k_shade<SHADE_TERMINAL><<<dim3(std::max(1, shade_grid / 4)), dim3(256), 0, s>>>(pp));
 		}
 		if (d == TUTU_MAX_DEPTH + 1) break;  // the last shade only connects; nothing continues
-		int rc = build_lists<LIST_FLAGS>(c, s, n_pad, meta, meta + 8, c->flag_lists.p, &c->totals.p->closest_rays, &c->totals.p->shadow_rays);
+		rc = build_lists<LIST_FLAGS>(c, s, n_pad, meta, meta + 8, c->flag_lists.p, &c->totals.p->closest_rays, &c->totals.p->shadow_rays);
 		if (rc != TUTU_OK) return rc;
 		TraceParams tp;
 		tp.sc = c->sc;
@@ -446,6 +469,21 @@ int tutu_hip_create(const TutuSceneDesc* scene, int device, TutuCtx** out) {
 	memcpy(sc.bkg, c->hs.bkg, 12);
 	sc.n_tris = (int)c->hs.tri_isect.size();
 	sc.n_inner = (int)c->hs.nodes.size();
+	{
+		const size_t ml = c->hs.mats.size() * sizeof(GpuMaterial) + c->hs.lights.size() * sizeof(GpuLight);
+		const size_t tr = c->hs.tri_shade.size() * sizeof(GpuTriShade);
+		if (ml <= 16 * 1024 && tr <= 16 * 1024 - ml) {
+			c->shade_tab = 2;
+			c->shade_lds_bytes = (unsigned)(ml + tr);
+		} else if (ml <= 16 * 1024) {
+			c->shade_tab = 1;
+			c->shade_lds_bytes = (unsigned)ml;
+		} else {
+			c->shade_tab = 0;
+			c->shade_lds_bytes = 0;
+		}
+		if (c->shade_lds_bytes == 0 && c->shade_tab != 0) c->shade_tab = 0;
+	}
 	c->type_mask = 0;
 	for (const GpuMaterial& m : c->hs.mats)
 		if (m.type >= 0 && m.type <= TUTU_UNLIT) c->type_mask |= 1u << m.type;
@@ -611,8 +649,12 @@ __global__ void k_test_sample_light(SceneDev sc, const float* xi3, uint32_t n, i
 	Rng rng;
 	rng.init(0, 0, 0, 0, 0);
 	rng.inj = xi3 + 3 * (size_t)i;
-	const LightSample ls = sample_light(sc, rng);
-	tri[i] = __float_as_int(sc.tri_shade[3 * ls.tri + 2].z);
+	ShadeTabs tb;
+	tb.mats = sc.mats;
+	tb.lights = sc.lights;
+	tb.tris = sc.tri_shade;
+	const LightSample ls = sample_light(tb, sc.n_lights, rng);
+	tri[i] = __float_as_int(sc.tri_shade[4 * ls.tri + 3].y);
 	pos[3 * (size_t)i + 0] = ls.pos.x; pos[3 * (size_t)i + 1] = ls.pos.y; pos[3 * (size_t)i + 2] = ls.pos.z;
 	nrm[3 * (size_t)i + 0] = ls.N.x; nrm[3 * (size_t)i + 1] = ls.N.y; nrm[3 * (size_t)i + 2] = ls.N.z;
 	pdf[i] = ls.pdf;
