@@ -29,7 +29,6 @@ struct ListParams {
 	uint32_t* tile_counts;    // [n_tiles][8]
 	uint32_t* tile_offsets;   // [n_tiles][8]  exclusive scan over tiles, per list
 	uint32_t* list_count;     // [8]  out: entries per list
-	uint32_t* list_base;      // [8]  out: start of each list in `out`
 	uint32_t* out;            // the lists
 	uint32_t flags_stride;    // FLAGS: list 1 starts at this offset (= capacity)
 	unsigned long long* stat_a;  // totals to bump by list_count[0] (closest rays) -- may be null
@@ -112,52 +111,64 @@ __global__ void __launch_bounds__(256) k_list_count(ListParams p) {
 	}
 }
 
-// one block: exclusive scan of the tile counts of each list; list totals and bases
+// one block PER LIST (blockIdx.x = list): exclusive scan of that list's tile counts; its total.  The start of each
+// list inside `out` (list_base) is derived from the totals by whoever needs it (tiny prefix over <= 8 values).
 template <int MODE>
 __global__ void __launch_bounds__(1024) k_list_scan(ListParams p) {
 	__shared__ uint32_t part[1024];
-	__shared__ uint32_t totals[8];
+	const int c = blockIdx.x;
 	const uint32_t per = (p.n_tiles + 1023u) / 1024u;
 	const uint32_t t0 = threadIdx.x * per;
-	const int nlists = MODE == LIST_FLAGS ? 2 : TUTU_NCLASS;
-	for (int c = 0; c < nlists; c++) {
-		uint32_t sum = 0;
-		for (uint32_t k = 0; k < per; k++) {
-			const uint32_t t = t0 + k;
-			if (t < p.n_tiles) sum += p.tile_counts[t * 8 + c];
+	uint32_t sum = 0;
+	for (uint32_t k = 0; k < per; k++) {
+		const uint32_t t = t0 + k;
+		if (t < p.n_tiles) sum += p.tile_counts[t * 8 + c];
+	}
+	// inclusive scan of the 1024 partial sums: wave scan + scan of the 16 wave totals
+	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	uint32_t v = sum;
+#pragma unroll
+	for (int d = 1; d < 64; d <<= 1) {
+		const uint32_t o = (uint32_t)__shfl_up((int)v, d);
+		if (lane >= d) v += o;
+	}
+	if (lane == 63) part[wave] = v;
+	__syncthreads();
+	uint32_t pre = 0, tot = 0;
+#pragma unroll
+	for (int w = 0; w < 16; w++) {
+		const uint32_t x = part[w];
+		if (w < wave) pre += x;
+		tot += x;
+	}
+	uint32_t run = v + pre - sum;  // exclusive prefix of this thread's first tile
+	for (uint32_t k = 0; k < per; k++) {
+		const uint32_t t = t0 + k;
+		if (t < p.n_tiles) {
+			p.tile_offsets[t * 8 + c] = run;
+			run += p.tile_counts[t * 8 + c];
 		}
-		part[threadIdx.x] = sum;
-		__syncthreads();
-		for (int d = 1; d < 1024; d <<= 1) {  // Hillis-Steele inclusive scan
-			uint32_t v = threadIdx.x >= (uint32_t)d ? part[threadIdx.x - d] : 0u;
-			__syncthreads();
-			part[threadIdx.x] += v;
-			__syncthreads();
-		}
-		uint32_t run = part[threadIdx.x] - sum;  // exclusive prefix of this thread's first tile
-		for (uint32_t k = 0; k < per; k++) {
-			const uint32_t t = t0 + k;
-			if (t < p.n_tiles) {
-				p.tile_offsets[t * 8 + c] = run;
-				run += p.tile_counts[t * 8 + c];
-			}
-		}
-		if (threadIdx.x == 1023) totals[c] = part[1023];
-		__syncthreads();
 	}
 	if (threadIdx.x == 0) {
-		uint32_t base = 0;
+		p.list_count[c] = tot;
+		if (c == 0 && p.stat_a) *p.stat_a += tot;
+		if (c == 1 && p.stat_b) *p.stat_b += tot;
+	}
+}
+
+// start of list c inside `out`
+template <int MODE>
+__device__ __forceinline__ void list_bases(const ListParams& p, uint32_t base[8]) {
+	if (MODE == LIST_FLAGS) {
+#pragma unroll
+		for (int c = 0; c < 8; c++) base[c] = c == 1 ? p.flags_stride : 0u;
+	} else {
+		uint32_t run = 0;
+#pragma unroll
 		for (int c = 0; c < 8; c++) {
-			const uint32_t n = c < nlists ? totals[c] : 0u;
-			p.list_count[c] = n;
-			if (MODE == LIST_FLAGS) p.list_base[c] = c == 1 ? p.flags_stride : 0u;
-			else {
-				p.list_base[c] = base;
-				base += n;
-			}
+			base[c] = run;
+			run += p.list_count[c];
 		}
-		if (p.stat_a) *p.stat_a += totals[0];
-		if (p.stat_b) *p.stat_b += totals[1];
 	}
 }
 
@@ -172,11 +183,13 @@ __global__ void __launch_bounds__(256) k_list_scatter(ListParams p) {
 	const unsigned long long elo = block_scan_incl(lo, lds, tl) - lo;  // exclusive
 	const unsigned long long ehi = block_scan_incl(hi, lds + 4, th) - hi;
 	if (lo == 0 && hi == 0) return;
+	uint32_t base[8];
+	list_bases<MODE>(p, base);
 	uint32_t pos[8];
 #pragma unroll
 	for (int c = 0; c < 8; c++) {
 		const unsigned long long e = c < 4 ? elo : ehi;
-		pos[c] = p.list_base[c] + p.tile_offsets[blockIdx.x * 8 + c] + (uint32_t)((e >> (16 * (c & 3))) & 0xFFFFu);
+		pos[c] = base[c] + p.tile_offsets[blockIdx.x * 8 + c] + (uint32_t)((e >> (16 * (c & 3))) & 0xFFFFu);
 	}
 	const uint32_t wa[4] = {ka.x, ka.y, ka.z, ka.w};
 	const uint32_t wb[4] = {kb.x, kb.y, kb.z, kb.w};

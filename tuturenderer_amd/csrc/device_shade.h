@@ -65,8 +65,7 @@ struct PassParams {
 	Queue q;
 	uint8_t* kA;              // out: continuation / shadow flags per slot
 	const uint32_t* perm;     // class-sorted continuing slots (packed lists)
-	const uint32_t* cls_count;  // [8]
-	const uint32_t* cls_base;   // [8]
+	const uint32_t* cls_count;  // [8] entries per class list (the lists are packed back to back in `perm`)
 	uint32_t class_mask;        // classes this launch shades
 	int n_mats;
 };
@@ -178,10 +177,13 @@ __global__ void __launch_bounds__(256) k_shade(PassParams pp) {
 	uint32_t total_chunks = 0;
 	if (!FIRST) {
 		pref[0] = 0;
+		uint32_t run = 0;
 #pragma unroll
 		for (int c = 0; c < TUTU_NCLASS; c++) {
-			cnt[c] = ((pp.class_mask >> c) & 1u) ? pp.cls_count[c] : 0u;
-			base[c] = pp.cls_base[c];
+			const uint32_t n_c = pp.cls_count[c];
+			cnt[c] = ((pp.class_mask >> c) & 1u) ? n_c : 0u;
+			base[c] = run;
+			run += n_c;
 			pref[c + 1] = pref[c] + ((cnt[c] + 63u) >> 6);
 		}
 		total_chunks = pref[TUTU_NCLASS];

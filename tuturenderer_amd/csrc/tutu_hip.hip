@@ -167,7 +167,7 @@ int persistent_grid(size_t upper_items, int n_cu, int blocks_per_cu) {
 
 // count -> scan -> scatter: stable index lists from the per-slot key bytes (device_lists.h)
 template <int MODE>
-int build_lists(TutuCtx* c, hipStream_t s, uint32_t n_slots_padded, uint32_t* meta_count, uint32_t* meta_base, uint32_t* out,
+int build_lists(TutuCtx* c, hipStream_t s, uint32_t n_slots_padded, uint32_t* meta_count, uint32_t* out,
                 unsigned long long* stat_a, unsigned long long* stat_b) {
 	ListParams lp;
 	lp.kA = c->kA.p;
@@ -177,13 +177,12 @@ int build_lists(TutuCtx* c, hipStream_t s, uint32_t n_slots_padded, uint32_t* me
 	lp.tile_counts = c->tile_counts.p;
 	lp.tile_offsets = c->tile_offsets.p;
 	lp.list_count = meta_count;
-	lp.list_base = meta_base;
 	lp.out = out;
 	lp.flags_stride = (uint32_t)c->cap;
 	lp.stat_a = stat_a;
 	lp.stat_b = stat_b;
 	TIMED(EV_OTHER, k_list_count<MODE><<<dim3(lp.n_tiles), dim3(256), 0, s>>>(lp));
-	TIMED(EV_OTHER, k_list_scan<MODE><<<dim3(1), dim3(1024), 0, s>>>(lp));
+	TIMED(EV_OTHER, k_list_scan<MODE><<<dim3(MODE == LIST_FLAGS ? 2 : TUTU_NCLASS), dim3(1024), 0, s>>>(lp));
 	TIMED(EV_OTHER, k_list_scatter<MODE><<<dim3(lp.n_tiles), dim3(256), 0, s>>>(lp));
 	return TUTU_OK;
 }
@@ -248,7 +247,6 @@ int run_pass(TutuCtx* c, hipStream_t s, const TutuCameraFrame* cam, uint32_t key
 			// that only connect and end (UNLIT, emissive hit, miss) ride along with the first launch
 			uint32_t* pm = c->list_meta.p + (size_t)TUTU_META_STRIDE * (d - 1);
 			pp.cls_count = pm + 16;
-			pp.cls_base = pm + 24;
 			const uint32_t types = c->type_mask;
 			uint32_t extra = (1u << TUTU_UNLIT) | (1u << TUTU_CLASS_EMISSIVE) | (1u << TUTU_CLASS_MISS);
 			const struct { int mode; uint32_t mask; } groups[4] = {
@@ -270,7 +268,7 @@ int run_pass(TutuCtx* c, hipStream_t s, const TutuCameraFrame* cam, uint32_t key
 			}
 		}
 		if (d == TUTU_MAX_DEPTH + 1) break;  // the last shade only connects; nothing continues
-		rc = build_lists<LIST_FLAGS>(c, s, n_pad, meta, meta + 8, c->flag_lists.p, &c->totals.p->closest_rays, &c->totals.p->shadow_rays);
+		rc = build_lists<LIST_FLAGS>(c, s, n_pad, meta, c->flag_lists.p, &c->totals.p->closest_rays, &c->totals.p->shadow_rays);
 		if (rc != TUTU_OK) return rc;
 		TraceParams tp;
 		tp.sc = c->sc;
@@ -288,7 +286,7 @@ int run_pass(TutuCtx* c, hipStream_t s, const TutuCameraFrame* cam, uint32_t key
 		tp.n_ptr = meta + 1;
 		if (c->lds_scene) TIMED(EV_TRACE_ANY, k_trace<true, true><<<dim3(trace_grid), dim3(256), c->trace_lds_bytes, s>>>(tp));
 		else TIMED(EV_TRACE_ANY, k_trace<false, true><<<dim3(trace_grid), dim3(256), c->trace_lds_bytes, s>>>(tp));
-		rc = build_lists<LIST_CLASS>(c, s, n_pad, meta + 16, meta + 24, c->perm.p, nullptr, nullptr);
+		rc = build_lists<LIST_CLASS>(c, s, n_pad, meta + 16, c->perm.p, nullptr, nullptr);
 		if (rc != TUTU_OK) return rc;
 	}
 	return TUTU_OK;
