@@ -151,8 +151,8 @@ __global__ void __launch_bounds__(1024) k_list_scan(ListParams p) {
 	}
 	if (threadIdx.x == 0) {
 		p.list_count[c] = tot;
-		if (c == 0 && p.stat_a) *p.stat_a += tot;
-		if (c == 1 && p.stat_b) *p.stat_b += tot;
+		if (c == 0 && p.stat_a) atomicAdd(p.stat_a, (unsigned long long)tot);  // two passes may run concurrently on two streams
+		if (c == 1 && p.stat_b) atomicAdd(p.stat_b, (unsigned long long)tot);
 	}
 }
 

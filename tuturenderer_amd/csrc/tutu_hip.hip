@@ -78,15 +78,21 @@ struct TutuCtx {
 	SceneDev sc;
 	DevBuf<float4> d_nodes, d_tri_isect, d_tri_shade, d_mats, d_lights;
 	DevBuf<uint8_t> d_tri_class;
-	// work buffers
-	size_t cap = 0;         // path slots (multiple of TUTU_LIST_TILE)
-	DevBuf<float4> qbuf[11];  // A..H, S0..S2
+	// work buffers: two sets, so that consecutive passes run on two streams and a memory-bound stage of one pass
+	// overlaps a compute-bound stage of the other
+	struct WorkSet {
+		size_t cap = 0;           // path slots (multiple of TUTU_LIST_TILE)
+		DevBuf<float4> qbuf[11];  // A..H, S0..S2
+		DevBuf<uint8_t> kA, kB;
+		DevBuf<uint32_t> flag_lists;  // [2][cap]: extension-ray slots, shadow-request slots
+		DevBuf<uint32_t> perm;        // [cap]: continuing slots sorted by class
+		DevBuf<uint32_t> tile_counts, tile_offsets;
+		DevBuf<uint32_t> list_meta;   // per depth: flag-list counts [8] | class-list counts [8]
+		hipEvent_t ev_resolved = nullptr;
+	} ws[2];
+	hipStream_t stream2 = nullptr;
+	hipEvent_t ev_fork = nullptr;
 	DevBuf<float4> prim_dir, prim_hit, accum;
-	DevBuf<uint8_t> kA, kB;
-	DevBuf<uint32_t> flag_lists;  // [2][cap]: extension-ray slots, shadow-request slots
-	DevBuf<uint32_t> perm;        // [cap]: continuing slots sorted by class
-	DevBuf<uint32_t> tile_counts, tile_offsets;
-	DevBuf<uint32_t> list_meta;   // per depth: flags count[8], flags base[8], class count[8], class base[8]
 	DevBuf<Totals> totals;
 	DevBuf<int32_t> pixels;
 	DevBuf<uint32_t> u32a, u32b;
@@ -97,34 +103,44 @@ struct TutuCtx {
 
 namespace {
 
-Queue queue_of(TutuCtx* c) {
+typedef TutuCtx::WorkSet WorkSet;
+
+Queue queue_of(WorkSet& w) {
 	Queue q;
-	q.A = c->qbuf[0].p; q.B = c->qbuf[1].p; q.C = c->qbuf[2].p; q.D = c->qbuf[3].p;
-	q.E = c->qbuf[4].p; q.F = c->qbuf[5].p; q.G = c->qbuf[6].p; q.H = c->qbuf[7].p;
-	q.S0 = c->qbuf[8].p; q.S1 = c->qbuf[9].p; q.S2 = c->qbuf[10].p;
+	q.A = w.qbuf[0].p; q.B = w.qbuf[1].p; q.C = w.qbuf[2].p; q.D = w.qbuf[3].p;
+	q.E = w.qbuf[4].p; q.F = w.qbuf[5].p; q.G = w.qbuf[6].p; q.H = w.qbuf[7].p;
+	q.S0 = w.qbuf[8].p; q.S1 = w.qbuf[9].p; q.S2 = w.qbuf[10].p;
 	return q;
 }
 
 #define TUTU_META_STRIDE 32  // uint32 per depth in list_meta
 
-int ensure_work(TutuCtx* c, size_t want_slots, size_t nitems) {
+int ensure_set(WorkSet& w, size_t want_slots) {
 	int rc;
 	const size_t cap = (want_slots + TUTU_LIST_TILE - 1) / TUTU_LIST_TILE * TUTU_LIST_TILE;
-	if (cap > c->cap) {
+	if (cap > w.cap) {
 		for (int f = 0; f < 11; f++)
-			if ((rc = c->qbuf[f].ensure(cap)) != TUTU_OK) return rc;
-		if ((rc = c->kA.ensure(cap)) != TUTU_OK) return rc;
-		if ((rc = c->kB.ensure(cap)) != TUTU_OK) return rc;
-		if ((rc = c->flag_lists.ensure(2 * cap)) != TUTU_OK) return rc;
-		if ((rc = c->perm.ensure(cap)) != TUTU_OK) return rc;
-		if ((rc = c->tile_counts.ensure(8 * (cap / TUTU_LIST_TILE))) != TUTU_OK) return rc;
-		if ((rc = c->tile_offsets.ensure(8 * (cap / TUTU_LIST_TILE))) != TUTU_OK) return rc;
-		c->cap = cap;
+			if ((rc = w.qbuf[f].ensure(cap)) != TUTU_OK) return rc;
+		if ((rc = w.kA.ensure(cap)) != TUTU_OK) return rc;
+		if ((rc = w.kB.ensure(cap)) != TUTU_OK) return rc;
+		if ((rc = w.flag_lists.ensure(2 * cap)) != TUTU_OK) return rc;
+		if ((rc = w.perm.ensure(cap)) != TUTU_OK) return rc;
+		if ((rc = w.tile_counts.ensure(8 * (cap / TUTU_LIST_TILE))) != TUTU_OK) return rc;
+		if ((rc = w.tile_offsets.ensure(8 * (cap / TUTU_LIST_TILE))) != TUTU_OK) return rc;
+		w.cap = cap;
 	}
+	if ((rc = w.list_meta.ensure(TUTU_META_STRIDE * (TUTU_MAX_DEPTH + 3))) != TUTU_OK) return rc;
+	if (!w.ev_resolved) HIP_TRY(hipEventCreateWithFlags(&w.ev_resolved, hipEventDisableTiming));
+	return TUTU_OK;
+}
+
+int ensure_work(TutuCtx* c, size_t want_slots, size_t nitems, int n_sets) {
+	int rc;
+	for (int k = 0; k < n_sets; k++)
+		if ((rc = ensure_set(c->ws[k], want_slots)) != TUTU_OK) return rc;
 	if ((rc = c->prim_dir.ensure(nitems)) != TUTU_OK) return rc;
 	if ((rc = c->prim_hit.ensure(nitems)) != TUTU_OK) return rc;
 	if ((rc = c->accum.ensure(nitems)) != TUTU_OK) return rc;
-	if ((rc = c->list_meta.ensure(TUTU_META_STRIDE * (TUTU_MAX_DEPTH + 3))) != TUTU_OK) return rc;
 	if ((rc = c->totals.ensure(1)) != TUTU_OK) return rc;
 	return TUTU_OK;
 }
@@ -167,18 +183,18 @@ int persistent_grid(size_t upper_items, int n_cu, int blocks_per_cu) {
 
 // count -> scan -> scatter: stable index lists from the per-slot key bytes (device_lists.h)
 template <int MODE>
-int build_lists(TutuCtx* c, hipStream_t s, uint32_t n_slots_padded, uint32_t* meta_count, uint32_t* out,
+int build_lists(TutuCtx* c, WorkSet& w, hipStream_t s, uint32_t n_slots_padded, uint32_t* meta_count, uint32_t* out,
                 unsigned long long* stat_a, unsigned long long* stat_b) {
 	ListParams lp;
-	lp.kA = c->kA.p;
-	lp.kB = c->kB.p;
+	lp.kA = w.kA.p;
+	lp.kB = w.kB.p;
 	lp.n_slots = n_slots_padded;
 	lp.n_tiles = n_slots_padded / TUTU_LIST_TILE;
-	lp.tile_counts = c->tile_counts.p;
-	lp.tile_offsets = c->tile_offsets.p;
+	lp.tile_counts = w.tile_counts.p;
+	lp.tile_offsets = w.tile_offsets.p;
 	lp.list_count = meta_count;
 	lp.out = out;
-	lp.flags_stride = (uint32_t)c->cap;
+	lp.flags_stride = (uint32_t)w.cap;
 	lp.stat_a = stat_a;
 	lp.stat_b = stat_b;
 	TIMED(EV_OTHER, k_list_count<MODE><<<dim3(lp.n_tiles), dim3(256), 0, s>>>(lp));
@@ -208,12 +224,12 @@ int launch_shade(TutuCtx* c, hipStream_t s, int mode, dim3 grid, const PassParam
 }
 
 // One wavefront pass over `npix` work items x `nsamp` samples (or, with smp_list, one sample per item).
-int run_pass(TutuCtx* c, hipStream_t s, const TutuCameraFrame* cam, uint32_t key0, uint32_t key1, int npix, int s0, int nsamp,
+int run_pass(TutuCtx* c, WorkSet& w, hipStream_t s, const TutuCameraFrame* cam, uint32_t key0, uint32_t key1, int npix, int s0, int nsamp,
              const uint32_t* d_smp_list, uint32_t* n_trace_launches) {
 	const size_t npaths = (size_t)npix * (size_t)nsamp;
 	const uint32_t n_pad = (uint32_t)((npaths + TUTU_LIST_TILE - 1) / TUTU_LIST_TILE * TUTU_LIST_TILE);
 	// padding keys must read "nothing here"
-	if (n_pad > npaths) HIP_TRY(hipMemsetAsync(c->kA.p + npaths, 0, n_pad - npaths, s));
+	if (n_pad > npaths) HIP_TRY(hipMemsetAsync(w.kA.p + npaths, 0, n_pad - npaths, s));
 
 	PassParams pp;
 	memset(&pp, 0, sizeof(pp));
@@ -227,9 +243,9 @@ int run_pass(TutuCtx* c, hipStream_t s, const TutuCameraFrame* cam, uint32_t key
 	pp.prim_hit = c->prim_hit.p;
 	pp.smp_list = d_smp_list;
 	memcpy(pp.eye, cam->eye, sizeof(pp.eye));
-	pp.q = queue_of(c);
-	pp.kA = c->kA.p;
-	pp.perm = c->perm.p;
+	pp.q = queue_of(w);
+	pp.kA = w.kA.p;
+	pp.perm = w.perm.p;
 
 	const int shade_grid = persistent_grid(npaths, c->n_cu, 8);  // persistent blocks: the table staging is paid once per block
 	const int trace_grid = persistent_grid(npaths, c->n_cu, c->trace_blocks_per_cu);
@@ -237,7 +253,7 @@ int run_pass(TutuCtx* c, hipStream_t s, const TutuCameraFrame* cam, uint32_t key
 	pp.n_mats = (int)c->hs.mats.size();
 	for (int d = 0; d <= TUTU_MAX_DEPTH + 1; d++) {
 		pp.depth = d;
-		uint32_t* meta = c->list_meta.p + (size_t)TUTU_META_STRIDE * d;  // [0..8) flag counts, [8..16) flag bases, [16..24) class counts, [24..32) class bases
+		uint32_t* meta = w.list_meta.p + (size_t)TUTU_META_STRIDE * d;  // [0..8) flag counts, [8..16) flag bases, [16..24) class counts, [24..32) class bases
 		if (d == 0) {
 			dim3 g((unsigned)((npix + 255) / 256), (unsigned)nsamp, 1);
 			rc = launch_shade(c, s, SHADE_FIRST, g, pp);
@@ -245,7 +261,7 @@ int run_pass(TutuCtx* c, hipStream_t s, const TutuCameraFrame* cam, uint32_t key
 		} else {
 			// one launch per material class group that exists in the scene (sort-by-material pipeline); the classes
 			// that only connect and end (UNLIT, emissive hit, miss) ride along with the first launch
-			uint32_t* pm = c->list_meta.p + (size_t)TUTU_META_STRIDE * (d - 1);
+			uint32_t* pm = w.list_meta.p + (size_t)TUTU_META_STRIDE * (d - 1);
 			pp.cls_count = pm + 16;
 			const uint32_t types = c->type_mask;
 			uint32_t extra = (1u << TUTU_UNLIT) | (1u << TUTU_CLASS_EMISSIVE) | (1u << TUTU_CLASS_MISS);
@@ -268,25 +284,25 @@ int run_pass(TutuCtx* c, hipStream_t s, const TutuCameraFrame* cam, uint32_t key
 			}
 		}
 		if (d == TUTU_MAX_DEPTH + 1) break;  // the last shade only connects; nothing continues
-		rc = build_lists<LIST_FLAGS>(c, s, n_pad, meta, c->flag_lists.p, &c->totals.p->closest_rays, &c->totals.p->shadow_rays);
+		rc = build_lists<LIST_FLAGS>(c, w, s, n_pad, meta, w.flag_lists.p, &c->totals.p->closest_rays, &c->totals.p->shadow_rays);
 		if (rc != TUTU_OK) return rc;
 		TraceParams tp;
 		tp.sc = c->sc;
 		tp.q = pp.q;
-		tp.list = c->flag_lists.p;
+		tp.list = w.flag_lists.p;
 		tp.n_ptr = meta + 0;
-		tp.kA = c->kA.p;
-		tp.kB = c->kB.p;
+		tp.kA = w.kA.p;
+		tp.kB = w.kB.p;
 		tp.tri_class = c->d_tri_class.p;
 		tp.stack_entries = c->stack_entries;
 		if (c->lds_scene) TIMED(EV_TRACE_CLOSEST, k_trace<true, false><<<dim3(trace_grid), dim3(256), c->trace_lds_bytes, s>>>(tp));
 		else TIMED(EV_TRACE_CLOSEST, k_trace<false, false><<<dim3(trace_grid), dim3(256), c->trace_lds_bytes, s>>>(tp));
 		(*n_trace_launches)++;
-		tp.list = c->flag_lists.p + c->cap;
+		tp.list = w.flag_lists.p + w.cap;
 		tp.n_ptr = meta + 1;
 		if (c->lds_scene) TIMED(EV_TRACE_ANY, k_trace<true, true><<<dim3(trace_grid), dim3(256), c->trace_lds_bytes, s>>>(tp));
 		else TIMED(EV_TRACE_ANY, k_trace<false, true><<<dim3(trace_grid), dim3(256), c->trace_lds_bytes, s>>>(tp));
-		rc = build_lists<LIST_CLASS>(c, s, n_pad, meta + 16, c->perm.p, nullptr, nullptr);
+		rc = build_lists<LIST_CLASS>(c, w, s, n_pad, meta + 16, w.perm.p, nullptr, nullptr);
 		if (rc != TUTU_OK) return rc;
 	}
 	return TUTU_OK;
@@ -365,12 +381,15 @@ int render_impl(TutuCtx* c, const TutuCameraFrame* cam, const TutuRenderParams* 
 		npix = rect_w * (rp->y1 - rp->y0);
 	}
 	HIP_TRY(hipSetDevice(c->device));
+	// Paths in flight: max_paths in total, split over the two work sets that alternate passes on two streams.
 	const int64_t max_paths = rp->max_paths > 0 ? rp->max_paths : ((int64_t)16 << 20);
-	int spp_pass = rp->spp_per_pass > 0 ? rp->spp_per_pass : (int)std::max<int64_t>(1, max_paths / npix);
+	int spp_pass = rp->spp_per_pass > 0 ? rp->spp_per_pass : (int)std::max<int64_t>(1, (max_paths / 2) / npix);
 	spp_pass = std::min(spp_pass, rp->spp);
 	spp_pass = std::min(spp_pass, 65535);  // grid.y limit
+	const int n_passes = (rp->spp + spp_pass - 1) / spp_pass;
+	const int n_sets = n_passes > 1 ? 2 : 1;
 	const size_t cap = (size_t)npix * (size_t)spp_pass;
-	int rc = ensure_work(c, cap, (size_t)npix);
+	int rc = ensure_work(c, cap, (size_t)npix, n_sets);
 	if (rc != TUTU_OK) return rc;
 	const int32_t* d_pixels = nullptr;
 	if (rp->pixels) {
@@ -382,12 +401,30 @@ int render_impl(TutuCtx* c, const TutuCameraFrame* cam, const TutuRenderParams* 
 	HIP_TRY(hipMemsetAsync(c->totals.p, 0, sizeof(Totals), s));
 	if ((rc = launch_primary(c, s, cam, npix, d_pixels, nullptr, x0, y0, rect_w)) != TUTU_OK) return rc;
 	HIP_TRY(hipMemsetAsync(c->accum.p, 0, sizeof(float4) * (size_t)npix, s));
+	hipStream_t streams[2] = {s, c->stream2};
+	if (n_sets == 2) {  // fork: the second stream starts after the primary hits exist
+		HIP_TRY(hipEventRecord(c->ev_fork, s));
+		HIP_TRY(hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
+	}
 	uint32_t passes = 0, trace_launches = 0;
-	for (int s0 = 0; s0 < rp->spp; s0 += spp_pass) {
+	for (int s0 = 0, i = 0; s0 < rp->spp; s0 += spp_pass, i++) {
+		const int k = i & (n_sets - 1);
+		TutuCtx::WorkSet& w = c->ws[k];
+		hipStream_t sk = streams[k];
 		const int ns = std::min(spp_pass, rp->spp - s0);
-		if ((rc = run_pass(c, s, cam, rp->key0, rp->key1, npix, s0, ns, nullptr, &trace_launches)) != TUTU_OK) return rc;
-		TIMED(EV_OTHER, k_resolve<<<dim3((npix + 255) / 256), dim3(256), 0, s>>>(c->qbuf[5].p, c->accum.p, npix, ns));
+		if ((rc = run_pass(c, w, sk, cam, rp->key0, rp->key1, npix, s0, ns, nullptr, &trace_launches)) != TUTU_OK) return rc;
+		// samples are added to the estimate in sample order (PathTracing.hpp:507-513): pass i resolves after pass i-1
+		if (i > 0 && n_sets == 2) HIP_TRY(hipStreamWaitEvent(sk, c->ws[k ^ 1].ev_resolved, 0));
+		{
+			hipStream_t s = sk;  // TIMED records on `s`
+			TIMED(EV_OTHER, k_resolve<<<dim3((npix + 255) / 256), dim3(256), 0, s>>>(w.qbuf[5].p, c->accum.p, npix, ns));
+		}
+		if (n_sets == 2) HIP_TRY(hipEventRecord(w.ev_resolved, sk));
 		passes++;
+	}
+	if (n_sets == 2) {  // join
+		const int last = (int)((passes - 1) & 1u);
+		if (last == 1) HIP_TRY(hipStreamWaitEvent(s, c->ws[1].ev_resolved, 0));
 	}
 	const float spp_inv = 1.f / rp->spp;  // SPP_inv, global.hpp:20
 	TIMED(EV_OTHER, k_finalize<<<dim3((npix + 255) / 256), dim3(256), 0, s>>>(c->accum.p, d_out, npix, spp_inv));
@@ -443,6 +480,8 @@ int tutu_hip_create(const TutuSceneDesc* scene, int device, TutuCtx** out) {
 	hipDeviceProp_t prop;
 	if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
 	if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) return fail(TUTU_E_HIP);
+	if (hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) != hipSuccess) return fail(TUTU_E_HIP);
+	if (hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess) return fail(TUTU_E_HIP);
 	hipStream_t s = c->stream;
 	if ((rc = upload(c->d_nodes, c->hs.nodes, s)) != TUTU_OK) return fail(rc);
 	if ((rc = upload(c->d_tri_isect, c->hs.tri_isect, s)) != TUTU_OK) return fail(rc);
@@ -507,9 +546,17 @@ int tutu_hip_destroy(TutuCtx* c) {
 		(void)hipEventDestroy(e.b);
 	}
 	c->d_tri_class.release(); c->d_nodes.release(); c->d_tri_isect.release(); c->d_tri_shade.release(); c->d_mats.release(); c->d_lights.release();
-	for (int f = 0; f < 11; f++) c->qbuf[f].release();
-	c->prim_dir.release(); c->prim_hit.release(); c->accum.release(); c->kA.release(); c->kB.release();
-	c->flag_lists.release(); c->perm.release(); c->tile_counts.release(); c->tile_offsets.release(); c->list_meta.release();
+	if (c->stream2) (void)hipStreamSynchronize(c->stream2);
+	for (int k = 0; k < 2; k++) {
+		TutuCtx::WorkSet& w = c->ws[k];
+		for (int f = 0; f < 11; f++) w.qbuf[f].release();
+		w.kA.release(); w.kB.release(); w.flag_lists.release(); w.perm.release(); w.tile_counts.release(); w.tile_offsets.release();
+		w.list_meta.release();
+		if (w.ev_resolved) (void)hipEventDestroy(w.ev_resolved);
+	}
+	if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+	if (c->stream2) (void)hipStreamDestroy(c->stream2);
+	c->prim_dir.release(); c->prim_hit.release(); c->accum.release();
 	c->totals.release(); c->pixels.release(); c->u32a.release(); c->u32b.release();
 	c->out_stage.release();
 	if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -559,7 +606,7 @@ int tutu_hip_trace_samples(TutuCtx* c, const TutuCameraFrame* cam, uint32_t n, c
 		if (pix[i] >= (uint32_t)(cam->width * cam->height)) return TUTU_E_INVALID;
 	HIP_TRY(hipSetDevice(c->device));
 	hipStream_t s = c->stream;
-	int rc = ensure_work(c, n, n);
+	int rc = ensure_work(c, n, n, 1);
 	if (rc != TUTU_OK) return rc;
 	if ((rc = c->u32a.ensure(n)) != TUTU_OK) return rc;
 	if ((rc = c->u32b.ensure(n)) != TUTU_OK) return rc;
@@ -570,8 +617,8 @@ int tutu_hip_trace_samples(TutuCtx* c, const TutuCameraFrame* cam, uint32_t n, c
 	HIP_TRY(hipMemsetAsync(c->totals.p, 0, sizeof(Totals), s));
 	if ((rc = launch_primary(c, s, cam, (int)n, nullptr, c->u32a.p, 0, 0, 1)) != TUTU_OK) return rc;
 	uint32_t tl = 0;
-	if ((rc = run_pass(c, s, cam, key0, key1, (int)n, 0, 1, c->u32b.p, &tl)) != TUTU_OK) return rc;
-	hipLaunchKernelGGL(k_copy_L, dim3((n + 255) / 256), dim3(256), 0, s, c->qbuf[5].p, c->out_stage.p, (int)n);
+	if ((rc = run_pass(c, c->ws[0], s, cam, key0, key1, (int)n, 0, 1, c->u32b.p, &tl)) != TUTU_OK) return rc;
+	hipLaunchKernelGGL(k_copy_L, dim3((n + 255) / 256), dim3(256), 0, s, c->ws[0].qbuf[5].p, c->out_stage.p, (int)n);
 	HIP_TRY(hipGetLastError());
 	HIP_TRY(hipStreamSynchronize(s));
 	c->ev_used = 0;
@@ -695,18 +742,19 @@ extern "C" {
 // parity tests exercise exactly the code the renderer uses.
 static int run_trace_kernel(TutuCtx* c, uint32_t n, bool any) {
 	hipStream_t s = c->stream;
+	TutuCtx::WorkSet& w = c->ws[0];
 	std::vector<uint32_t> iota(n);
 	for (uint32_t i = 0; i < n; i++) iota[i] = i;
-	uint32_t* list = any ? c->flag_lists.p + c->cap : c->flag_lists.p;
+	uint32_t* list = any ? w.flag_lists.p + w.cap : w.flag_lists.p;
 	HIP_TRY(hipMemcpyAsync(list, iota.data(), sizeof(uint32_t) * n, hipMemcpyHostToDevice, s));
-	HIP_TRY(hipMemcpyAsync(c->list_meta.p + (any ? 1 : 0), &n, sizeof(uint32_t), hipMemcpyHostToDevice, s));
+	HIP_TRY(hipMemcpyAsync(w.list_meta.p + (any ? 1 : 0), &n, sizeof(uint32_t), hipMemcpyHostToDevice, s));
 	TraceParams tp;
 	tp.sc = c->sc;
-	tp.q = queue_of(c);
+	tp.q = queue_of(w);
 	tp.list = list;
-	tp.n_ptr = c->list_meta.p + (any ? 1 : 0);
-	tp.kA = c->kA.p;
-	tp.kB = c->kB.p;
+	tp.n_ptr = w.list_meta.p + (any ? 1 : 0);
+	tp.kA = w.kA.p;
+	tp.kB = w.kB.p;
 	tp.tri_class = c->d_tri_class.p;
 	tp.stack_entries = c->stack_entries;
 	const int grid = persistent_grid(n, c->n_cu, c->trace_blocks_per_cu);
@@ -726,18 +774,18 @@ int tutu_hip_trace_closest(TutuCtx* c, uint32_t n, const float* orig, const floa
 	if (!c || !orig || !dir || !hits) return TUTU_E_INVALID;
 	if (n == 0) return TUTU_OK;
 	HIP_TRY(hipSetDevice(c->device));
-	int rc = ensure_work(c, n, 1);
+	int rc = ensure_work(c, n, 1, 1);
 	if (rc != TUTU_OK) return rc;
 	std::vector<float4> A(n), B(n);
 	for (uint32_t i = 0; i < n; i++) {
 		A[i] = make_float4(orig[3 * (size_t)i], orig[3 * (size_t)i + 1], orig[3 * (size_t)i + 2], 0.f);
 		B[i] = make_float4(dir[3 * (size_t)i], dir[3 * (size_t)i + 1], dir[3 * (size_t)i + 2], 0.f);
 	}
-	HIP_TRY(hipMemcpyAsync(c->qbuf[0].p, A.data(), sizeof(float4) * n, hipMemcpyHostToDevice, c->stream));
-	HIP_TRY(hipMemcpyAsync(c->qbuf[1].p, B.data(), sizeof(float4) * n, hipMemcpyHostToDevice, c->stream));
+	HIP_TRY(hipMemcpyAsync(c->ws[0].qbuf[0].p, A.data(), sizeof(float4) * n, hipMemcpyHostToDevice, c->stream));
+	HIP_TRY(hipMemcpyAsync(c->ws[0].qbuf[1].p, B.data(), sizeof(float4) * n, hipMemcpyHostToDevice, c->stream));
 	rc = run_trace_kernel(c, n, false);
 	if (rc != TUTU_OK) return rc;
-	HIP_TRY(hipMemcpy(A.data(), c->qbuf[2].p, sizeof(float4) * n, hipMemcpyDeviceToHost));
+	HIP_TRY(hipMemcpy(A.data(), c->ws[0].qbuf[2].p, sizeof(float4) * n, hipMemcpyDeviceToHost));
 	for (uint32_t i = 0; i < n; i++) {
 		int tri;
 		memcpy(&tri, &A[i].w, 4);
@@ -753,7 +801,7 @@ int tutu_hip_trace_any(TutuCtx* c, uint32_t n, const float* orig, const float* t
 	if (!c || !orig || !target || !blocked) return TUTU_E_INVALID;
 	if (n == 0) return TUTU_OK;
 	HIP_TRY(hipSetDevice(c->device));
-	int rc = ensure_work(c, n, 1);
+	int rc = ensure_work(c, n, 1, 1);
 	if (rc != TUTU_OK) return rc;
 	// a shadow request with contribution (1,0,0): unblocked rays add it to the (zeroed) radiance field
 	std::vector<float4> S0(n), S1(n), S2(n);
@@ -765,14 +813,14 @@ int tutu_hip_trace_any(TutuCtx* c, uint32_t n, const float* orig, const float* t
 		S2[i] = make_float4(0.f, 0.f, 0.f, 0.f);
 	}
 	hipStream_t s = c->stream;
-	HIP_TRY(hipMemcpyAsync(c->qbuf[8].p, S0.data(), sizeof(float4) * n, hipMemcpyHostToDevice, s));
-	HIP_TRY(hipMemcpyAsync(c->qbuf[9].p, S1.data(), sizeof(float4) * n, hipMemcpyHostToDevice, s));
-	HIP_TRY(hipMemcpyAsync(c->qbuf[10].p, S2.data(), sizeof(float4) * n, hipMemcpyHostToDevice, s));
-	HIP_TRY(hipMemsetAsync(c->qbuf[5].p, 0, sizeof(float4) * n, s));
-	HIP_TRY(hipMemsetAsync(c->kA.p, 0, n, s));
+	HIP_TRY(hipMemcpyAsync(c->ws[0].qbuf[8].p, S0.data(), sizeof(float4) * n, hipMemcpyHostToDevice, s));
+	HIP_TRY(hipMemcpyAsync(c->ws[0].qbuf[9].p, S1.data(), sizeof(float4) * n, hipMemcpyHostToDevice, s));
+	HIP_TRY(hipMemcpyAsync(c->ws[0].qbuf[10].p, S2.data(), sizeof(float4) * n, hipMemcpyHostToDevice, s));
+	HIP_TRY(hipMemsetAsync(c->ws[0].qbuf[5].p, 0, sizeof(float4) * n, s));
+	HIP_TRY(hipMemsetAsync(c->ws[0].kA.p, 0, n, s));
 	rc = run_trace_kernel(c, n, true);
 	if (rc != TUTU_OK) return rc;
-	HIP_TRY(hipMemcpy(S0.data(), c->qbuf[5].p, sizeof(float4) * n, hipMemcpyDeviceToHost));
+	HIP_TRY(hipMemcpy(S0.data(), c->ws[0].qbuf[5].p, sizeof(float4) * n, hipMemcpyDeviceToHost));
 	for (uint32_t i = 0; i < n; i++) blocked[i] = S0[i].x == 0.f ? 1 : 0;
 	return TUTU_OK;
 }
