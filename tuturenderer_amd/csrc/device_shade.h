@@ -427,10 +427,15 @@ __global__ void __launch_bounds__(256) k_shade(PassParams pp) {
 							} else {
 								sh_c = beta * (mis_weight_l * ls.emission * f_r * cos_theta * cos_theta_prime / (r2 * pdfl));
 							}
-							pp.q.S0[slot] = make_float4(shadowRayOrig.x, shadowRayOrig.y, shadowRayOrig.z, lightPos.x);
-							pp.q.S1[slot] = make_float4(lightPos.y, lightPos.z, sh_c.x, sh_c.y);
-							pp.q.S2[slot] = make_float4(sh_c.z, __uint_as_float(sh_flags), 0.f, 0.f);
-							key |= TUTU_KEY_SHADOW;
+							// A contribution that is exactly zero (surface facing away from the light: f_r = 0) cannot change
+							// the radiance whatever the shadow ray finds: the reference traces that ray for nothing, we do not.
+							// (NaN != 0, so a NaN contribution is still traced and still poisons the sample as it must.)
+							if (kill_req || sh_c.x != 0.f || sh_c.y != 0.f || sh_c.z != 0.f) {
+								pp.q.S0[slot] = make_float4(shadowRayOrig.x, shadowRayOrig.y, shadowRayOrig.z, lightPos.x);
+								pp.q.S1[slot] = make_float4(lightPos.y, lightPos.z, sh_c.x, sh_c.y);
+								pp.q.S2[slot] = make_float4(sh_c.z, __uint_as_float(sh_flags), 0.f, 0.f);
+								key |= TUTU_KEY_SHADOW;
+							}
 						}
 					}
 				}

@@ -247,8 +247,10 @@ int run_pass(TutuCtx* c, WorkSet& w, hipStream_t s, const TutuCameraFrame* cam, 
 	pp.kA = w.kA.p;
 	pp.perm = w.perm.p;
 
-	const int shade_grid = persistent_grid(npaths, c->n_cu, 8);  // persistent blocks: the table staging is paid once per block
-	const int trace_grid = persistent_grid(npaths, c->n_cu, c->trace_blocks_per_cu);
+	static const int shade_bpc = getenv("TUTU_SHADE_BPC") ? atoi(getenv("TUTU_SHADE_BPC")) : 8;
+	static const int trace_bpc_env = getenv("TUTU_TRACE_BPC") ? atoi(getenv("TUTU_TRACE_BPC")) : 0;
+	const int shade_grid = persistent_grid(npaths, c->n_cu, shade_bpc);  // persistent blocks: the table staging is paid once per block
+	const int trace_grid = persistent_grid(npaths, c->n_cu, trace_bpc_env > 0 ? std::min(trace_bpc_env, c->trace_blocks_per_cu) : c->trace_blocks_per_cu);
 	int rc = TUTU_OK;
 	pp.n_mats = (int)c->hs.mats.size();
 	for (int d = 0; d <= TUTU_MAX_DEPTH + 1; d++) {
@@ -270,7 +272,10 @@ int run_pass(TutuCtx* c, WorkSet& w, hipStream_t s, const TutuCameraFrame* cam, 
 			    {SHADE_MIRROR, 1u << TUTU_PERFECT_REFLECTIVE},
 			    {SHADE_REFRACT, (1u << TUTU_PERFECT_REFRACTIVE) | (1u << TUTU_MICROFACET_T)},
 			    {SHADE_GGXR, 1u << TUTU_MICROFACET_R}};
-			for (int gi = 0; gi < 4; gi++) {
+			// the last stage only connects vertex MAX_DEPTH: nothing but a BSDF ray that landed on a light (or the
+			// background behind a refractive vertex) can still add radiance -> classes emissive / miss only
+			const bool last = d == TUTU_MAX_DEPTH + 1;
+			for (int gi = 0; gi < 4 && !last; gi++) {
 				if (!(types & groups[gi].mask)) continue;
 				pp.class_mask = groups[gi].mask | extra;
 				extra = 0;
