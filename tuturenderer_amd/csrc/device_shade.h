@@ -515,6 +515,7 @@ TUTU_DEV void trace_persistent(const S& ss, const TraceParams& tp, int* stack, c
 	uint32_t next = begin;
 
 	int cur = TUTU_TRAV_IDLE;
+	int pend = TUTU_TRAV_IDLE;  // parked leaf (TUTU_TRAV_IDLE = none)
 	int sp = 0;
 	uint32_t slot = 0;
 	RayPre r = make_ray(mk1(0.f), mk1(1.f));
@@ -561,7 +562,8 @@ TUTU_DEV void trace_persistent(const S& ss, const TraceParams& tp, int* stack, c
 		}
 		if (__ballot(cur != TUTU_TRAV_IDLE) == 0ull) break;
 
-		// ---- inner nodes
+		// ---- inner nodes.  A lane that reaches a leaf parks it in `pend` and keeps descending, so that lanes are not
+		// idle while the wave's other lanes still walk inner nodes (postponed leaf test)
 #pragma unroll 1
 		for (int k = 0; k < TUTU_INNER_STEPS; k++) {
 			if (__ballot(cur >= 0) == 0ull) break;
@@ -585,29 +587,55 @@ TUTU_DEV void trace_persistent(const S& ss, const TraceParams& tp, int* stack, c
 					sp--;
 					cur = stack[sp * 256];
 				}
+				if (cur < 0 && cur > TUTU_TRAV_IDLE && pend == TUTU_TRAV_IDLE) {  // park the leaf, go on
+					pend = cur;
+					if (sp == 0) cur = TUTU_TRAV_DONE;
+					else {
+						sp--;
+						cur = stack[sp * 256];
+					}
+				}
 			}
 		}
 
-		// ---- leaf
-		if (cur < 0 && cur > TUTU_TRAV_IDLE) {
-			const int ti = ~cur;
-			float t, u, v;
-			const bool h = tri_test(ss, ti, r, t, u, v);
-			if (ANY) {
-				if (h && t < dis && !float_equal(t, dis)) blocked = true;  // BVH.hpp:186
-			} else if (h && (t < best_t || (t == best_t && ti < best_tri))) {
-				best_t = t; best_u = u; best_v = v; best_tri = ti;
-			}
-			if ((ANY && blocked) || sp == 0) {
-				cur = TUTU_TRAV_DONE;
-			} else {
-				sp--;
-				cur = stack[sp * 256];
+		// ---- leaf: the parked leaf, or the leaf the lane sits on
+		{
+			const bool has_pend = pend != TUTU_TRAV_IDLE;
+			const bool on_leaf = cur < 0 && cur > TUTU_TRAV_IDLE;
+			if (has_pend || on_leaf) {
+				const int ti = has_pend ? ~pend : ~cur;
+				float t, u, v;
+				const bool h = tri_test(ss, ti, r, t, u, v);
+				if (ANY) {
+					if (h && t < dis && !float_equal(t, dis)) blocked = true;  // BVH.hpp:186
+				} else if (h && (t < best_t || (t == best_t && ti < best_tri))) {
+					best_t = t; best_u = u; best_v = v; best_tri = ti;
+				}
+				if (has_pend) {
+					pend = TUTU_TRAV_IDLE;
+					if (on_leaf) {  // the second leaf reached meanwhile moves into the parking slot
+						pend = cur;
+						if (sp == 0) cur = TUTU_TRAV_DONE;
+						else {
+							sp--;
+							cur = stack[sp * 256];
+						}
+					}
+				} else if (sp == 0) {
+					cur = TUTU_TRAV_DONE;
+				} else {
+					sp--;
+					cur = stack[sp * 256];
+				}
+				if (ANY && blocked) {
+					cur = TUTU_TRAV_DONE;
+					pend = TUTU_TRAV_IDLE;
+				}
 			}
 		}
 
 		// ---- finish
-		if (cur == TUTU_TRAV_DONE) {
+		if (cur == TUTU_TRAV_DONE && pend == TUTU_TRAV_IDLE) {
 			if (!ANY) {
 				tp.q.C[slot] = make_float4(best_t, best_u, best_v, __int_as_float(best_tri));
 				tp.kB[slot] = best_tri >= 0 ? tri_class[best_tri] : (uint8_t)TUTU_CLASS_MISS;
