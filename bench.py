@@ -66,6 +66,8 @@ def main():
     ap.add_argument("--max-paths", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dump", type=str, default="")
+    ap.add_argument("--backend", default="nccl", help="nccl (= RCCL, the measured configuration) or gloo (rehearsal of the N>1 path)")
+    ap.add_argument("--same-device", action="store_true", help="rehearsal only: every rank uses cuda:0 (needs --backend gloo)")
     args = ap.parse_args()
 
     import torch
@@ -81,18 +83,23 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N")
     distributed = world > 1
+    if args.same_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if distributed:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group("gloo")
 
     W, H, spp = args.width, args.height, args.spp
     scene = scenes.cornell_box(W, H)
     from tuturenderer_amd.dist import TILE, FrameGather
 
     ctx = tr.Context(scene, device=local_rank)
-    fg = FrameGather(W, H, rank, world, dev)
+    fg = FrameGather(W, H, rank, world, dev, host_staging=(distributed and args.backend != "nccl"))
     mine = fg.mine
     torch.cuda.synchronize()  # the library renders on its own stream: torch's allocation fills must have landed
 

@@ -34,11 +34,12 @@ def tile_pixel_lists(W, H, n_ranks, tile=TILE):
 class FrameGather:
     """Owns the per-rank output piece and, on rank 0, the assembled frame."""
 
-    def __init__(self, W, H, rank, world, device, tile=TILE):
+    def __init__(self, W, H, rank, world, device, tile=TILE, host_staging=False):
         import torch
 
         self.torch = torch
         self.W, self.H, self.rank, self.world = W, H, rank, world
+        self.host_staging = host_staging  # gloo rehearsal: the collective runs on CPU copies of the pieces
         self.lists = tile_pixel_lists(W, H, world, tile)
         self.mine = self.lists[rank]
         n_max = max(len(l) for l in self.lists)
@@ -52,10 +53,18 @@ class FrameGather:
         if self.world > 1:
             import torch.distributed as dist
 
-            dist.gather(self.piece, self.gather_list, dst=0)
-            if self.rank == 0:
-                for r in range(self.world):
-                    self.frame.index_copy_(0, self.index[r], self.gather_list[r][: len(self.lists[r])])
+            if self.host_staging:
+                piece = self.piece.cpu()
+                glist = [self.torch.zeros_like(piece) for _ in range(self.world)] if self.rank == 0 else None
+                dist.gather(piece, glist, dst=0)
+                if self.rank == 0:
+                    for r in range(self.world):
+                        self.frame.index_copy_(0, self.index[r], glist[r][: len(self.lists[r])].to(self.frame.device))
+            else:
+                dist.gather(self.piece, self.gather_list, dst=0)
+                if self.rank == 0:
+                    for r in range(self.world):
+                        self.frame.index_copy_(0, self.index[r], self.gather_list[r][: len(self.lists[r])])
         else:
             self.frame.index_copy_(0, self.index[0], self.piece[: len(self.mine)])
         return self.frame
