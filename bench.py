@@ -118,7 +118,8 @@ def main():
     fence()
     t0 = time.perf_counter()
     agg = {"ms_trace_closest": 0.0, "ms_trace_any": 0.0, "ms_shade": 0.0, "ms_other": 0.0, "trace_launches": 0, "closest_rays": 0,
-           "shadow_rays": 0, "passes": 0}
+           "shadow_rays": 0, "passes": 0, "ms_shade_first": 0.0, "ms_shade_material": 0.0, "ms_shade_terminal": 0.0,
+           "shade_material_launches": 0}
     for _ in range(args.steps):
         st = step()
         for k in agg:
@@ -142,20 +143,27 @@ def main():
             "k_shade": 192.0,                                                          # per segment
         }
         prim = len(mine) * args.steps  # primary rays go through k_primary, not the queue kernel
-        units = {"k_trace_closest": agg["closest_rays"] - prim, "k_trace_any": agg["shadow_rays"], "k_shade": agg["closest_rays"]}
-        ms = {"k_trace_closest": agg["ms_trace_closest"], "k_trace_any": agg["ms_trace_any"], "k_shade": agg["ms_shade"]}
+        ext = agg["closest_rays"] - prim  # extension rays = path vertices shaded at depth >= 1
+        # k_shade here = the per-material-class launches at depth >= 1 (one kernel name per class group; the Cornell
+        # box has one group, LAMBERTIAN: rocprof's `k_shade<1, 2>`); the depth-0 and connect-only launches are separate
+        units = {"k_trace_closest": ext, "k_trace_any": agg["shadow_rays"], "k_shade": ext}
+        ms = {"k_trace_closest": agg["ms_trace_closest"], "k_trace_any": agg["ms_trace_any"], "k_shade": agg["ms_shade_material"]}
+        nl = {"k_trace_closest": agg["trace_launches"], "k_trace_any": agg["trace_launches"], "k_shade": agg["shade_material_launches"]}
         dom = max(ms, key=ms.get)
-        launches = agg["trace_launches"] if dom != "k_shade" else agg["trace_launches"] + agg["passes"]
+        launches = nl[dom]
         achieved = units[dom] * per_unit[dom] / (ms[dom] * 1e-3) / 1e9  # GB/s
-        traffic = None
+        traffic = None  # HBM bytes per launch from the committed PMC passes (profiles/make_traffic.py), if any
         prof = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(prof):
-            traffic = json.load(open(prof)).get(dom)
+            traffic = json.load(open(prof)).get(dom, {}).get("bytes_per_launch")
         roofline = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                    "algorithmic_bytes_per_launch": units[dom] * per_unit[dom] / max(launches, 1),
                     "algorithmic_bytes_per_unit": per_unit[dom], "units_per_launch": units[dom] / max(launches, 1),
                     "avg_launch_ms": ms[dom] / max(launches, 1), "launches": launches,
-                    "kernel_ms_per_step": {k: v / args.steps for k, v in ms.items()},
+                    "kernel_ms_per_step": dict({k: v / args.steps for k, v in ms.items()}, k_shade_depth0=agg["ms_shade_first"] / args.steps,
+                                               k_shade_connect_only=agg["ms_shade_terminal"] / args.steps, other=agg["ms_other"] / args.steps),
+                    "note": "consecutive passes run on two streams, so stage times overlap: their sum exceeds ms_per_step",
                     "pipeline_B_sample": wc["B_sample_bytes_at_512spp"],
                     "pipeline_frac": value * 1e6 * wc["B_sample_bytes_at_512spp"] / (HBM_PEAK_GBS * 1e9)}
         line = {

@@ -96,7 +96,7 @@ typedef struct TutuRenderParams {
 	int32_t n_pixels;
 	int32_t x0, y0, x1, y1;
 	int32_t spp_per_pass; /* samples per pixel traced per wavefront pass; 0 = choose from max_paths */
-	int64_t max_paths;    /* cap on paths in flight per pass (device memory ~ 400 B each); 0 = default 16 Mi */
+	int64_t max_paths;    /* cap on paths in flight, summed over the two work sets that alternate passes (device memory ~ 190 B each); 0 = default 16 Mi */
 } TutuRenderParams;
 
 typedef struct TutuStats {
@@ -109,8 +109,12 @@ typedef struct TutuStats {
 	float ms_total;          /* device time of the whole call's kernels, HIP events on the library's stream */
 	float ms_trace_closest;  /* summed over launches */
 	float ms_trace_any;
-	float ms_shade;
-	float ms_other; /* primary rays, resolve, memsets */
+	float ms_shade;          /* all shade launches (= ms_shade_first + ms_shade_material + ms_shade_terminal) */
+	float ms_other;          /* primary rays, list building, resolve */
+	float ms_shade_first;    /* depth-0 launches (k_shade<SHADE_FIRST>) */
+	float ms_shade_material; /* per-material-class launches at depth >= 1 */
+	float ms_shade_terminal; /* launches that only connect (last depth; scenes without scattering materials) */
+	uint32_t shade_material_launches;
 } TutuStats;
 
 typedef struct TutuHit {

@@ -32,7 +32,7 @@ static thread_local std::string g_last_error;
 
 namespace {
 
-enum EvKind { EV_TRACE_CLOSEST = 0, EV_TRACE_ANY = 1, EV_SHADE = 2, EV_OTHER = 3, EV_NKIND = 4 };
+enum EvKind { EV_TRACE_CLOSEST = 0, EV_TRACE_ANY = 1, EV_SHADE = 2, EV_OTHER = 3, EV_SHADE_FIRST = 4, EV_SHADE_TERM = 5, EV_NKIND = 6 };
 
 struct EvPair {
 	hipEvent_t a, b;
@@ -205,10 +205,11 @@ int build_lists(TutuCtx* c, WorkSet& w, hipStream_t s, uint32_t n_slots_padded, 
 
 template <int MODE>
 int launch_shade_tab(TutuCtx* c, hipStream_t s, dim3 grid, const PassParams& pp) {
+	const int ev = MODE == SHADE_FIRST ? EV_SHADE_FIRST : (MODE == SHADE_TERMINAL ? EV_SHADE_TERM : EV_SHADE);
 	switch (c->shade_tab) {
-	case 2: TIMED(EV_SHADE, k_shade<MODE, 2><<<grid, dim3(256), c->shade_lds_bytes, s>>>(pp)); break;
-	case 1: TIMED(EV_SHADE, k_shade<MODE, 1><<<grid, dim3(256), c->shade_lds_bytes, s>>>(pp)); break;
-	default: TIMED(EV_SHADE, k_shade<MODE, 0><<<grid, dim3(256), 0, s>>>(pp)); break;
+	case 2: TIMED(ev, k_shade<MODE, 2><<<grid, dim3(256), c->shade_lds_bytes, s>>>(pp)); break;
+	case 1: TIMED(ev, k_shade<MODE, 1><<<grid, dim3(256), c->shade_lds_bytes, s>>>(pp)); break;
+	default: TIMED(ev, k_shade<MODE, 0><<<grid, dim3(256), 0, s>>>(pp)); break;
 	}
 	return TUTU_OK;
 }
@@ -349,11 +350,13 @@ int collect_stats(TutuCtx* c, hipStream_t s, TutuStats* st, uint64_t samples, ui
 	st->segments = samples + (t.closest_rays > (uint64_t)0 ? t.closest_rays : 0) - 0;  // vertices reached: depth-0 of every sample + every extension ray
 	st->passes = passes;
 	st->trace_launches = trace_launches;
-	float ms[EV_NKIND] = {0, 0, 0, 0};
+	float ms[EV_NKIND] = {0, 0, 0, 0, 0, 0};
+	uint32_t launches[EV_NKIND] = {0, 0, 0, 0, 0, 0};
 	for (size_t i = 0; i < c->ev_used; i++) {
 		float e = 0.f;
 		HIP_TRY(hipEventElapsedTime(&e, c->ev_pool[i].a, c->ev_pool[i].b));
 		ms[c->ev_pool[i].kind] += e;
+		launches[c->ev_pool[i].kind]++;
 	}
 	if (c->ev_used > 0) {
 		float tot = 0.f;
@@ -362,7 +365,11 @@ int collect_stats(TutuCtx* c, hipStream_t s, TutuStats* st, uint64_t samples, ui
 	}
 	st->ms_trace_closest = ms[EV_TRACE_CLOSEST];
 	st->ms_trace_any = ms[EV_TRACE_ANY];
-	st->ms_shade = ms[EV_SHADE];
+	st->ms_shade = ms[EV_SHADE] + ms[EV_SHADE_FIRST] + ms[EV_SHADE_TERM];
+	st->ms_shade_first = ms[EV_SHADE_FIRST];
+	st->ms_shade_material = ms[EV_SHADE];
+	st->ms_shade_terminal = ms[EV_SHADE_TERM];
+	st->shade_material_launches = launches[EV_SHADE];
 	st->ms_other = ms[EV_OTHER];
 	c->ev_used = 0;
 	return TUTU_OK;
