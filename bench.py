@@ -68,6 +68,7 @@ def main():
     ap.add_argument("--dump", type=str, default="")
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL, the measured configuration) or gloo (rehearsal of the N>1 path)")
     ap.add_argument("--same-device", action="store_true", help="rehearsal only: every rank uses cuda:0 (needs --backend gloo)")
+    ap.add_argument("--emulate-shard", type=int, default=0, help="analysis only: render just shard 0 of an N-way tile split (no collective)")
     args = ap.parse_args()
 
     import torch
@@ -101,11 +102,15 @@ def main():
     ctx = tr.Context(scene, device=local_rank)
     fg = FrameGather(W, H, rank, world, dev, host_staging=(distributed and args.backend != "nccl"))
     mine = fg.mine
+    if args.emulate_shard > 1:
+        from tuturenderer_amd.dist import tile_pixel_lists
+        mine = tile_pixel_lists(W, H, args.emulate_shard)[0]
     torch.cuda.synchronize()  # the library renders on its own stream: torch's allocation fills must have landed
 
     def step():
         ctx.render_device(fg.piece.data_ptr(), spp, KEY0, KEY1, pixels=mine, max_paths=args.max_paths)
-        fg.assemble()  # N > 1: the one collective, an RCCL gather of the framebuffer pieces to rank 0
+        if args.emulate_shard <= 1:
+            fg.assemble()  # N > 1: the one collective, an RCCL gather of the framebuffer pieces to rank 0
         return ctx.last_stats
 
     def fence():

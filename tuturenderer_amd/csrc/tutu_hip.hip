@@ -377,7 +377,7 @@ int collect_stats(TutuCtx* c, hipStream_t s, TutuStats* st, uint64_t samples, ui
 
 int render_impl(TutuCtx* c, const TutuCameraFrame* cam, const TutuRenderParams* rp, float* d_out, hipStream_t s, TutuStats* st) {
 	if (!c || !cam || !rp || !d_out) return TUTU_E_INVALID;
-	if (rp->spp <= 0 || cam->width <= 0 || cam->height <= 0) return TUTU_E_INVALID;
+	if (rp->spp <= 0 || rp->spp > (1 << 24) || cam->width <= 0 || cam->height <= 0) return TUTU_E_INVALID;  // sample index: 24 bits of the record
 	int npix, x0 = 0, y0 = 0, rect_w = 1;
 	if (rp->pixels) {
 		if (rp->n_pixels <= 0) return TUTU_E_INVALID;
