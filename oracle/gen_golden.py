@@ -38,6 +38,7 @@ def golden_scenes():
             short=make_material(PERFECT_REFRACTIVE, (0.725, 0.71, 0.68), eta=1.5)), 3),
         "veach": (lambda: scenes.veach_room(96, 72, small_light=False), 5),
         "veach_slight": (lambda: scenes.veach_room(96, 72, small_light=True), 6),
+        "cornell_degenerate": (lambda: pc.degenerate_cornell(64, 64), 9),
     }
 
 

@@ -274,3 +274,22 @@ def run_samples(S, key1, n=3000, spp=4):
     pix, smp = sample_ids(S, n=n, spp=spp)
     L, nd, nc = S.trace_samples(pix, smp, KEY0, key1, stats=True)
     return {"L": L, "ndraws": nd, "nclosest": nc, "in_crc": checksum(pix, smp)}
+
+
+def degenerate_cornell(W=64, H=64):
+    """Edge-case scene: the Cornell box with a floor triangle whose vertex normals are all zero (Ns = 0), a ceiling
+    triangle with one zero vertex normal, a zero-area (collinear) diffuse triangle and a ZERO-AREA LIGHT.  The light's
+    pdf 1/(n*0) is +inf, the power heuristic becomes inf/inf, and about one sample in six comes out NaN -- which
+    sub_render_pt drops while still dividing by SPP (PathTracing.hpp:510-513)."""
+    from tuturenderer_amd import scenes
+
+    sc = scenes.cornell_box(W, H)
+    v, n, m = sc["verts"].copy(), sc["normals"].copy(), sc["mat_id"].copy()
+    n[0] = 0
+    n[3, :3] = 0
+    extra_v = np.array([[100, 100, 100, 200, 200, 200, 300, 300, 300], [260, 300, 200, 270, 300, 200, 280, 300, 200]], np.float32)
+    extra_n = np.array([[0, 1, 0] * 3, [0, -1, 0] * 3], np.float32)
+    sc["verts"] = np.concatenate([v, extra_v])
+    sc["normals"] = np.concatenate([n, extra_n])
+    sc["mat_id"] = np.concatenate([m, np.array([0, 1], np.int32)])
+    return sc

@@ -34,7 +34,7 @@ def test_struct_sizes(tr):
     assert tr.HIT_DTYPE.itemsize == 16
 
 
-SCENES = ["cornell", "cornell_ggxT_mirror", "cornell_ggxR_glass", "veach", "veach_slight"]
+SCENES = ["cornell", "cornell_ggxT_mirror", "cornell_ggxR_glass", "veach", "veach_slight", "cornell_degenerate"]
 
 
 @pytest.mark.parametrize("name", SCENES)

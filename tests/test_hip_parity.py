@@ -19,7 +19,7 @@ from oracle import parity_cases as pc
 
 pytestmark = pytest.mark.gpu
 
-SCENES = ["cornell", "cornell_ggxT_mirror", "cornell_ggxR_glass", "veach", "veach_slight"]
+SCENES = ["cornell", "cornell_ggxT_mirror", "cornell_ggxR_glass", "veach", "veach_slight", "cornell_degenerate"]
 
 
 @pytest.fixture(scope="module")
@@ -155,18 +155,23 @@ def test_per_sample_radiance_matched_seed(tr, port, name):
     with tr.Context(sc) as ctx:
         L = ctx.trace_samples(pix, smp, pc.KEY0, key1)
     want = z["samples.L"]  # produced by the reference's own traceRay on the same Philox stream
-    assert not np.isnan(L).any() or np.isnan(want).any()
-    err = np.abs(L - want).max(1)
-    scale = np.maximum(np.abs(want).max(1), 1e-3)
+    # NaN samples (the zero-area light of the degenerate scene makes ~1 in 6) must be NaN on both sides
+    nan_g, nan_w = np.isnan(L).any(1), np.isnan(want).any(1)
+    assert (nan_g != nan_w).mean() < 1e-3, (int(nan_g.sum()), int(nan_w.sum()))
+    if name == "cornell_degenerate":
+        assert nan_w.mean() > 0.05
+    fin = ~(nan_g | nan_w)
+    err = np.abs(L[fin] - want[fin]).max(1)
+    scale = np.maximum(np.abs(want[fin]).max(1), 1e-3)
     ok = err <= 1e-4 * scale + 1e-6
     frac_bad = 1.0 - ok.mean()
-    print(f"{name}: diverged samples {int((~ok).sum())}/{len(ok)} max rel err of the rest {float((err[ok] / scale[ok]).max()):.2e}")
+    print(f"{name}: NaN samples {int(nan_w.sum())}; diverged {int((~ok).sum())}/{len(ok)} max rel err of the rest {float((err[ok] / scale[ok]).max()):.2e}")
     assert frac_bad < 5e-3, frac_bad
-    assert abs(L.mean() - want.mean()) < 2e-2 * max(want.mean(), 1e-3)
+    assert abs(L[fin].mean() - want[fin].mean()) < 2e-2 * max(want[fin].mean(), 1e-3)
     S.close()
 
 
-@pytest.mark.parametrize("name", ["cornell", "cornell_ggxR_glass", "veach_slight"])
+@pytest.mark.parametrize("name", ["cornell", "cornell_ggxR_glass", "veach_slight", "cornell_degenerate"])
 def test_image_matched_seed_l2(tr, name):
     sc, key1 = _scene(name)
     z = np.load(golden_path(f"scene_{name}.npz"))
