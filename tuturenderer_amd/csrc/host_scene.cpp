@@ -183,13 +183,27 @@ int build_host_scene(const TutuSceneDesc* d, HostScene& hs) {
 	hs.leaf_of_orig.assign(n, -1);
 	std::vector<int32_t> inner_id(tree.size(), -1);
 	{
-		int32_t next_inner = 0;
+		// leaves: pre-order walk = left-to-right order
 		for (size_t i = 0; i < tree.size(); i++) {
-			if (tree[i].left >= 0 || tree[i].right >= 0) inner_id[i] = next_inner++;  // pre-order numbering
-			else if (tree[i].tri >= 0) {
+			if (!(tree[i].left >= 0 || tree[i].right >= 0) && tree[i].tri >= 0) {
 				hs.leaf_of_orig[tree[i].tri] = (int32_t)order.size();
 				order.push_back(tree[i].tri);
 			}
+		}
+		// inner nodes: breadth-first numbering, so that the first K ids are the top of the tree -- the part every
+		// ray walks, which the traversal kernels keep in LDS when the whole tree does not fit
+		int32_t next_inner = 0;
+		std::vector<int32_t> level;
+		if (!tree.empty() && (tree[0].left >= 0 || tree[0].right >= 0)) level.push_back(0);
+		while (!level.empty()) {
+			std::vector<int32_t> next_level;
+			for (int32_t bn : level) {
+				inner_id[bn] = next_inner++;
+				const int32_t ch[2] = {tree[bn].left, tree[bn].right};
+				for (int k = 0; k < 2; k++)
+					if (ch[k] >= 0 && (tree[ch[k]].left >= 0 || tree[ch[k]].right >= 0)) next_level.push_back(ch[k]);
+			}
+			level.swap(next_level);
 		}
 		hs.nodes.assign((size_t)next_inner, GpuNode{});
 	}
