@@ -39,6 +39,7 @@ def golden_scenes():
         "veach": (lambda: scenes.veach_room(96, 72, small_light=False), 5),
         "veach_slight": (lambda: scenes.veach_room(96, 72, small_light=True), 6),
         "cornell_degenerate": (lambda: pc.degenerate_cornell(64, 64), 9),
+        "cornell_textured": (lambda: scenes.cornell_textured(96, 96), 11),
     }
 
 
@@ -77,6 +78,8 @@ def main():
     fn["philox.key"] = np.array([[0, 0], [0xFFFFFFFF, 0xFFFFFFFF], [0xA4093822, 0x299F31D0]], np.uint32)
     fn["philox.out"] = np.stack([R.philox(fn["philox.ctr"][i:i + 1], *[int(x) for x in fn["philox.key"][i]])[0] for i in range(3)])
     fn["philox.stream"] = R.rng_stream(12345, 7, pc.KEY0, 2, 64)
+    for k, v in pc.run_texture(R, scenes.procedural_maps()["diffuse"][0]).items():
+        fn[f"texture.{k}"] = v
     np.savez_compressed(os.path.join(GOLD, "functions.npz"), **fn)
 
     # ---- scene-level vectors + per-sample radiance

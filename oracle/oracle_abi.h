@@ -32,6 +32,11 @@ typedef struct TorMaterial {
 	float metallic;
 } TorMaterial;
 
+typedef struct TorTexture {
+	int32_t width, height;
+	const float* rgb; /* width*height*3, row-major (Texture::rgb) */
+} TorTexture;
+
 typedef struct TorSceneDesc {
 	int32_t n_tris;
 	const float* verts;    /* n_tris*9 : v0 v1 v2 */
@@ -44,6 +49,13 @@ typedef struct TorSceneDesc {
 	int32_t width, height;
 	float eye[3], viewdir[3], updir[3];
 	int32_t hfov; /* integer degrees, like the config keyword */
+	/* optional textures: NULL / 0 = none.  Four map lists like PPMGenerator's diffuseMaps,
+	 * normalMaps, roughnessMaps, metallicMaps; normal-map texels already mapped to [-1,1] (c*2-1), as the `bump`
+	 * keyword does at load time (PPMGenerator.hpp:713-722). */
+	const float* uvs;       /* n_tris*6: uv0 uv1 uv2 */
+	const int32_t* tex_ids; /* n_tris*4: diffuse, normal, roughness, metallic map index, -1 = none */
+	int32_t n_textures[4];
+	const struct TorTexture* textures[4];
 } TorSceneDesc;
 
 const char* tor_kind(void); /* "port" or "reference" */
@@ -69,6 +81,8 @@ int tor_math_G(int n, const float* wi, const float* wo, const float* nrm, const 
 int tor_math_mis(int n, const float* a, const float* b, float* out);
 int tor_math_local2world(int n, const float* N, const float* dir, float* out);
 int tor_write_pixel(int n, const float* c, int32_t* out);
+/* Texture::getRGBat (Texture.hpp:18-39) on one texture */
+int tor_texture_lookup(const struct TorTexture* t, int n, const float* u, const float* v, float* rgb);
 
 /* ---- material (one material, n evaluations) ---- */
 int tor_mat_bxdf(int n, const TorMaterial* m, const float* wi, const float* wo, const float* Ng, const float* Ns,

@@ -293,3 +293,21 @@ def degenerate_cornell(W=64, H=64):
     sc["normals"] = np.concatenate([n, extra_n])
     sc["mat_id"] = np.concatenate([m, np.array([0, 1], np.int32)])
     return sc
+
+
+def texture_inputs(n=4000, seed=31):
+    """(u, v) for Texture::getRGBat: a spread over [-3,3] plus the exact integers and the wrap edge cases."""
+    r = np.random.default_rng(seed)
+    u = (r.random(n, dtype=np.float32) * 6 - 3).astype(np.float32)
+    v = (r.random(n, dtype=np.float32) * 6 - 3).astype(np.float32)
+    edge = np.array([0.0, 1.0, -1.0, 2.0, -2.0, 0.5, -0.5, 0.99999994, -0.99999994, 1e-8, -1e-8, 3.0], np.float32)
+    u[:len(edge)] = edge
+    v[:len(edge)] = edge[::-1]
+    u[len(edge):2 * len(edge)] = edge
+    v[len(edge):2 * len(edge)] = 0.25
+    return u, v
+
+
+def run_texture(O, img):
+    u, v = texture_inputs()
+    return {"in_crc": checksum(u, v, np.ascontiguousarray(img, np.float32)), "rgb": O.texture_lookup(img, u, v)}

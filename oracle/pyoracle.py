@@ -64,7 +64,44 @@ class _SceneDesc(C.Structure):
         ("viewdir", C.c_float * 3),
         ("updir", C.c_float * 3),
         ("hfov", C.c_int32),
+        ("uvs", C.c_void_p),
+        ("tex_ids", C.c_void_p),
+        ("n_textures", C.c_int32 * 4),
+        ("textures", C.c_void_p * 4),
     ]
+
+
+class _Texture(C.Structure):
+    _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("rgb", C.c_void_p)]
+
+
+TEXTURE_LISTS = ("diffuse", "normal", "roughness", "metallic")
+
+
+def pack_textures(scene, desc, texture_struct):
+    """scene["textures"] = {"diffuse": [HxWx3 float32, ...], "normal": [...], "roughness": [...], "metallic": [...]},
+    scene["uvs"] (n,6), scene["tex_ids"] (n,4) -> fills the optional texture fields of a scene descriptor; returns
+    the objects that must stay alive."""
+    keep = []
+    if scene.get("uvs") is None or scene.get("tex_ids") is None:
+        return keep
+    uvs = np.ascontiguousarray(scene["uvs"], dtype=np.float32).reshape(-1, 6)
+    ids = np.ascontiguousarray(scene["tex_ids"], dtype=np.int32).reshape(-1, 4)
+    desc.uvs, desc.tex_ids = uvs.ctypes.data, ids.ctypes.data
+    keep += [uvs, ids]
+    texs = scene.get("textures", {})
+    for k, name in enumerate(TEXTURE_LISTS):
+        lst = texs.get(name, [])
+        arr = (texture_struct * max(1, len(lst)))()
+        for i, img in enumerate(lst):
+            a = np.ascontiguousarray(img, dtype=np.float32)
+            arr[i].height, arr[i].width = a.shape[0], a.shape[1]
+            arr[i].rgb = a.ctypes.data
+            keep.append(a)
+        desc.n_textures[k] = len(lst)
+        desc.textures[k] = C.cast(arr, C.c_void_p).value
+        keep.append(arr)
+    return keep
 
 
 def _f32(a):
@@ -160,6 +197,15 @@ class Oracle:
     def local2world(self, N, d):
         return self._vec1(self.lib.tor_math_local2world, N, d)
 
+    def texture_lookup(self, img, u, v):
+        img = np.ascontiguousarray(img, dtype=np.float32)
+        t = _Texture()
+        t.height, t.width, t.rgb = img.shape[0], img.shape[1], img.ctypes.data
+        u, v = _f32(u), _f32(v)
+        out = np.empty((len(u), 3), np.float32)
+        self.lib.tor_texture_lookup(C.byref(t), C.c_int(len(u)), _p(u), _p(v), _p(out))
+        return out
+
     def write_pixel(self, c):
         c = _f32(c).ravel()
         out = np.empty(len(c), np.int32)
@@ -243,6 +289,7 @@ class OracleScene:
         d.viewdir = (C.c_float * 3)(*[float(x) for x in scene["viewdir"]])
         d.updir = (C.c_float * 3)(*[float(x) for x in scene["updir"]])
         d.hfov = int(scene["hfov"])
+        self._tex_keep = pack_textures(scene, d, _Texture)
         self.h = C.c_void_p()
         rc = self.lib.tor_scene_create(C.byref(d), C.byref(self.h))
         if rc != 0:

@@ -100,6 +100,16 @@ public:
 	}
 };
 
+static Texture* make_texture(const TorTexture* t, int list, int index) {
+	Texture* tex = new Texture;  // owned by the PPMGenerator (deleteMaps, PPMGenerator.hpp:110-136)
+	tex->name = "tex" + std::to_string(list) + "_" + std::to_string(index);
+	tex->width = t->width;
+	tex->height = t->height;
+	tex->rgb.resize((size_t)t->width * t->height);
+	for (size_t i = 0; i < tex->rgb.size(); i++) tex->rgb[i] = V(t->rgb + 3 * i);
+	return tex;
+}
+
 struct RefScene {
 	PPMGenerator* g = nullptr;
 	PathTracing* pt = nullptr;
@@ -328,12 +338,30 @@ int tor_scene_create(const TorSceneDesc* d, void** out) {
 	s->g = make_generator(d);
 	if (!s->g) { delete s; return -2; }
 	PPMGenerator* g = s->g;
+	{
+		std::vector<Texture*>* lists[4] = {&g->diffuseMaps, &g->normalMaps, &g->roughnessMaps, &g->metallicMaps};
+		for (int k = 0; k < 4; k++)
+			for (int i = 0; i < d->n_textures[k]; i++) lists[k]->push_back(make_texture(&d->textures[k][i], k, i));
+	}
 	for (int i = 0; i < d->n_tris; i++) {
 		// as PPMGenerator::loadObj does per triangle (PPMGenerator.hpp:170-203)
 		std::unique_ptr<Triangle> t = std::make_unique<Triangle>();
 		fill_triangle(*t, d->verts + 9 * i, d->normals + 9 * i);
 		Material mat = to_material(&d->mats[d->mat_id[i]]);
 		t->mtlcolor = mat;
+		if (d->uvs) {
+			t->uv0 = Vector2f(d->uvs[6 * i + 0], d->uvs[6 * i + 1]);
+			t->uv1 = Vector2f(d->uvs[6 * i + 2], d->uvs[6 * i + 3]);
+			t->uv2 = Vector2f(d->uvs[6 * i + 4], d->uvs[6 * i + 5]);
+		}
+		if (d->tex_ids) {  // as PPMGenerator::loadObj sets them (PPMGenerator.hpp:195-201)
+			t->textureIndex = d->tex_ids[4 * i + 0];
+			t->normalMapIndex = d->tex_ids[4 * i + 1];
+			t->roughnessMapIndex = d->tex_ids[4 * i + 2];
+			t->metallicMapIndex = d->tex_ids[4 * i + 3];
+			if (t->textureIndex != -1 || t->normalMapIndex != -1 || t->metallicMapIndex != -1 || t->roughnessMapIndex != -1)
+				t->isTextureActivated = true;
+		}
 		t->initializeBound();
 		s->index[t.get()] = i;
 		g->scene.add(std::move(t));
@@ -499,6 +527,13 @@ int tor_render(void* h, int spp, uint32_t key0, uint32_t key1, int x0, int y0, i
 	std::vector<std::thread> th;
 	for (int t = 0; t < nthreads; t++) th.emplace_back(worker, t);
 	for (auto& t : th) t.join();
+	return 0;
+}
+
+int tor_texture_lookup(const struct TorTexture* t, int n, const float* u, const float* v, float* rgb) {
+	Texture* tex = make_texture(t, 9, 0);
+	for (int i = 0; i < n; i++) S(rgb + 3 * i, tex->getRGBat(u[i], v[i]));
+	delete tex;
 	return 0;
 }
 

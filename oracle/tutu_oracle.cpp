@@ -504,12 +504,17 @@ struct Tri {
 	V3 v0, v1, v2, n0, n1, n2;
 	int mat = 0;
 	Box bound;
+	// textures
+	float uv0[2] = {-1.f, -1.f}, uv1[2] = {-1.f, -1.f}, uv2[2] = {-1.f, -1.f};  // Vector2f() = (-1,-1), Vector.hpp:54-57
+	int tex[4] = {-1, -1, -1, -1};  // textureIndex, normalMapIndex, roughnessMapIndex, metallicMapIndex (Object.hpp:31-35)
+	bool isTextureActivated = false;
 };
 struct Hit { // Intersection.hpp:13-31 (the fields the path needs)
 	bool intersected = false;
 	float t = FLT_MAX;
 	V3 pos, Ng, Ns;
 	int tri = -1;
+	float textPos[2] = {-1.f, -1.f};  // Intersection::textPos, set when the triangle has a texture (Triangle.hpp:61-68)
 };
 
 // Triangle.hpp:23-74
@@ -533,6 +538,11 @@ static inline bool tri_intersect(const Tri& tr, int tri_index, const V3& orig, c
 		inter.pos = orig + inter.t * dir;
 		inter.Ns = normalized((tr.n0 * (1 - res.y - res.z)) + tr.n1 * res.y + tr.n2 * res.z);
 		inter.Ng = normal;
+		if (tr.isTextureActivated) {  // Triangle.hpp:61-68; Vector2f::operator*(float) and operator+ (Vector.hpp:59-66)
+			const float w0 = (1 - res.y - res.z);
+			inter.textPos[0] = (tr.uv0[0] * w0 + tr.uv1[0] * res.y) + tr.uv2[0] * res.z;
+			inter.textPos[1] = (tr.uv0[1] * w0 + tr.uv1[1] * res.y) + tr.uv2[1] * res.z;
+		}
 		return true;
 	}
 	return false;
@@ -554,7 +564,57 @@ struct Counters {
 	int64_t nodes_shadow = 0, tris_shadow = 0;  // the share of nodes/tris spent on shadow rays
 };
 
+struct Texture {  // Texture.hpp:10-39
+	int width = 0, height = 0;
+	std::vector<V3> rgb;
+	V3 getRGBat(float u, float v) const {
+		if (width == 0 && height == 0) return V3();
+		if (u > 0) u = u - (int)u;
+		else u = 1 - (fabsf(u) - (int)fabsf(u));
+		if (v > 0) v = v - (int)v;
+		else v = 1 - (fabsf(v) - (int)fabsf(v));
+		int x = u * width;
+		int y = v * height;
+		int index = y * width + x;
+		if (index < 0) index = 0;
+		if (index >= (int)rgb.size()) index = (int)rgb.size() - 1;
+		return rgb[(size_t)index];
+	}
+};
+
 struct Scene {
+	std::vector<Texture> maps[4];  // diffuseMaps, normalMaps, roughnessMaps, metallicMaps (PPMGenerator.hpp:36-39)
+
+	// changeNormalDir, IIntegrator.hpp:27-63 (triangle case)
+	void changeNormalDir(Hit& inter, const Tri& t) const {
+		const V3 color = maps[1][(size_t)t.tex[1]].getRGBat(inter.textPos[0], inter.textPos[1]);
+		V3 e1 = t.v1 - t.v0;
+		V3 e2 = t.v2 - t.v0;
+		V3 nDir = normalized(inter.Ns);
+		float deltaU1 = t.uv1[0] - t.uv0[0];
+		float deltaV1 = t.uv1[1] - t.uv0[1];
+		float deltaU2 = t.uv2[0] - t.uv0[0];
+		float deltaV2 = t.uv2[1] - t.uv0[1];
+		float coef = 1 / (-deltaU1 * deltaV2 + deltaV1 * deltaU2);
+		V3 T = coef * (-deltaV2 * e1 + deltaV1 * e2);
+		V3 B = coef * (-deltaU2 * e1 + deltaU1 * e2);
+		T = normalized(T);
+		B = normalized(B);
+		V3 res;
+		res.x = T.x * color.x + B.x * color.y + nDir.x * color.z;
+		res.y = T.y * color.x + B.y * color.y + nDir.y * color.z;
+		res.z = T.z * color.x + B.z * color.y + nDir.z * color.z;
+		inter.Ns = normalized(res);
+	}
+	// textureModify, IIntegrator.hpp:89-127
+	void textureModify(Hit& inter, Material& m) const {
+		const Tri& t = tris[inter.tri];
+		if (t.tex[0] != -1) m.diffuse = maps[0][(size_t)t.tex[0]].getRGBat(inter.textPos[0], inter.textPos[1]);
+		if (t.tex[1] != -1) changeNormalDir(inter, t);
+		if (t.tex[2] != -1) m.roughness = maps[2][(size_t)t.tex[2]].getRGBat(inter.textPos[0], inter.textPos[1]).x;
+		if (t.tex[3] != -1) m.metallic = maps[3][(size_t)t.tex[3]].getRGBat(inter.textPos[0], inter.textPos[1]).x;
+	}
+
 	std::vector<Tri> tris;
 	std::vector<Material> mats;
 	std::vector<Node> nodes; // nodes[0] = root
@@ -903,6 +963,7 @@ struct Scene {
 				inter = closest(origin, dir, c);
 				continue;
 			}
+			if (tris[inter.tri].isTextureActivated) textureModify(inter, m); // :157-158
 			if (m.mType == UNLIT) { tail = m.diffuse; Lf = Lf + beta * m.diffuse; break; } // :161
 			if (m.hasEmission() && depth > 0) { tail = V3(0.f); break; }                   // :164-165
 			if (m.hasEmission()) { tail = m.emission; Lf = Lf + beta * m.emission; break; } // :169-170
@@ -1096,6 +1157,16 @@ int tor_math_local2world(int n, const float* N, const float* dir, float* out) {
 	for (int i = 0; i < n; i++) ST(out + 3 * i, SphereLocal2world(L(N + 3 * i), L(dir + 3 * i)));
 	return 0;
 }
+int tor_texture_lookup(const struct TorTexture* t, int n, const float* u, const float* v, float* rgb) {
+	Texture tx;
+	tx.width = t->width;
+	tx.height = t->height;
+	tx.rgb.resize((size_t)t->width * t->height);
+	for (size_t j = 0; j < tx.rgb.size(); j++) tx.rgb[j] = L(t->rgb + 3 * j);
+	for (int i = 0; i < n; i++) ST(rgb + 3 * i, tx.getRGBat(u[i], v[i]));
+	return 0;
+}
+
 // PPMGenerator.hpp:825-843: 255 * pow(clamp(0,1,c), 0.78f) -> (int)
 int tor_write_pixel(int n, const float* c, int32_t* out) {
 	for (int i = 0; i < n; i++) {
@@ -1138,10 +1209,28 @@ int tor_scene_create(const TorSceneDesc* d, void** out) {
 	for (int i = 0; i < d->n_tris; i++) {
 		Tri t = make_tri(d->verts + 9 * i, d->normals + 9 * i);
 		t.mat = d->mat_id[i];
+		if (d->uvs) {
+			t.uv0[0] = d->uvs[6 * i + 0]; t.uv0[1] = d->uvs[6 * i + 1];
+			t.uv1[0] = d->uvs[6 * i + 2]; t.uv1[1] = d->uvs[6 * i + 3];
+			t.uv2[0] = d->uvs[6 * i + 4]; t.uv2[1] = d->uvs[6 * i + 5];
+		}
+		if (d->tex_ids) {  // PPMGenerator::loadObj, PPMGenerator.hpp:195-201
+			for (int k = 0; k < 4; k++) t.tex[k] = d->tex_ids[4 * i + k];
+			t.isTextureActivated = t.tex[0] != -1 || t.tex[1] != -1 || t.tex[2] != -1 || t.tex[3] != -1;
+		}
 		t.bound = box_union_pt(box_of_points(t.v0, t.v1), t.v2); // Triangle.hpp:104-107
 		s->tris[i] = t;
 	}
 	for (int i = 0; i < d->n_mats; i++) s->mats.push_back(from_abi(&d->mats[i]));
+	for (int k = 0; k < 4; k++)
+		for (int i = 0; i < d->n_textures[k]; i++) {
+			Texture tx;
+			tx.width = d->textures[k][i].width;
+			tx.height = d->textures[k][i].height;
+			tx.rgb.resize((size_t)tx.width * tx.height);
+			for (size_t j = 0; j < tx.rgb.size(); j++) tx.rgb[j] = L(d->textures[k][i].rgb + 3 * j);
+			s->maps[k].push_back(tx);
+		}
 	s->eta = d->eta;
 	s->bkg = L(d->bkg);
 	s->W = d->width; s->H = d->height; s->hfov = d->hfov;

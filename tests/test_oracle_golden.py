@@ -49,6 +49,13 @@ def test_math(port, fn_golden):
     assert_dict_bit_equal(pc.run_math(port), _sub(fn_golden, "math."), "math.")
 
 
+def test_texture_lookup(port, fn_golden):
+    """Texture::getRGBat (Texture.hpp:18-39): wrap of negative / >1 coordinates, truncation, index clamp"""
+    from tuturenderer_amd import scenes
+
+    assert_dict_bit_equal(pc.run_texture(port, scenes.procedural_maps()["diffuse"][0]), _sub(fn_golden, "texture."), "texture.")
+
+
 @pytest.mark.parametrize("name", [n for n, _ in pc.material_set()])
 def test_material(port, fn_golden, name):
     mat = dict(pc.material_set())[name]
@@ -72,7 +79,7 @@ def test_cornell_restated_matches_reference_obj_load():
     assert off == 32
 
 
-SCENES = ["cornell", "cornell_ggxT_mirror", "cornell_ggxR_glass", "veach", "veach_slight", "cornell_degenerate"]
+SCENES = ["cornell", "cornell_ggxT_mirror", "cornell_ggxR_glass", "veach", "veach_slight", "cornell_degenerate", "cornell_textured"]
 
 
 def _check_samples(got, want, name):

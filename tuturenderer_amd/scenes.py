@@ -295,9 +295,86 @@ def broom_room(width=1600, height=900, n_bristles=4000, seed=70002):
     return _camera(s, width, height, eye=(W / 2, 273, -800 * sx * 0.62), viewdir=(0, 0, 1), hfov=50)
 
 
+# ---- textures on triangles ------------------------------------------------------------------------
+# A scene may carry, next to verts/normals/mat_id:
+#   uvs      (n_tris, 6)  uv0 uv1 uv2 per triangle (the `vt` of the OBJ face corners)
+#   tex_ids  (n_tris, 4)  index into the diffuse / normal / roughness / metallic map lists, -1 = none
+#   textures {"diffuse": [HxWx3 f32, ...], "normal": [...], "roughness": [...], "metallic": [...]}
+# Normal-map texels are stored already mapped to [-1,1] (the `bump` keyword does c*2-1 at load time,
+# PPMGenerator.hpp:713-722); all other maps hold c/255 like loadTexture (PPMGenerator.hpp:1027-1084).
+TEXTURE_LISTS = ("diffuse", "normal", "roughness", "metallic")
+
+
+def _planar_uvs(verts, scale, offset=(0.0, 0.0)):
+    """uv per corner from the two coordinates in which the triangle's plane is largest; deliberately reaches
+    negative and >1 values so the wrap rule of Texture::getRGBat (Texture.hpp:18-39) is exercised."""
+    v = np.asarray(verts, np.float32).reshape(-1, 3, 3)
+    n = np.abs(np.cross(v[:, 1] - v[:, 0], v[:, 2] - v[:, 0]))
+    drop = np.argmax(n, axis=1)
+    keep = np.array([[1, 2], [0, 2], [0, 1]])[drop]
+    uv = np.take_along_axis(v, keep[:, None, :].repeat(3, axis=1), axis=2)
+    uv = uv * np.float32(scale) + np.asarray(offset, np.float32)
+    return uv.reshape(-1, 6).astype(np.float32)
+
+
+def procedural_maps(seed=70003):
+    """Four small seeded maps (non-square on purpose): checker+noise albedo, a bumpy tangent-space normal map,
+    a roughness map and a metallic map."""
+    rng = np.random.Generator(np.random.Philox(key=seed))
+    h, w = 48, 64
+    yy, xx = np.mgrid[0:h, 0:w]
+    check = (((xx // 8) + (yy // 8)) & 1).astype(np.float32)
+    albedo = np.stack([0.25 + 0.6 * check, 0.3 + 0.4 * (1 - check), 0.2 + 0.5 * (xx / w)], -1).astype(np.float32)
+    albedo = np.round((albedo + 0.1 * rng.random((h, w, 3), dtype=np.float32)).clip(0, 1) * 255) / np.float32(255)
+    hn, wn = 40, 56
+    nx = rng.random((hn, wn), dtype=np.float32) - 0.5
+    ny = rng.random((hn, wn), dtype=np.float32) - 0.5
+    c = np.round(np.stack([0.5 + 0.35 * nx, 0.5 + 0.35 * ny, np.full((hn, wn), 0.92, np.float32)], -1) * 255) / np.float32(255)
+    normal = (c * np.float32(2) - np.float32(1)).astype(np.float32)
+    rough = np.round((0.08 + 0.8 * rng.random((32, 24, 1), dtype=np.float32)) * 255) / np.float32(255)
+    metal = np.round(rng.random((16, 20, 1), dtype=np.float32) * 255) / np.float32(255)
+    return {
+        "diffuse": [albedo.astype(np.float32), np.ascontiguousarray(albedo[::-1, :, ::-1]).astype(np.float32)],
+        "normal": [normal],
+        "roughness": [np.repeat(rough, 3, axis=2).astype(np.float32)],
+        "metallic": [np.repeat(metal, 3, axis=2).astype(np.float32)],
+    }
+
+
+def cornell_textured(width=800, height=800):
+    """The Cornell box with maps on it: albedo + normal map on the floor/ceiling/back wall, a second albedo on the
+    short box, and a GGX-R tall box driven by roughness + metallic + normal maps.  Left/right walls and the light stay
+    untextured, so both kinds of triangle are in one BVH."""
+    mats = [
+        material(LAMBERTIAN, CB_WHITE),
+        material(LAMBERTIAN, CB_WHITE, emission=CB_EMISSION),
+        material(LAMBERTIAN, CB_GREEN),
+        material(LAMBERTIAN, CB_RED),
+        material(MICROFACET_R, CB_WHITE, roughness=0.4, metallic=0.3),
+    ]
+    part_mat = {"floor": 0, "light": 1, "right": 2, "left": 3, "tallbox": 4, "shortbox": 0}
+    part_tex = {"floor": (0, 0, -1, -1), "shortbox": (1, -1, -1, -1), "tallbox": (-1, 0, 0, 0)}
+    parts, uvs, ids = [], [], []
+    for name, v in cornell_parts():
+        parts.append((v, face_normals(v), part_mat[name]))
+        t = part_tex.get(name)
+        if t is None:
+            uvs.append(np.full((len(v), 6), -1.0, np.float32))  # Vector2f() default, Vector.hpp:54-57
+            ids.append(np.full((len(v), 4), -1, np.int32))
+        else:
+            uvs.append(_planar_uvs(v, 1.0 / 170.0, (-0.8, 0.3)))
+            ids.append(np.tile(np.array(t, np.int32), (len(v), 1)))
+    s = _assemble(parts, mats)
+    s["uvs"] = np.concatenate(uvs).astype(np.float32)
+    s["tex_ids"] = np.concatenate(ids).astype(np.int32)
+    s["textures"] = procedural_maps()
+    return _camera(s, width, height, eye=(278, 273, -800), viewdir=(0, 0, 1))
+
+
 SCENES = {
     "cornell": cornell_box,
     "veach": veach_room,
     "bunny": bunny_box,
     "broom": broom_room,
+    "cornell_textured": cornell_textured,
 }
