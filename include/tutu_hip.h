@@ -62,6 +62,24 @@ typedef struct TutuMaterial {
  * load order (PPMGenerator::loadObj, PPMGenerator.hpp:164-208), each triangle's Material, the scene IOR g->eta and
  * g->bkgcolor.  Lights are not passed: like PPMGenerator::initializeLights (PPMGenerator.hpp:317-324) the library
  * takes every triangle whose material has a non-zero emission, in list order. */
+/* One image of PPMGenerator's diffuseMaps / normalMaps / roughnessMaps / metallicMaps (PPMGenerator.hpp:36-39), as
+ * loadTexture leaves it (Texture.hpp:10-16; PPMGenerator.hpp:1027-1084): width*height float RGB triples, row-major,
+ * channel/255.  Normal maps are passed AFTER the `bump` keyword's c*2-1 mapping (PPMGenerator.hpp:713-722). */
+typedef struct TutuTexture {
+	int32_t width, height;
+	const float* rgb; /* width*height*3 */
+} TutuTexture;
+
+/* Optional per-triangle texture data: what PPMGenerator::loadObj stores on each Triangle when a texture keyword is
+ * active (uv0..uv2, textureIndex, normalMapIndex, roughnessMapIndex, metallicMapIndex; PPMGenerator.hpp:182-201,
+ * Object.hpp:31-35).  A triangle is "texture activated" when any of its four indices is not -1. */
+typedef struct TutuTextureSet {
+	const float* uvs;       /* n_tris*6: uv0 uv1 uv2 */
+	const int32_t* tex_ids; /* n_tris*4: diffuse, normal, roughness, metallic map index; -1 = none */
+	uint32_t n_maps[4];     /* list sizes, in the same order */
+	const TutuTexture* maps[4];
+} TutuTextureSet;
+
 typedef struct TutuSceneDesc {
 	uint32_t n_tris;
 	const float* verts;    /* n_tris*9: v0 v1 v2 (Triangle.hpp:11-14) */
@@ -71,6 +89,7 @@ typedef struct TutuSceneDesc {
 	const TutuMaterial* mats;
 	float eta;    /* g->eta: 4th number of the `bkgcolor` keyword */
 	float bkg[3]; /* g->bkgcolor */
+	const TutuTextureSet* textures; /* NULL: no textured triangles (textureModify, IIntegrator.hpp:89-127, never runs) */
 } TutuSceneDesc;
 
 /* The camera keywords of config.txt (imsize / eye / viewdir / hfov / updir; PPMGenerator.hpp:492-540). */
@@ -195,6 +214,10 @@ int tutu_hip_eval_pdf(TutuCtx* ctx, uint32_t n, const TutuMaterial* m, const flo
                       const float* N, float eta_i, float eta_t, float* out);
 int tutu_hip_eval_sample(TutuCtx* ctx, uint32_t n, const TutuMaterial* m, const float* wo, const float* N,
                          float eta_i, const float* xi3, float* wi, uint8_t* ok, uint8_t* special, int32_t* ndraws);
+/* Texture::getRGBat (Texture.hpp:18-39) on map `index` of list `list` (0 diffuse, 1 normal, 2 roughness, 3 metallic)
+ * of the context's scene; TUTU_E_INVALID when the scene has no such map. */
+int tutu_hip_eval_texture(TutuCtx* ctx, int32_t list, int32_t index, uint32_t n, const float* u, const float* v,
+                          float* rgb);
 /* sampleLight (IIntegrator.hpp:173-192) + Triangle::samplePoint (Triangle.hpp:119-142) with supplied xi */
 int tutu_hip_eval_sample_light(TutuCtx* ctx, uint32_t n, const float* xi3, int32_t* tri, float* pos, float* nrm,
                                float* pdf);

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Throughput + matched-seed parity spot check on every BASELINE config scene (not the contract bench: see bench.py).
-   python profiles/bench_scenes.py [scene ...]   scenes: cornell veach bunny broom"""
+   python profiles/bench_scenes.py [scene ...]   scenes: cornell veach bunny broom cornell_textured"""
 import json
 import os
 import sys
@@ -20,6 +20,7 @@ CFG = {
     "veach_slight": (lambda: scenes.veach_room(800, 600, small_light=True), 6, 32),
     "bunny": (lambda: scenes.bunny_box(1024, 1024), 3, 16),
     "broom": (lambda: scenes.broom_room(1600, 900), 4, 4),
+    "cornell_textured": (lambda: scenes.cornell_textured(800, 800), 11, 64),
 }
 
 

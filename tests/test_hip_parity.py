@@ -19,7 +19,7 @@ from oracle import parity_cases as pc
 
 pytestmark = pytest.mark.gpu
 
-SCENES = ["cornell", "cornell_ggxT_mirror", "cornell_ggxR_glass", "veach", "veach_slight", "cornell_degenerate"]
+SCENES = ["cornell", "cornell_ggxT_mirror", "cornell_ggxR_glass", "veach", "veach_slight", "cornell_degenerate", "cornell_textured"]
 
 
 @pytest.fixture(scope="module")
@@ -146,6 +146,64 @@ def test_material_functions(tr, name):
         assert (~close).mean() < 2e-3, (k, int((~close).sum()), g[~close][:4], w[~close][:4])
 
 
+def test_texture_lookup_bit_exact(tr):
+    """Texture::getRGBat on the device against the reference build's answers (wrap, truncation, index clamp)"""
+    from tuturenderer_amd import scenes
+
+    z = np.load(golden_path("functions.npz"))
+    sc = scenes.cornell_textured(32, 32)
+    u, v = pc.texture_inputs()
+    with tr.Context(sc) as ctx:
+        got = ctx.eval_texture(0, 0, u, v)
+        assert bit_equal(got, z["texture.rgb"])
+        # every map of every list answers, and an index beyond a list is refused like the reference's exit(1)
+        for k, name in enumerate(("diffuse", "normal", "roughness", "metallic")):
+            for i, img in enumerate(sc["textures"][name]):
+                g = ctx.eval_texture(k, i, u[:64], v[:64])
+                assert np.isin(g.reshape(-1), np.asarray(img, np.float32).reshape(-1)).all()
+            with pytest.raises(tr.TutuError):
+                ctx.eval_texture(k, len(sc["textures"][name]), u[:4], v[:4])
+    bad = dict(sc)
+    bad["tex_ids"] = sc["tex_ids"].copy()
+    bad["tex_ids"][0, 0] = 7
+    with pytest.raises(tr.TutuError):
+        tr.Context(bad)
+
+
+def test_textured_edge_cases(tr, port):
+    """degenerate uvs under a normal map (coef = 1/0 -> NaN tangent frame -> NaN shading normal: every comparison on
+    it fails and the reference returns black there), default (-1,-1) uvs under an albedo map, an empty 0x0 map"""
+    from tuturenderer_amd import scenes
+
+    sc = scenes.cornell_textured(48, 48)
+    sc["uvs"] = sc["uvs"].copy()
+    sc["tex_ids"] = sc["tex_ids"].copy()
+    floor = np.nonzero(sc["tex_ids"][:, 1] == 0)[0]
+    sc["uvs"][floor[0]] = 0.25               # all three corners equal: degenerate tangent frame
+    sc["uvs"][floor[1]] = -1.0               # Vector2f() default
+    sc["textures"] = dict(sc["textures"])
+    sc["textures"]["diffuse"] = list(sc["textures"]["diffuse"]) + [np.zeros((0, 0, 3), np.float32)]
+    short = np.nonzero(sc["tex_ids"][:, 0] == 1)[0]
+    sc["tex_ids"][short[:4], 0] = 2          # the empty map: reads as black
+    S = port.scene(sc)
+    pix, smp = pc.sample_ids(S, n=6000)
+    want = S.trace_samples(pix, smp, pc.KEY0, 21)
+    with tr.Context(sc) as ctx:
+        L = ctx.trace_samples(pix, smp, pc.KEY0, 21)
+        img = ctx.render(8, pc.KEY0, 21)
+    ref = S.render(8, pc.KEY0, 21, nthreads=4)
+    S.close()
+    nan_g, nan_w = np.isnan(L).any(1), np.isnan(want).any(1)
+    assert (nan_g != nan_w).mean() < 1e-3
+    fin = ~(nan_g | nan_w)
+    err = np.abs(L[fin] - want[fin]).max(1)
+    scale = np.maximum(np.abs(want[fin]).max(1), 1e-3)
+    assert (err > 1e-4 * scale + 1e-6).mean() < 5e-3
+    assert (want == 0).all(1).mean() > 0.05  # the black triangle is in view
+    assert np.isfinite(img).all()
+    assert np.sqrt(((img - ref) ** 2).sum(-1)).mean() < 1e-3
+
+
 @pytest.mark.parametrize("name", SCENES)
 def test_per_sample_radiance_matched_seed(tr, port, name):
     sc, key1 = _scene(name)
@@ -171,7 +229,7 @@ def test_per_sample_radiance_matched_seed(tr, port, name):
     S.close()
 
 
-@pytest.mark.parametrize("name", ["cornell", "cornell_ggxR_glass", "veach_slight", "cornell_degenerate"])
+@pytest.mark.parametrize("name", ["cornell", "cornell_ggxR_glass", "veach_slight", "cornell_degenerate", "cornell_textured"])
 def test_image_matched_seed_l2(tr, name):
     sc, key1 = _scene(name)
     z = np.load(golden_path(f"scene_{name}.npz"))

@@ -19,7 +19,7 @@ ABI_SYMBOLS = [
     "tutu_camera_frame", "tutu_bvh_build_preorder", "tutu_hip_error_string", "tutu_hip_last_error", "tutu_hip_version",
     "tutu_hip_device_count", "tutu_hip_create", "tutu_hip_destroy", "tutu_hip_render", "tutu_hip_render_device",
     "tutu_hip_trace_closest", "tutu_hip_trace_any", "tutu_hip_trace_samples", "tutu_hip_eval_bxdf", "tutu_hip_eval_pdf",
-    "tutu_hip_eval_sample", "tutu_hip_eval_sample_light", "tutu_hip_scene_info",
+    "tutu_hip_eval_sample", "tutu_hip_eval_sample_light", "tutu_hip_scene_info", "tutu_hip_eval_texture",
 ]
 
 
@@ -29,7 +29,44 @@ class TutuError(RuntimeError):
 
 class SceneDesc(C.Structure):
     _fields_ = [("n_tris", C.c_uint32), ("verts", C.c_void_p), ("normals", C.c_void_p), ("mat_id", C.c_void_p),
-                ("n_mats", C.c_uint32), ("mats", C.c_void_p), ("eta", C.c_float), ("bkg", C.c_float * 3)]
+                ("n_mats", C.c_uint32), ("mats", C.c_void_p), ("eta", C.c_float), ("bkg", C.c_float * 3),
+                ("textures", C.c_void_p)]
+
+
+class Texture(C.Structure):
+    _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("rgb", C.c_void_p)]
+
+
+class TextureSet(C.Structure):
+    _fields_ = [("uvs", C.c_void_p), ("tex_ids", C.c_void_p), ("n_maps", C.c_uint32 * 4), ("maps", C.c_void_p * 4)]
+
+
+def pack_texture_set(scene):
+    """scene["uvs"] (n,6), scene["tex_ids"] (n,4), scene["textures"] {"diffuse": [HxWx3 f32,...], "normal": ..,
+    "roughness": .., "metallic": ..} -> (TutuTextureSet or None, objects to keep alive)"""
+    if scene.get("uvs") is None or scene.get("tex_ids") is None:
+        return None, []
+    uvs = np.ascontiguousarray(scene["uvs"], dtype=np.float32).reshape(-1, 6)
+    ids = np.ascontiguousarray(scene["tex_ids"], dtype=np.int32).reshape(-1, 4)
+    n = len(np.asarray(scene["verts"]).reshape(-1, 9))
+    if len(uvs) != n or len(ids) != n:
+        raise ValueError("uvs / tex_ids must have one row per triangle")
+    ts = TextureSet()
+    ts.uvs, ts.tex_ids = uvs.ctypes.data, ids.ctypes.data
+    keep = [uvs, ids]
+    for k, name in enumerate(("diffuse", "normal", "roughness", "metallic")):
+        lst = scene.get("textures", {}).get(name, [])
+        arr = (Texture * max(1, len(lst)))()
+        for i, img in enumerate(lst):
+            a = np.ascontiguousarray(img, dtype=np.float32)
+            if a.ndim != 3 or a.shape[2] != 3:
+                raise ValueError("a texture is an H x W x 3 float array")
+            arr[i].height, arr[i].width, arr[i].rgb = a.shape[0], a.shape[1], a.ctypes.data
+            keep.append(a)
+        ts.n_maps[k] = len(lst)
+        ts.maps[k] = C.cast(arr, C.c_void_p).value
+        keep.append(arr)
+    return ts, keep
 
 
 class CameraDesc(C.Structure):
@@ -162,6 +199,8 @@ class Context:
         d.mats = self._mats.ctypes.data
         d.eta = float(scene.get("eta", 1.0))
         d.bkg = (C.c_float * 3)(*[float(x) for x in scene.get("bkg", (0, 0, 0))])
+        self._texture_set, self._texture_keep = pack_texture_set(scene)
+        d.textures = C.addressof(self._texture_set) if self._texture_set is not None else None
         self.h = C.c_void_p()
         _check(self.lib.tutu_hip_create(C.byref(d), C.c_int(device), C.byref(self.h)), "tutu_hip_create")
         self.cam = camera_frame(scene)
@@ -275,6 +314,13 @@ class Context:
         out = np.zeros(len(wi), np.float32)
         _check(self.lib.tutu_hip_eval_pdf(self.h, C.c_uint32(len(wi)), _p(m), _p(wi), _p(wo), _p(N), C.c_float(eta_i), C.c_float(eta_t),
                                           _p(out)), "tutu_hip_eval_pdf")
+        return out
+
+    def eval_texture(self, list_index, index, u, v):
+        u, v = _f32(u), _f32(v)
+        out = np.zeros((len(u), 3), np.float32)
+        _check(self.lib.tutu_hip_eval_texture(self.h, C.c_int32(list_index), C.c_int32(index), C.c_uint32(len(u)), _p(u), _p(v), _p(out)),
+               "tutu_hip_eval_texture")
         return out
 
     def eval_sample(self, mat, wo, N, xi3, eta_i=1.0):

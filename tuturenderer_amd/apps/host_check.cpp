@@ -3,7 +3,9 @@
 // tests can compare it with the golden dumps of the reference's own loader.
 //   host_check <config.txt> <out.bin> [obj ...]
 // out.bin: int32 width,height,hfov,integrateType,n_tris ; float eye[3],viewdir[3],updir[3],bkg[3],eta ;
-//          n_tris*9 float verts ; n_tris*9 float normals ; 256 x int32 quantise() of a 0..1 ramp
+//          n_tris*9 float verts ; n_tris*9 float normals ; 256 x int32 quantise() of a 0..1 ramp ;
+//          per triangle: 6 float uv, int32 textureIndex, normalMapIndex, roughnessMapIndex, metallicMapIndex, activated ;
+//          for each of the 4 map lists: int32 count, then per map int32 width, height + width*height*3 float
 #include <cstdio>
 
 #include "../host/tutu_renderer.hpp"
@@ -32,6 +34,23 @@ int main(int argc, char* argv[]) {
 	for (int i = 0; i < 256; i++) {
 		const int32_t q = (int32_t)PPMGenerator::quantise(-0.1f + 1.3f * (float)i / 255.f);
 		fwrite(&q, sizeof(q), 1, f);
+	}
+	for (auto& o : g.scene.objList) {
+		const Triangle* t = static_cast<const Triangle*>(o.get());
+		const float uv[6] = {t->uv0.x, t->uv0.y, t->uv1.x, t->uv1.y, t->uv2.x, t->uv2.y};
+		fwrite(uv, sizeof(uv), 1, f);
+		const int32_t ids[5] = {t->textureIndex, t->normalMapIndex, t->roughnessMapIndex, t->metallicMapIndex, t->isTextureActivated ? 1 : 0};
+		fwrite(ids, sizeof(ids), 1, f);
+	}
+	const std::vector<Texture*>* lists[4] = {&g.diffuseMaps, &g.normalMaps, &g.roughnessMaps, &g.metallicMaps};
+	for (int k = 0; k < 4; k++) {
+		const int32_t cnt = (int32_t)lists[k]->size();
+		fwrite(&cnt, sizeof(cnt), 1, f);
+		for (const Texture* t : *lists[k]) {
+			const int32_t wh[2] = {t->width, t->height};
+			fwrite(wh, sizeof(wh), 1, f);
+			for (const Vector3f& c : t->rgb) fwrite(&c.x, sizeof(float), 3, f);
+		}
 	}
 	fclose(f);
 	return 0;

@@ -148,6 +148,52 @@ TUTU_DEV LightSample sample_light(const ShadeTabs& tb, int size, Rng& rng) {
 	return s;
 }
 
+// Texture::getRGBat, Texture.hpp:18-39: wrap u,v into the unit square (the fraction for positive values,
+// 1 - fraction for the others, so u = 0 maps to 1), truncate to a texel, clamp the linear index.
+TUTU_DEV V3 texture_rgb(const SceneDev& sc, int list, int id, float u, float v) {
+	const int4 td = sc.tex_desc[sc.tex_base[list] + id];
+	if (td.y == 0 && td.z == 0) return mk1(0.f);
+	if (u > 0) u = u - (float)(int)u;
+	else u = 1 - (fabsf(u) - (float)(int)fabsf(u));
+	if (v > 0) v = v - (float)(int)v;
+	else v = 1 - (fabsf(v) - (float)(int)fabsf(v));
+	const int x = (int)(u * (float)td.y);
+	const int y = (int)(v * (float)td.z);
+	int index = y * td.y + x;
+	if (index < 0) index = 0;
+	if (index >= td.w) index = td.w - 1;
+	const float4 c = sc.texels[td.x + index];
+	return mk(c.x, c.y, c.z);
+}
+
+// textureModify + changeNormalDir (triangle case), IIntegrator.hpp:27-63, 89-127; textPos as Triangle::intersect
+// interpolates it (Triangle.hpp:61-68).  Changes the per-hit material copy and the shading normal.
+TUTU_DEV void texture_modify(const SceneDev& sc, int tri, float b1, float b2, Mat& m, V3& Ns) {
+	const float4 x3 = sc.tri_tex[4 * tri + 3];
+	const int i_diffuse = __float_as_int(x3.x), i_normal = __float_as_int(x3.y);
+	const int i_rough = __float_as_int(x3.z), i_metal = __float_as_int(x3.w);
+	if (i_diffuse == -1 && i_normal == -1 && i_rough == -1 && i_metal == -1) return;  // !isTextureActivated
+	const float4 x0 = sc.tri_tex[4 * tri + 0];
+	const float4 x1 = sc.tri_tex[4 * tri + 1];
+	const float w0 = (1 - b1 - b2);
+	const float tu = (x0.x * w0 + x0.z * b1) + x1.x * b2;
+	const float tv = (x0.y * w0 + x0.w * b1) + x1.y * b2;
+	if (i_diffuse != -1) m.diffuse = texture_rgb(sc, 0, i_diffuse, tu, tv);
+	if (i_normal != -1) {
+		const float4 x2 = sc.tri_tex[4 * tri + 2];
+		const V3 color = texture_rgb(sc, 1, i_normal, tu, tv);
+		const V3 T = mk(x1.z, x1.w, x2.x), B = mk(x2.y, x2.z, x2.w);
+		const V3 nDir = normalized(Ns);
+		V3 res;
+		res.x = T.x * color.x + B.x * color.y + nDir.x * color.z;
+		res.y = T.y * color.x + B.y * color.y + nDir.y * color.z;
+		res.z = T.z * color.x + B.z * color.y + nDir.z * color.z;
+		Ns = normalized(res);
+	}
+	if (i_rough != -1) m.roughness = texture_rgb(sc, 2, i_rough, tu, tv).x;
+	if (i_metal != -1) m.metallic = texture_rgb(sc, 3, i_metal, tu, tv).x;
+}
+
 // ------------------------------------------------------------------------------------------------------------
 // shade stage, specialised by material class ("sort by material": trace_closest files every continuing path under
 // the class of what it hit, lists<CLASS> sorts them, and each class group gets its own launch of its own kernel).
@@ -160,7 +206,9 @@ TUTU_DEV LightSample sample_light(const ShadeTabs& tb, int size, Rng& rng) {
 // path's slot as soon as they exist, so few values stay live across the BSDF code.
 enum ShadeMode { SHADE_FIRST = 0, SHADE_LAMBERT = 1, SHADE_MIRROR = 2, SHADE_REFRACT = 3, SHADE_GGXR = 4, SHADE_TERMINAL = 5 };
 
-template <int MODE, int TAB>
+// TEX: the scene has textured triangles (textureModify runs between the refractive test and everything else,
+// PathTracing.hpp:152-158); the untextured instantiations do not contain that code at all.
+template <int MODE, int TAB, bool TEX>
 __global__ void __launch_bounds__(256) k_shade(PassParams pp) {
 	constexpr bool FIRST = MODE == SHADE_FIRST;
 	const SceneDev& sc = pp.sc;
@@ -341,6 +389,7 @@ __global__ void __launch_bounds__(256) k_shade(PassParams pp) {
 			}
 			const V3 wo = -d;
 			const bool refractive = m.type == TUTU_PERFECT_REFRACTIVE || m.type == TUTU_MICROFACET_T;
+			if (TEX && !refractive) texture_modify(sc, tri, b1, b2, m, Ns);  // :157-158
 			if (terminal) {
 				if (m.type == TUTU_UNLIT) {  // :161
 					Ladd = beta * m.diffuse;

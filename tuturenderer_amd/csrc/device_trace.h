@@ -44,6 +44,11 @@ struct SceneDev {
 	float bkg[3];
 	int n_tris;
 	int n_inner;
+	// textures (only read by the TEX instantiations of the shade kernels)
+	const float4* tri_tex;  // 4 x float4 per triangle (GpuTriTex)
+	const float4* texels;   // rgb | pad per texel, all maps back to back
+	const int4* tex_desc;   // offset, width, height, size per map; the four lists back to back
+	int tex_base[4];        // first descriptor of the diffuse / normal / roughness / metallic list
 };
 
 struct SceneGlobal {

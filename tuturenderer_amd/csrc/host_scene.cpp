@@ -274,6 +274,74 @@ int build_host_scene(const TutuSceneDesc* d, HostScene& hs) {
 			s.cls = cls;
 		}
 	}
+	// textures: the per-triangle data PPMGenerator::loadObj stores (PPMGenerator.hpp:182-201) and the map lists
+	hs.tri_tex.clear();
+	hs.texels.clear();
+	hs.tex_desc.clear();
+	if (d->textures) {
+		const TutuTextureSet* ts = d->textures;
+		if (n > 0 && (!ts->uvs || !ts->tex_ids)) return TUTU_E_INVALID;
+		for (int k = 0; k < 4; k++) {
+			hs.tex_base[k] = (int32_t)hs.tex_desc.size();
+			if (ts->n_maps[k] > 0 && !ts->maps[k]) return TUTU_E_INVALID;
+			for (uint32_t i = 0; i < ts->n_maps[k]; i++) {
+				const TutuTexture& tx = ts->maps[k][i];
+				// an empty map (width == height == 0) reads as black (Texture.hpp:19-21); a map with exactly one zero
+				// side makes the reference index an empty vector, which is refused here
+				if (tx.width < 0 || tx.height < 0 || ((tx.width == 0) != (tx.height == 0))) return TUTU_E_INVALID;
+				const size_t count = (size_t)tx.width * (size_t)tx.height;
+				if (count > 0 && !tx.rgb) return TUTU_E_INVALID;
+				if (count > (size_t)INT_MAX || hs.texels.size() / 4 + count > (size_t)INT_MAX) return TUTU_E_INVALID;
+				GpuTexDesc gd;
+				gd.offset = (int32_t)(hs.texels.size() / 4);
+				gd.width = tx.width;
+				gd.height = tx.height;
+				gd.size = (int32_t)count;
+				hs.tex_desc.push_back(gd);
+				for (size_t j = 0; j < count; j++) {
+					hs.texels.push_back(tx.rgb[3 * j + 0]);
+					hs.texels.push_back(tx.rgb[3 * j + 1]);
+					hs.texels.push_back(tx.rgb[3 * j + 2]);
+					hs.texels.push_back(0.f);
+				}
+			}
+		}
+		hs.tri_tex.resize(n);
+		for (uint32_t li = 0; li < n; li++) {
+			const int32_t o = order[li];
+			const float* v = d->verts + 9 * (size_t)o;
+			const float* uv = ts->uvs + 6 * (size_t)o;
+			GpuTriTex& tt = hs.tri_tex[li];
+			memcpy(tt.uv0, uv, 8);
+			memcpy(tt.uv1, uv + 2, 8);
+			memcpy(tt.uv2, uv + 4, 8);
+			for (int k = 0; k < 4; k++) {
+				const int32_t id = ts->tex_ids[4 * (size_t)o + k];
+				// the reference exits when an index is beyond its list (IIntegrator.hpp:92-96, 106-110, 117-121)
+				if (id < -1 || (id >= 0 && (uint32_t)id >= ts->n_maps[k])) return TUTU_E_INVALID;
+				tt.ids[k] = id;
+			}
+			memset(tt.T, 0, 12);
+			memset(tt.B, 0, 12);
+			if (tt.ids[1] != -1) {  // changeNormalDir, IIntegrator.hpp:36-54
+				float e1[3], e2[3];
+				sub3(v + 3, v, e1);
+				sub3(v + 6, v, e2);
+				const float deltaU1 = tt.uv1[0] - tt.uv0[0];
+				const float deltaV1 = tt.uv1[1] - tt.uv0[1];
+				const float deltaU2 = tt.uv2[0] - tt.uv0[0];
+				const float deltaV2 = tt.uv2[1] - tt.uv0[1];
+				const float coef = 1 / (-deltaU1 * deltaV2 + deltaV1 * deltaU2);
+				for (int k = 0; k < 3; k++) {
+					tt.T[k] = coef * (-deltaV2 * e1[k] + deltaV1 * e2[k]);
+					tt.B[k] = coef * (-deltaU2 * e1[k] + deltaU1 * e2[k]);
+				}
+				normalize3(tt.T);
+				normalize3(tt.B);
+			}
+		}
+	}
+
 	hs.lights.resize(light_orig.size());
 	for (size_t k = 0; k < light_orig.size(); k++) {
 		const int32_t o = light_orig[k];

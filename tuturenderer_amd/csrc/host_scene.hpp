@@ -66,7 +66,27 @@ struct GpuLight {
 };
 static_assert(sizeof(GpuLight) == 96, "GpuLight must be 96 B");
 
+// Texture data of one triangle (64 B = 4 x dwordx4), only present when the scene has a TutuTextureSet.
+// T and B are the tangent and bitangent changeNormalDir derives from the triangle's vertices and uvs on every hit
+// (IIntegrator.hpp:39-54): they depend on the triangle only, so the host computes them once with the same fp32
+// operations.
+struct GpuTriTex {
+	float uv0[2], uv1[2], uv2[2];
+	float T[3], B[3];
+	int32_t ids[4];  // diffuse, normal, roughness, metallic map; -1 = none
+};
+static_assert(sizeof(GpuTriTex) == 64, "GpuTriTex must be 64 B");
+
+// One map of the texel atlas: texels [offset, offset + width*height) of HostScene::texels
+struct GpuTexDesc {
+	int32_t offset, width, height, size;
+};
+
 struct HostScene {
+	std::vector<GpuTriTex> tri_tex;    // leaf order; empty = untextured scene
+	std::vector<float> texels;         // 4 floats per texel (rgb, pad): one dwordx4 per lookup
+	std::vector<GpuTexDesc> tex_desc;  // the four map lists back to back
+	int32_t tex_base[4] = {0, 0, 0, 0};  // first descriptor of each list
 	std::vector<GpuNode> nodes;       // inner nodes; nodes[0] is the root when n_tris >= 2
 	std::vector<GpuTriIsect> tri_isect;  // leaf order
 	std::vector<GpuTriShade> tri_shade;  // leaf order

@@ -77,6 +77,8 @@ struct TutuCtx {
 	HostScene hs;
 	SceneDev sc;
 	DevBuf<float4> d_nodes, d_tri_isect, d_tri_shade, d_mats, d_lights;
+	bool textured = false;
+	DevBuf<float4> d_tri_tex, d_texels, d_tex_desc;
 	DevBuf<uint8_t> d_tri_class;
 	// work buffers: two sets, so that consecutive passes run on two streams and a memory-bound stage of one pass
 	// overlaps a compute-bound stage of the other
@@ -206,10 +208,18 @@ int build_lists(TutuCtx* c, WorkSet& w, hipStream_t s, uint32_t n_slots_padded, 
 template <int MODE>
 int launch_shade_tab(TutuCtx* c, hipStream_t s, dim3 grid, const PassParams& pp) {
 	const int ev = MODE == SHADE_FIRST ? EV_SHADE_FIRST : (MODE == SHADE_TERMINAL ? EV_SHADE_TERM : EV_SHADE);
+	if (c->textured) {
+		switch (c->shade_tab) {
+		case 2: TIMED(ev, k_shade<MODE, 2, true><<<grid, dim3(256), c->shade_lds_bytes, s>>>(pp)); break;
+		case 1: TIMED(ev, k_shade<MODE, 1, true><<<grid, dim3(256), c->shade_lds_bytes, s>>>(pp)); break;
+		default: TIMED(ev, k_shade<MODE, 0, true><<<grid, dim3(256), 0, s>>>(pp)); break;
+		}
+		return TUTU_OK;
+	}
 	switch (c->shade_tab) {
-	case 2: TIMED(ev, k_shade<MODE, 2><<<grid, dim3(256), c->shade_lds_bytes, s>>>(pp)); break;
-	case 1: TIMED(ev, k_shade<MODE, 1><<<grid, dim3(256), c->shade_lds_bytes, s>>>(pp)); break;
-	default: TIMED(ev, k_shade<MODE, 0><<<grid, dim3(256), 0, s>>>(pp)); break;
+	case 2: TIMED(ev, k_shade<MODE, 2, false><<<grid, dim3(256), c->shade_lds_bytes, s>>>(pp)); break;
+	case 1: TIMED(ev, k_shade<MODE, 1, false><<<grid, dim3(256), c->shade_lds_bytes, s>>>(pp)); break;
+	default: TIMED(ev, k_shade<MODE, 0, false><<<grid, dim3(256), 0, s>>>(pp)); break;
 	}
 	return TUTU_OK;
 }
@@ -503,8 +513,18 @@ int tutu_hip_create(const TutuSceneDesc* scene, int device, TutuCtx** out) {
 	if ((rc = c->d_tri_class.ensure(std::max<size_t>(16, c->hs.tri_class.size()))) != TUTU_OK) return fail(rc);
 	if (!c->hs.tri_class.empty() && hipMemcpyAsync(c->d_tri_class.p, c->hs.tri_class.data(), c->hs.tri_class.size(), hipMemcpyHostToDevice, s) != hipSuccess)
 		return fail(TUTU_E_HIP);
+	c->textured = !c->hs.tri_tex.empty();
+	if (c->textured) {
+		if ((rc = upload(c->d_tri_tex, c->hs.tri_tex, s)) != TUTU_OK) return fail(rc);
+		if ((rc = upload(c->d_texels, c->hs.texels, s)) != TUTU_OK) return fail(rc);
+		if ((rc = upload(c->d_tex_desc, c->hs.tex_desc, s)) != TUTU_OK) return fail(rc);
+	}
 	if (hipStreamSynchronize(s) != hipSuccess) return fail(TUTU_E_HIP);
 	SceneDev& sc = c->sc;
+	sc.tri_tex = c->d_tri_tex.p;
+	sc.texels = c->d_texels.p;
+	sc.tex_desc = reinterpret_cast<const int4*>(c->d_tex_desc.p);
+	memcpy(sc.tex_base, c->hs.tex_base, sizeof(sc.tex_base));
 	sc.nodes = c->d_nodes.p;
 	sc.tri_isect = c->d_tri_isect.p;
 	sc.tri_shade = c->d_tri_shade.p;
@@ -557,6 +577,7 @@ int tutu_hip_destroy(TutuCtx* c) {
 		(void)hipEventDestroy(e.a);
 		(void)hipEventDestroy(e.b);
 	}
+	c->d_tri_tex.release(); c->d_texels.release(); c->d_tex_desc.release();
 	c->d_tri_class.release(); c->d_nodes.release(); c->d_tri_isect.release(); c->d_tri_shade.release(); c->d_mats.release(); c->d_lights.release();
 	if (c->stream2) (void)hipStreamSynchronize(c->stream2);
 	for (int k = 0; k < 2; k++) {
@@ -674,6 +695,15 @@ __global__ void k_test_pdf(TutuMaterial m, const float* wi, const float* wo, con
 	if (i >= n) return;
 	const Mat mm = mat_from_abi(m);
 	out[i] = mat_pdf(mm, ld3(wi + 3 * (size_t)i), ld3(wo + 3 * (size_t)i), ld3(N + 3 * (size_t)i), eta_i, eta_t);
+}
+
+__global__ void k_test_texture(SceneDev sc, int list, int index, const float* u, const float* v, uint32_t n, float* rgb) {
+	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n) return;
+	const V3 c = texture_rgb(sc, list, index, u[i], v[i]);
+	rgb[3 * (size_t)i + 0] = c.x;
+	rgb[3 * (size_t)i + 1] = c.y;
+	rgb[3 * (size_t)i + 2] = c.z;
 }
 
 __global__ void k_test_sample(TutuMaterial m, const float* wo, const float* N, float eta_i, const float* xi3, uint32_t n, float* wi,
@@ -873,6 +903,24 @@ int tutu_hip_eval_pdf(TutuCtx* c, uint32_t n, const TutuMaterial* m, const float
 	HIP_TRY(hipGetLastError());
 	HIP_TRY(hipStreamSynchronize(c->stream));
 	HIP_TRY(hipMemcpy(out, d_out, sizeof(float) * (size_t)n, hipMemcpyDeviceToHost));
+	return TUTU_OK;
+}
+
+int tutu_hip_eval_texture(TutuCtx* c, int32_t list, int32_t index, uint32_t n, const float* u, const float* v, float* rgb) {
+	if (!c || !u || !v || !rgb || list < 0 || list > 3 || index < 0) return TUTU_E_INVALID;
+	const size_t n_list = (list < 3 ? (size_t)c->hs.tex_base[list + 1] : c->hs.tex_desc.size()) - (size_t)c->hs.tex_base[list];
+	if (!c->textured || (size_t)index >= n_list) return TUTU_E_INVALID;
+	if (n == 0) return TUTU_OK;
+	HIP_TRY(hipSetDevice(c->device));
+	Scratch sc;
+	float *d_u, *d_v, *d_out;
+	RC(sc.up(u, (size_t)n, &d_u));
+	RC(sc.up(v, (size_t)n, &d_v));
+	RC(sc.alloc(3 * (size_t)n, &d_out));
+	hipLaunchKernelGGL(k_test_texture, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->sc, (int)list, (int)index, d_u, d_v, n, d_out);
+	HIP_TRY(hipGetLastError());
+	HIP_TRY(hipStreamSynchronize(c->stream));
+	HIP_TRY(hipMemcpy(rgb, d_out, sizeof(float) * 3 * (size_t)n, hipMemcpyDeviceToHost));
 	return TUTU_OK;
 }
 

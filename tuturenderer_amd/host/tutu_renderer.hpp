@@ -187,6 +187,53 @@ public:
 	Material mtlcolor;  // current material of the inline `v/f` geometry
 	std::vector<Vector3f> vertices, normals;
 	std::vector<Vector2f> textCoords;
+	// texture state of the config parser (PPMGenerator.hpp:36-39, 59-64)
+	std::vector<Texture*> diffuseMaps, normalMaps, roughnessMaps, metallicMaps;
+	bool isTextureOn = false;
+	int textIndex = -1, bumpIndex = -1, roughnessIndex = -1, metallicIndex = -1;
+
+	~PPMGenerator() {
+		for (auto* lst : {&diffuseMaps, &normalMaps, &roughnessMaps, &metallicMaps})
+			for (Texture* t : *lst) delete t;
+	}
+	PPMGenerator(const PPMGenerator&) = delete;
+	PPMGenerator& operator=(const PPMGenerator&) = delete;
+
+	// ASCII PPM ("P3 w h max r g b ...") -> Texture with channel/max floats; a name already in the list is not
+	// loaded again (PPMGenerator.hpp:1027-1084)
+	void loadTexture(const char* name, std::vector<Texture*>& textList) {
+		for (Texture* t : textList)
+			if (t->name == name) return;
+		std::ifstream input(name, std::ios_base::in);
+		if (!input.is_open()) {
+			std::cout << "ERROR:: texture file does not exits, program terminates.\n";
+			exit(-1);
+		}
+		std::string b0, b1, b2;
+		input >> b0 >> b1 >> b2;
+		if (b0 != "P3") {
+			std::cout << "ERROR:: Need P3 keyword, program terminates.\n";
+			exit(-1);
+		}
+		needPosInt(b1);
+		needPosInt(b2);
+		Texture* t = new Texture;
+		t->name = name;
+		t->width = std::stoi(b1);
+		t->height = std::stoi(b2);
+		input >> b0;
+		const float max = (float)std::stoi(b0);
+		t->rgb.reserve((size_t)t->width * t->height);
+		for (int j = 0; j < t->height; j++)
+			for (int i = 0; i < t->width; i++) {
+				input >> b0 >> b1 >> b2;
+				needPosInt(b0);
+				needPosInt(b1);
+				needPosInt(b2);
+				t->rgb.emplace_back(Vector3f(std::stoi(b0) / max, std::stoi(b1) / max, std::stoi(b2) / max));
+			}
+		textList.emplace_back(t);
+	}
 
 	explicit PPMGenerator(const char* path) {
 		fin.open(path, std::ios_base::in);
@@ -202,10 +249,6 @@ public:
 	// the reference (PPMGenerator.hpp:164-208), so only pre-triangulated OBJ files work.
 	void loadObj(objl::Loader& loader, Material& mtl, int textureIndex = -1, int bumpMapIndex = -1, int roughnessIndex = -1,
 	             int metallicIndex = -1) {
-		if (textureIndex != -1 || bumpMapIndex != -1 || roughnessIndex != -1 || metallicIndex != -1) {
-			std::cout << "ERROR: textures are outside the GPU PathTracing path of this build\n";
-			exit(-1);
-		}
 		for (auto& m : loader.LoadedMeshes) {
 			for (size_t i = 0; i + 2 < m.Vertices.size(); i += 3) {
 				auto t = std::make_unique<Triangle>();
@@ -220,6 +263,11 @@ public:
 				t->uv1 = {b.TextureCoordinate.X, b.TextureCoordinate.Y};
 				t->uv2 = {c.TextureCoordinate.X, c.TextureCoordinate.Y};
 				t->mtlcolor = mtl;
+				t->textureIndex = textureIndex;
+				t->normalMapIndex = bumpMapIndex;
+				t->roughnessMapIndex = roughnessIndex;
+				t->metallicMapIndex = metallicIndex;
+				if (textureIndex != -1 || bumpMapIndex != -1 || roughnessIndex != -1 || metallicIndex != -1) t->isTextureActivated = true;
 				t->initializeBound();
 				scene.add(std::move(t));
 			}
@@ -372,6 +420,7 @@ private:
 			mtlcolor.specular = triple();
 			mtlcolor.alpha = number();
 			mtlcolor.eta = number();
+			isTextureOn = false;  // :608
 		} else if (key == "MICROFACET_R" || key == "MICROFACET_T") {
 			mtlcolor.mType = key == "MICROFACET_R" ? MICROFACET_R : MICROFACET_T;
 			mtlcolor.diffuse = triple();
@@ -400,13 +449,40 @@ private:
 			const float a = number(), b = number();
 			textCoords.push_back({a, b});
 		} else if (key == "f") face();
-		else if (key == "texture" || key == "bump" || key == "roughnessTexture" || key == "metallicTexture" || key == "sphere")
+		else if (key == "texture") textIndex = textureKeyword(diffuseMaps, false);
+		else if (key == "bump") bumpIndex = textureKeyword(normalMaps, true);
+		else if (key == "roughnessTexture") roughnessIndex = textureKeyword(roughnessMaps, false);
+		else if (key == "metallicTexture") metallicIndex = textureKeyword(metallicMaps, false);
+		else if (key == "sphere")
 			throw std::runtime_error("`" + key + "` is outside the GPU PathTracing path of this build (SURVEY.md 8f)\n");
 		else throw std::runtime_error("extraneous string in the input file\n");
 	}
 
-	// f a b c | a//n .. | a/t .. | a/t/n ..   (PPMGenerator.hpp:404-452, 879-1023); texture coordinates are
-	// stored but no texture is ever active on this path
+	// `texture` / `bump` / `roughnessTexture` / `metallicTexture` <file>  (PPMGenerator.hpp:669-765): load the map unless
+	// a map of that name is already in the list, make it the active one; a freshly loaded normal map is mapped from
+	// [0,1] to [-1,1] (:713-722)
+	int textureKeyword(std::vector<Texture*>& list, bool isNormalMap) {
+		const size_t size0 = list.size();
+		const std::string a = next();
+		loadTexture(a.c_str(), list);
+		isTextureOn = true;
+		if (list.size() == size0) {
+			for (size_t i = 0; i < list.size(); i++)
+				if (list[i]->name == a) return (int)i;
+			return -1;
+		}
+		const int idx = (int)list.size() - 1;
+		if (isNormalMap)
+			for (Vector3f& c : list[(size_t)idx]->rgb) {
+				c = c * 2.f;
+				c.x = c.x - 1.f;
+				c.y = c.y - 1.f;
+				c.z = c.z - 1.f;
+			}
+		return idx;
+	}
+
+	// f a b c | a//n .. | a/t .. | a/t/n ..   (PPMGenerator.hpp:404-452, 879-1023)
 	void face() {
 		const std::string tok[3] = {next(), next(), next()};
 		Triangle t;
@@ -440,6 +516,14 @@ private:
 			t.n0 = t.n1 = t.n2 = n;
 		}
 		auto s = std::make_unique<Triangle>(t);
+		if (isTextureOn) {  // :439-448 -- a face takes the active albedo map and, once, the pending normal map
+			s->isTextureActivated = true;
+			s->textureIndex = textIndex;
+			if (bumpIndex != -1) {
+				s->normalMapIndex = bumpIndex;
+				bumpIndex = -1;
+			}
+		}
 		s->objectType = TRIANGLE;
 		s->initializeBound();
 		scene.add(std::move(s));
@@ -512,10 +596,23 @@ public:
 		std::vector<float> verts(9 * n), normals(9 * n);
 		std::vector<int32_t> mat_id(n);
 		std::vector<TutuMaterial> mats;
+		std::vector<float> uvs(6 * n, -1.f);
+		std::vector<int32_t> tex_ids(4 * n, -1);
+		bool any_texture = false;
 		for (size_t i = 0; i < n; i++) {
 			Object* o = gen->scene.objList[i].get();
-			if (o->objectType != TRIANGLE || o->isTextureActivated) die(TUTU_E_UNSUPPORTED, "scene");
+			if (o->objectType != TRIANGLE) die(TUTU_E_UNSUPPORTED, "scene");
 			const Triangle* t = static_cast<const Triangle*>(o);
+			if (o->isTextureActivated) {
+				any_texture = true;
+				uvs[6 * i + 0] = t->uv0.x; uvs[6 * i + 1] = t->uv0.y;
+				uvs[6 * i + 2] = t->uv1.x; uvs[6 * i + 3] = t->uv1.y;
+				uvs[6 * i + 4] = t->uv2.x; uvs[6 * i + 5] = t->uv2.y;
+				tex_ids[4 * i + 0] = o->textureIndex;
+				tex_ids[4 * i + 1] = o->normalMapIndex;
+				tex_ids[4 * i + 2] = o->roughnessMapIndex;
+				tex_ids[4 * i + 3] = o->metallicMapIndex;
+			}
 			const Vector3f* pv[3] = {&t->v0, &t->v1, &t->v2};
 			const Vector3f* pn[3] = {&t->n0, &t->n1, &t->n2};
 			for (int k = 0; k < 3; k++) {
@@ -552,6 +649,28 @@ public:
 		sd.mats = mats.data();
 		sd.eta = gen->eta;
 		sd.bkg[0] = gen->bkgcolor.x; sd.bkg[1] = gen->bkgcolor.y; sd.bkg[2] = gen->bkgcolor.z;
+		// textured triangles: the four map lists of the front-end go over as they are (Texture::rgb is already a
+		// packed float triple per texel)
+		TutuTextureSet ts;
+		std::memset(&ts, 0, sizeof(ts));
+		std::vector<TutuTexture> maps[4];
+		if (any_texture) {
+			const std::vector<Texture*>* lists[4] = {&gen->diffuseMaps, &gen->normalMaps, &gen->roughnessMaps, &gen->metallicMaps};
+			for (int k = 0; k < 4; k++) {
+				for (const Texture* t : *lists[k]) {
+					TutuTexture tt;
+					tt.width = t->width;
+					tt.height = t->height;
+					tt.rgb = t->rgb.empty() ? nullptr : &t->rgb[0].x;
+					maps[k].push_back(tt);
+				}
+				ts.n_maps[k] = (uint32_t)maps[k].size();
+				ts.maps[k] = maps[k].data();
+			}
+			ts.uvs = uvs.data();
+			ts.tex_ids = tex_ids.data();
+			sd.textures = &ts;
+		}
 
 		TutuCameraDesc cd;
 		cd.width = gen->width;
