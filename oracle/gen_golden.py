@@ -40,6 +40,7 @@ def golden_scenes():
         "veach_slight": (lambda: scenes.veach_room(96, 72, small_light=True), 6),
         "cornell_degenerate": (lambda: pc.degenerate_cornell(64, 64), 9),
         "cornell_textured": (lambda: scenes.cornell_textured(96, 96), 11),
+        "cornell_spheres": (lambda: scenes.cornell_spheres(96, 96), 12),
     }
 
 

@@ -56,6 +56,14 @@ typedef struct TorSceneDesc {
 	const int32_t* tex_ids; /* n_tris*4: diffuse, normal, roughness, metallic map index, -1 = none */
 	int32_t n_textures[4];
 	const struct TorTexture* textures[4];
+	/* optional spheres: Scene::objList is the triangles with the spheres inserted at the given
+	 * object-list positions (ascending; NULL = all spheres after the triangles).  With spheres present every
+	 * "triangle index" this ABI reports is an index into that combined object list. */
+	int32_t n_spheres;
+	const float* spheres;            /* n_spheres*4: centre xyz, radius */
+	const int32_t* sphere_mat_id;    /* n_spheres */
+	const int32_t* sphere_tex_ids;   /* n_spheres*4 or NULL */
+	const int32_t* sphere_pos;       /* n_spheres or NULL */
 } TorSceneDesc;
 
 const char* tor_kind(void); /* "port" or "reference" */

@@ -68,6 +68,11 @@ class _SceneDesc(C.Structure):
         ("tex_ids", C.c_void_p),
         ("n_textures", C.c_int32 * 4),
         ("textures", C.c_void_p * 4),
+        ("n_spheres", C.c_int32),
+        ("spheres", C.c_void_p),
+        ("sphere_mat_id", C.c_void_p),
+        ("sphere_tex_ids", C.c_void_p),
+        ("sphere_pos", C.c_void_p),
     ]
 
 
@@ -76,6 +81,26 @@ class _Texture(C.Structure):
 
 
 TEXTURE_LISTS = ("diffuse", "normal", "roughness", "metallic")
+
+
+def pack_spheres(scene, desc):
+    """scene["spheres"] (n,4) centre+radius, scene["sphere_mat_id"] (n,), optional scene["sphere_tex_ids"] (n,4) and
+    scene["sphere_pos"] (n,) object-list positions -> fills the optional sphere fields of a scene descriptor"""
+    if scene.get("spheres") is None or len(scene["spheres"]) == 0:
+        return []
+    sp = np.ascontiguousarray(scene["spheres"], dtype=np.float32).reshape(-1, 4)
+    mid = np.ascontiguousarray(scene["sphere_mat_id"], dtype=np.int32)
+    keep = [sp, mid]
+    desc.n_spheres, desc.spheres, desc.sphere_mat_id = len(sp), sp.ctypes.data, mid.ctypes.data
+    if scene.get("sphere_tex_ids") is not None:
+        t = np.ascontiguousarray(scene["sphere_tex_ids"], dtype=np.int32).reshape(-1, 4)
+        desc.sphere_tex_ids = t.ctypes.data
+        keep.append(t)
+    if scene.get("sphere_pos") is not None:
+        q = np.ascontiguousarray(scene["sphere_pos"], dtype=np.int32)
+        desc.sphere_pos = q.ctypes.data
+        keep.append(q)
+    return keep
 
 
 def pack_textures(scene, desc, texture_struct):
@@ -290,6 +315,7 @@ class OracleScene:
         d.updir = (C.c_float * 3)(*[float(x) for x in scene["updir"]])
         d.hfov = int(scene["hfov"])
         self._tex_keep = pack_textures(scene, d, _Texture)
+        self._sphere_keep = pack_spheres(scene, d)
         self.h = C.c_void_p()
         rc = self.lib.tor_scene_create(C.byref(d), C.byref(self.h))
         if rc != 0:
@@ -307,7 +333,8 @@ class OracleScene:
             pass
 
     def bvh_dump(self):
-        cap = 2 * len(self.verts) + 8
+        n_obj = len(self.verts) + (len(self._sphere_keep[0]) if self._sphere_keep else 0)
+        cap = 2 * n_obj + 8
         b = np.zeros((cap, 6), np.float32)
         leaf = np.zeros(cap, np.int32)
         n = C.c_int32(0)

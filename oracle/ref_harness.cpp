@@ -12,6 +12,7 @@
 // Nothing in this file is shipped or measured as the product.
 #include "Renderer.hpp" // the reference's umbrella header (pulls PathTracing.hpp, BVH.hpp, Material.hpp, ...)
 #include "OBJ_Loader.h"
+#include "Sphere.hpp"
 
 #include "oracle_abi.h"
 
@@ -343,7 +344,38 @@ int tor_scene_create(const TorSceneDesc* d, void** out) {
 		for (int k = 0; k < 4; k++)
 			for (int i = 0; i < d->n_textures[k]; i++) lists[k]->push_back(make_texture(&d->textures[k][i], k, i));
 	}
-	for (int i = 0; i < d->n_tris; i++) {
+	// Scene::objList = the triangles with the spheres inserted at their object-list positions
+	const int n_obj = d->n_tris + d->n_spheres;
+	std::vector<int> sphere_at(n_obj, -1);
+	for (int j = 0; j < d->n_spheres; j++) {
+		const int pos = d->sphere_pos ? d->sphere_pos[j] : d->n_tris + j;
+		if (pos < 0 || pos >= n_obj || sphere_at[pos] != -1) { delete s->g; delete s; return -1; }
+		sphere_at[pos] = j;
+	}
+	int i = -1;  // running triangle index
+	for (int slot = 0; slot < n_obj; slot++) {
+		if (sphere_at[slot] >= 0) {
+			// as PPMGenerator::readObject does for the `sphere` keyword (PPMGenerator.hpp:358-402)
+			const int j = sphere_at[slot];
+			std::unique_ptr<Sphere> sp = std::make_unique<Sphere>();
+			sp->mtlcolor = to_material(&d->mats[d->sphere_mat_id[j]]);
+			sp->centerPos = Vector3f(d->spheres[4 * j + 0], d->spheres[4 * j + 1], d->spheres[4 * j + 2]);
+			sp->radius = d->spheres[4 * j + 3];
+			sp->objectType = OBJTYPE::SPEHRE;
+			if (d->sphere_tex_ids) {
+				sp->textureIndex = d->sphere_tex_ids[4 * j + 0];
+				sp->normalMapIndex = d->sphere_tex_ids[4 * j + 1];
+				sp->roughnessMapIndex = d->sphere_tex_ids[4 * j + 2];
+				sp->metallicMapIndex = d->sphere_tex_ids[4 * j + 3];
+				if (sp->textureIndex != -1 || sp->normalMapIndex != -1 || sp->metallicMapIndex != -1 || sp->roughnessMapIndex != -1)
+					sp->isTextureActivated = true;
+			}
+			sp->initializeBound();
+			s->index[sp.get()] = slot;
+			g->scene.add(std::move(sp));
+			continue;
+		}
+		i++;
 		// as PPMGenerator::loadObj does per triangle (PPMGenerator.hpp:170-203)
 		std::unique_ptr<Triangle> t = std::make_unique<Triangle>();
 		fill_triangle(*t, d->verts + 9 * i, d->normals + 9 * i);
@@ -363,7 +395,7 @@ int tor_scene_create(const TorSceneDesc* d, void** out) {
 				t->isTextureActivated = true;
 		}
 		t->initializeBound();
-		s->index[t.get()] = i;
+		s->index[t.get()] = slot;
 		g->scene.add(std::move(t));
 	}
 	g->scene.initializeBVH(); // Renderer.hpp:53

@@ -500,10 +500,13 @@ static inline bool box_intersect(const Box& b, const V3& o, const V3& d, float* 
 	return false;
 }
 
-struct Tri {
+struct Tri {  // one entry of Scene::objList: a Triangle (Triangle.hpp) or, kind == 1, a Sphere (Sphere.hpp:6-21)
 	V3 v0, v1, v2, n0, n1, n2;
 	int mat = 0;
 	Box bound;
+	int kind = 0;
+	V3 centerPos;
+	float radius = 1.f;
 	// textures
 	float uv0[2] = {-1.f, -1.f}, uv1[2] = {-1.f, -1.f}, uv2[2] = {-1.f, -1.f};  // Vector2f() = (-1,-1), Vector.hpp:54-57
 	int tex[4] = {-1, -1, -1, -1};  // textureIndex, normalMapIndex, roughnessMapIndex, metallicMapIndex (Object.hpp:31-35)
@@ -553,6 +556,66 @@ static inline float tri_area(const Tri& tr) { // Triangle.hpp:109-116
 	return norm(cross(e1, e2)) * 0.5f;
 }
 
+// global.hpp:147-167
+static inline void solveQuadratic(float& t1, float& t2, float A, float B, float C) {
+	float discriminant = B * B - 4 * A * C;
+	if (discriminant < 0) {
+		t1 = FLT_MAX;
+		t2 = FLT_MAX;
+	} else if (discriminant == 0) {
+		t1 = (-B + sqrtf(discriminant)) / (2 * A);
+		t2 = t1;
+	} else {
+		t1 = (-B + sqrtf(discriminant)) / (2 * A);
+		t2 = (-B - sqrtf(discriminant)) / (2 * A);
+	}
+	if (t1 > t2) std::swap(t1, t2);
+}
+// Sphere::intersect, Sphere.hpp:26-131.  A = 1 whatever the length of dir [sic]; C goes through pow(float, int),
+// i.e. double arithmetic, and is rounded to float once.
+static inline bool sphere_intersect(const Tri& sp, int index, const V3& orig, const V3& dir, Hit& inter) {
+	float A = 1.f;
+	float B = 2 * (dir.x * (orig.x - sp.centerPos.x) + dir.y * (orig.y - sp.centerPos.y) + dir.z * (orig.z - sp.centerPos.z));
+	const double dx = (double)(orig.x - sp.centerPos.x), dy = (double)(orig.y - sp.centerPos.y), dz = (double)(orig.z - sp.centerPos.z);
+	float C = (float)(dx * dx + dy * dy + dz * dz - (double)(sp.radius * sp.radius));
+	float t1 = 0, t2 = 0;
+	solveQuadratic(t1, t2, A, B, C);
+	inter.intersected = false;
+	float t;
+	if (float_equal(t1, FLT_MAX) && float_equal(t2, FLT_MAX)) return false;
+	else if (float_equal(t1, t2)) {
+		if (t1 < 0) return false;
+		t = t1;
+	} else {
+		if (t1 > 0 && t2 > 0) t = t1;
+		else if (t1 > 0 && t2 < 0) t = t1;
+		else if (t1 < 0 && t2 > 0) t = t2;
+		else return false;
+	}
+	inter.t = t;
+	inter.intersected = true;
+	inter.tri = index;
+	inter.pos = orig + inter.t * dir;
+	inter.Ng = normalized(inter.pos - sp.centerPos);
+	inter.Ns = inter.Ng;
+	if (sp.isTextureActivated) {  // :54-74
+		float phi = acosf(inter.Ng.z);
+		float v = phi / kPi;
+		float theta = atan2f(inter.Ng.y, inter.Ng.x);
+		if (theta < 0) theta += 2 * kPi;
+		float u = (theta / (2.f * kPi));
+		inter.textPos[0] = u;
+		inter.textPos[1] = v;
+	}
+	return true;
+}
+static inline bool prim_intersect(const Tri& p, int index, const V3& orig, const V3& dir, Hit& inter) {
+	return p.kind == 1 ? sphere_intersect(p, index, orig, dir, inter) : tri_intersect(p, index, orig, dir, inter);
+}
+static inline float prim_area(const Tri& p) {  // Sphere::getArea is r*r*pi [sic], Sphere.hpp:140-142
+	return p.kind == 1 ? p.radius * p.radius * kPi : tri_area(p);
+}
+
 // ------------------------------------------------------------------------------------------------ BVH
 struct Node { // BVH.hpp:15-23
 	Box bound;
@@ -588,6 +651,17 @@ struct Scene {
 	// changeNormalDir, IIntegrator.hpp:27-63 (triangle case)
 	void changeNormalDir(Hit& inter, const Tri& t) const {
 		const V3 color = maps[1][(size_t)t.tex[1]].getRGBat(inter.textPos[0], inter.textPos[1]);
+		if (t.kind == 1) {  // SPEHRE case, :65-79
+			V3 nDir = inter.Ng;
+			V3 T = V3(-nDir.y / sqrtf(nDir.x * nDir.x + nDir.y * nDir.y), nDir.x / sqrtf(nDir.x * nDir.x + nDir.y * nDir.y), 0);
+			V3 B = cross(nDir, T);
+			V3 res;
+			res.x = T.x * color.x + B.x * color.y + nDir.x * color.z;
+			res.y = T.y * color.x + B.y * color.y + nDir.y * color.z;
+			res.z = T.z * color.x + B.z * color.y + nDir.z * color.z;
+			inter.Ns = normalized(res);
+			return;
+		}
 		V3 e1 = t.v1 - t.v0;
 		V3 e2 = t.v2 - t.v0;
 		V3 nDir = normalized(inter.Ns);
@@ -681,7 +755,7 @@ struct Scene {
 		if (n.left < 0 && n.right < 0) {
 			if (n.tri >= 0) {
 				if (c) c->tris++;
-				tri_intersect(tris[n.tri], n.tri, o, d, inter);
+				prim_intersect(tris[n.tri], n.tri, o, d, inter);
 			}
 			return inter;
 		}
@@ -700,7 +774,7 @@ struct Scene {
 			Hit inter;
 			if (n.tri >= 0) {
 				if (c) c->tris++;
-				tri_intersect(tris[n.tri], n.tri, o, d, inter);
+				prim_intersect(tris[n.tri], n.tri, o, d, inter);
 			}
 			if (inter.intersected && inter.t < dis && !float_equal(inter.t, dis)) return true;
 			return false;
@@ -731,7 +805,7 @@ struct Scene {
 				if (n.tri >= 0) {
 					if (c) c->tris++;
 					Hit h;
-					if (tri_intersect(tris[n.tri], n.tri, o, d, h)) {
+					if (prim_intersect(tris[n.tri], n.tri, o, d, h)) {
 						int ord = leaf_order[n.tri];
 						if (h.t < best.t || (h.t == best.t && ord < best_order)) {
 							best = h;
@@ -781,7 +855,7 @@ struct Scene {
 				if (n.tri >= 0) {
 					if (c) c->tris++;
 					Hit h;
-					tri_intersect(tris[n.tri], n.tri, o, d, h);
+					prim_intersect(tris[n.tri], n.tri, o, d, h);
 					if (h.intersected && h.t < dis && !float_equal(h.t, dis)) return true;
 				}
 			} else {
@@ -832,7 +906,7 @@ struct Scene {
 		int size = (int)lights.size();
 		if (size == 0) return 0;
 		if (!mats[tris[inter.tri].mat].hasEmission()) return 0;
-		float area = tri_area(tris[inter.tri]);
+		float area = prim_area(tris[inter.tri]);
 		return 1 / (size * area);
 	}
 	// IIntegrator.hpp:173-192 + Triangle.hpp:119-142.  The pick is drawn even with one light; the pick is not
@@ -847,6 +921,19 @@ struct Scene {
 		int index = (int)(rng.next() * (size - 1) + 0.4999f);
 		if (size == 1) index = 0;
 		const Tri& tr = tris[lights[index]];
+		if (tr.kind == 1) {  // Sphere::samplePoint, Sphere.hpp:144-163: angles drawn uniformly, not the area [sic]
+			float theta = rng.next() * 2 * kPi;
+			float phi = rng.next() * kPi;
+			inter.pos.x = tr.centerPos.x + tr.radius * cosf(theta) * sinf(phi);
+			inter.pos.y = tr.centerPos.y + tr.radius * sinf(theta) * sinf(phi);
+			inter.pos.z = tr.centerPos.z + tr.radius * cosf(phi);
+			inter.Ng = normalized(inter.pos - tr.centerPos);
+			inter.Ns = inter.Ng;
+			inter.intersected = true;
+			inter.tri = lights[index];
+			pdf_out = (1.f / (size * prim_area(tr)));
+			return true;
+		}
 		float u = rng.next();
 		float v = rng.next() * (1 - u); // non-uniform over the triangle [sic]
 		V3 pos = (1 - u - v) * tr.v0 + u * tr.v1 + v * tr.v2;
@@ -1205,7 +1292,36 @@ int tor_mat_sample(int n, const TorMaterial* m, const float* wo, const float* N,
 int tor_scene_create(const TorSceneDesc* d, void** out) {
 	if (!d || !out) return -1;
 	Scene* s = new Scene();
-	s->tris.resize(d->n_tris);
+	const int n_obj = d->n_tris + d->n_spheres;
+	s->tris.resize(n_obj);
+	// object-list slot of every triangle / sphere
+	std::vector<int> slot_of_sphere(d->n_spheres), slot_of_tri(d->n_tris);
+	{
+		std::vector<char> is_sphere(n_obj, 0);
+		for (int j = 0; j < d->n_spheres; j++) {
+			slot_of_sphere[j] = d->sphere_pos ? d->sphere_pos[j] : d->n_tris + j;
+			if (slot_of_sphere[j] < 0 || slot_of_sphere[j] >= n_obj || is_sphere[slot_of_sphere[j]]) { delete s; return -1; }
+			is_sphere[slot_of_sphere[j]] = 1;
+		}
+		int k = 0;
+		for (int i = 0; i < n_obj; i++)
+			if (!is_sphere[i]) slot_of_tri[k++] = i;
+	}
+	for (int j = 0; j < d->n_spheres; j++) {  // Sphere.hpp:6-21, 133-138; texture fields as readObject sets them
+		Tri t;
+		t.kind = 1;
+		t.centerPos = V3(d->spheres[4 * j + 0], d->spheres[4 * j + 1], d->spheres[4 * j + 2]);
+		t.radius = d->spheres[4 * j + 3];
+		t.mat = d->sphere_mat_id[j];
+		if (d->sphere_tex_ids) {
+			for (int k = 0; k < 4; k++) t.tex[k] = d->sphere_tex_ids[4 * j + k];
+			t.isTextureActivated = t.tex[0] != -1 || t.tex[1] != -1 || t.tex[2] != -1 || t.tex[3] != -1;
+		}
+		V3 mn(t.centerPos.x - t.radius, t.centerPos.y - t.radius, t.centerPos.z - t.radius);
+		V3 mx(t.centerPos.x + t.radius, t.centerPos.y + t.radius, t.centerPos.z + t.radius);
+		t.bound = box_of_points(mn, mx);
+		s->tris[slot_of_sphere[j]] = t;
+	}
 	for (int i = 0; i < d->n_tris; i++) {
 		Tri t = make_tri(d->verts + 9 * i, d->normals + 9 * i);
 		t.mat = d->mat_id[i];
@@ -1219,7 +1335,7 @@ int tor_scene_create(const TorSceneDesc* d, void** out) {
 			t.isTextureActivated = t.tex[0] != -1 || t.tex[1] != -1 || t.tex[2] != -1 || t.tex[3] != -1;
 		}
 		t.bound = box_union_pt(box_of_points(t.v0, t.v1), t.v2); // Triangle.hpp:104-107
-		s->tris[i] = t;
+		s->tris[slot_of_tri[i]] = t;
 	}
 	for (int i = 0; i < d->n_mats; i++) s->mats.push_back(from_abi(&d->mats[i]));
 	for (int k = 0; k < 4; k++)
@@ -1235,13 +1351,13 @@ int tor_scene_create(const TorSceneDesc* d, void** out) {
 	s->bkg = L(d->bkg);
 	s->W = d->width; s->H = d->height; s->hfov = d->hfov;
 	s->eye = L(d->eye); s->viewdir = L(d->viewdir); s->updir = L(d->updir);
-	std::vector<int> all(d->n_tris);
-	for (int i = 0; i < d->n_tris; i++) all[i] = i;
+	std::vector<int> all(n_obj);
+	for (int i = 0; i < n_obj; i++) all[i] = i;
 	s->build(all);
-	s->leaf_order.assign(d->n_tris, 0);
+	s->leaf_order.assign(n_obj, 0);
 	int counter = 0;
-	if (d->n_tris > 0) index_leaves(s, 0, counter);
-	for (int i = 0; i < d->n_tris; i++)
+	if (n_obj > 0) index_leaves(s, 0, counter);
+	for (int i = 0; i < n_obj; i++)
 		if (s->mats[s->tris[i].mat].hasEmission()) s->lights.push_back(i);
 	s->camera_frame();
 	*out = s;

@@ -79,7 +79,7 @@ def test_cornell_restated_matches_reference_obj_load():
     assert off == 32
 
 
-SCENES = ["cornell", "cornell_ggxT_mirror", "cornell_ggxR_glass", "veach", "veach_slight", "cornell_degenerate", "cornell_textured"]
+SCENES = ["cornell", "cornell_ggxT_mirror", "cornell_ggxR_glass", "veach", "veach_slight", "cornell_degenerate", "cornell_textured", "cornell_spheres"]
 
 
 def _check_samples(got, want, name):

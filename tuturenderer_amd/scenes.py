@@ -371,10 +371,51 @@ def cornell_textured(width=800, height=800):
     return _camera(s, width, height, eye=(278, 273, -800), viewdir=(0, 0, 1))
 
 
+# ---- spheres ----------------------------------------------------------------------------------------
+# A scene may carry spheres next to its triangles:
+#   spheres        (n, 4)  centre xyz, radius           sphere_mat_id (n,)
+#   sphere_tex_ids (n, 4)  optional map indices         sphere_pos    (n,) optional position of each sphere in the
+#                                                                      combined object list (default: after the triangles)
+def cornell_spheres(width=800, height=800):
+    """The Cornell room (no boxes) with five spheres: a mirror ball, a glass ball, a textured Lambertian ball (albedo +
+    normal map), a rough-glass ball and a small emissive ball next to the ceiling light -- so closest-hit, any-hit,
+    sphere light sampling, getLightPdf on a sphere and the sphere case of changeNormalDir are all on the path.
+    The spheres sit at interleaved positions of the object list."""
+    mats = [
+        material(LAMBERTIAN, CB_WHITE),
+        material(LAMBERTIAN, CB_WHITE, emission=CB_EMISSION),
+        material(LAMBERTIAN, CB_GREEN),
+        material(LAMBERTIAN, CB_RED),
+        material(PERFECT_REFLECTIVE, CB_WHITE),
+        material(PERFECT_REFRACTIVE, CB_WHITE, eta=1.5),
+        material(MICROFACET_T, CB_WHITE, eta=1.5, roughness=0.25),
+        material(LAMBERTIAN, CB_WHITE, emission=(30.0, 24.0, 12.0)),
+    ]
+    part_mat = {"floor": 0, "light": 1, "right": 2, "left": 3}
+    parts = [(v, face_normals(v), part_mat[name]) for name, v in cornell_parts() if name in part_mat]
+    s = _assemble(parts, mats)
+    n_tris = len(s["verts"])
+    s["uvs"] = np.full((n_tris, 6), -1.0, np.float32)
+    s["tex_ids"] = np.full((n_tris, 4), -1, np.int32)
+    s["textures"] = procedural_maps()
+    s["spheres"] = np.array([
+        [400.0, 90.0, 350.0, 90.0],    # mirror
+        [150.0, 70.0, 200.0, 70.0],    # glass
+        [290.0, 60.0, 120.0, 60.0],    # textured Lambertian
+        [420.0, 45.0, 130.0, 45.0],    # rough glass
+        [120.0, 420.0, 400.0, 25.0],   # emissive
+    ], np.float32)
+    s["sphere_mat_id"] = np.array([4, 5, 0, 6, 7], np.int32)
+    s["sphere_tex_ids"] = np.array([[-1, -1, -1, -1], [-1, -1, -1, -1], [0, 0, -1, -1], [-1, -1, -1, -1], [-1, -1, -1, -1]], np.int32)
+    s["sphere_pos"] = np.array([0, 5, 11, n_tris + 3, n_tris + 4], np.int32)
+    return _camera(s, width, height, eye=(278, 273, -800), viewdir=(0, 0, 1))
+
+
 SCENES = {
     "cornell": cornell_box,
     "veach": veach_room,
     "bunny": bunny_box,
     "broom": broom_room,
     "cornell_textured": cornell_textured,
+    "cornell_spheres": cornell_spheres,
 }
