@@ -32,7 +32,7 @@ extern "C" {
 #define TUTU_E_HIP -3          /* a HIP runtime call failed; see tutu_hip_last_error() */
 #define TUTU_E_OOM -4          /* device or host allocation failed */
 #define TUTU_E_BVH_DEPTH -5    /* BVH deeper than the traversal stack (TUTU_MAX_BVH_DEPTH) */
-#define TUTU_E_UNSUPPORTED -6  /* feature outside the PathTracing hot path (textures, spheres) */
+#define TUTU_E_UNSUPPORTED -6  /* feature outside the PathTracing hot path */
 
 #define TUTU_MAX_BVH_DEPTH 30
 
@@ -80,6 +80,21 @@ typedef struct TutuTextureSet {
 	const TutuTexture* maps[4];
 } TutuTextureSet;
 
+/* Optional spheres: the `sphere cx cy cz r` objects of config.txt (Sphere.hpp:6-21; PPMGenerator.hpp:358-402).
+ * Scene::objList is then the triangles with the spheres inserted at the given object-list positions (ascending;
+ * NULL = all spheres after the triangles) -- the order matters because BVHAccel::recursiveBuild sorts that list and
+ * because the light list is taken in that order.  With spheres present, every "triangle index" this ABI reports
+ * (TutuHit::tri, eval_sample_light's tri) is an index into the combined object list.
+ * Reference quirks kept: the quadratic assumes a unit direction (A = 1) even for the un-normalised mirror/refraction
+ * directions; Sphere::getArea is pi*r*r; Sphere::samplePoint draws the two angles uniformly. */
+typedef struct TutuSphereSet {
+	uint32_t n_spheres;
+	const float* spheres;    /* n_spheres*4: centre xyz, radius */
+	const int32_t* mat_id;   /* n_spheres: index into TutuSceneDesc::mats */
+	const int32_t* tex_ids;  /* n_spheres*4 (diffuse, normal, roughness, metallic map; -1 = none) or NULL */
+	const int32_t* pos;      /* n_spheres object-list positions or NULL */
+} TutuSphereSet;
+
 typedef struct TutuSceneDesc {
 	uint32_t n_tris;
 	const float* verts;    /* n_tris*9: v0 v1 v2 (Triangle.hpp:11-14) */
@@ -90,6 +105,7 @@ typedef struct TutuSceneDesc {
 	float eta;    /* g->eta: 4th number of the `bkgcolor` keyword */
 	float bkg[3]; /* g->bkgcolor */
 	const TutuTextureSet* textures; /* NULL: no textured triangles (textureModify, IIntegrator.hpp:89-127, never runs) */
+	const TutuSphereSet* spheres;   /* NULL: triangles only */
 } TutuSceneDesc;
 
 /* The camera keywords of config.txt (imsize / eye / viewdir / hfov / updir; PPMGenerator.hpp:492-540). */

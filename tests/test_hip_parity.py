@@ -19,7 +19,7 @@ from oracle import parity_cases as pc
 
 pytestmark = pytest.mark.gpu
 
-SCENES = ["cornell", "cornell_ggxT_mirror", "cornell_ggxR_glass", "veach", "veach_slight", "cornell_degenerate", "cornell_textured"]
+SCENES = ["cornell", "cornell_ggxT_mirror", "cornell_ggxR_glass", "veach", "veach_slight", "cornell_degenerate", "cornell_textured", "cornell_spheres"]
 
 
 @pytest.fixture(scope="module")
@@ -71,8 +71,14 @@ def test_closest_and_any_hit_bit_exact(tr, port, name):
         idx = np.nonzero(h)[0]
         xi = pc.xi24(r, (len(idx), 3))
         ltri, lpos, lnrm, lpdf = ctx.eval_sample_light(xi)
-        assert bit_equal(ltri, z["scene.light_tri"]) and bit_equal(lpos, z["scene.light_pos"])
-        assert bit_equal(lnrm, z["scene.light_nrm"]) and bit_equal(lpdf, z["scene.light_pdf"])
+        assert bit_equal(ltri, z["scene.light_tri"]) and bit_equal(lpdf, z["scene.light_pdf"])
+        # a point on a sphere light goes through cosf/sinf (Sphere.hpp:152-158): a few ulp; triangle lights are exact
+        on_sphere = np.isin(ltri, np.asarray(sc.get("sphere_pos", []), np.int32))
+        assert bit_equal(lpos[~on_sphere], z["scene.light_pos"][~on_sphere]) and bit_equal(lnrm[~on_sphere], z["scene.light_nrm"][~on_sphere])
+        if on_sphere.any():
+            assert np.abs(lpos[on_sphere] - z["scene.light_pos"][on_sphere]).max() < 1e-4
+            assert np.abs(lnrm[on_sphere] - z["scene.light_nrm"][on_sphere]).max() < 1e-5
+        lpos, lnrm = z["scene.light_pos"], z["scene.light_nrm"]  # shadow targets: the reference's own points
         pos, Ns = want["pos"], want["Ns"]
         orig = (pos[idx] + np.float32(0.0005) * Ns[idx] * np.sign((Ns[idx] * -D[idx]).sum(1, keepdims=True))).astype(np.float32)
         target = (lpos + np.float32(0.0005) * lnrm).astype(np.float32)
@@ -224,12 +230,15 @@ def test_per_sample_radiance_matched_seed(tr, port, name):
     ok = err <= 1e-4 * scale + 1e-6
     frac_bad = 1.0 - ok.mean()
     print(f"{name}: NaN samples {int(nan_w.sum())}; diverged {int((~ok).sum())}/{len(ok)} max rel err of the rest {float((err[ok] / scale[ok]).max()):.2e}")
-    assert frac_bad < 5e-3, frac_bad
+    # A shadow ray towards a point sampled on a sphere light ends 5e-4 in front of that sphere, and the sphere's own
+    # float quadratic (error ~3e-4 at room-scale distances) decides whether the light blocks itself: the reference's
+    # answer there is rounding noise, and a last-bit difference upstream flips it.  1 % instead of 0.5 % for that scene.
+    assert frac_bad < (1e-2 if name == "cornell_spheres" else 5e-3), frac_bad
     assert abs(L[fin].mean() - want[fin].mean()) < 2e-2 * max(want[fin].mean(), 1e-3)
     S.close()
 
 
-@pytest.mark.parametrize("name", ["cornell", "cornell_ggxR_glass", "veach_slight", "cornell_degenerate", "cornell_textured"])
+@pytest.mark.parametrize("name", ["cornell", "cornell_ggxR_glass", "veach_slight", "cornell_degenerate", "cornell_textured", "cornell_spheres"])
 def test_image_matched_seed_l2(tr, name):
     sc, key1 = _scene(name)
     z = np.load(golden_path(f"scene_{name}.npz"))

@@ -30,7 +30,35 @@ class TutuError(RuntimeError):
 class SceneDesc(C.Structure):
     _fields_ = [("n_tris", C.c_uint32), ("verts", C.c_void_p), ("normals", C.c_void_p), ("mat_id", C.c_void_p),
                 ("n_mats", C.c_uint32), ("mats", C.c_void_p), ("eta", C.c_float), ("bkg", C.c_float * 3),
-                ("textures", C.c_void_p)]
+                ("textures", C.c_void_p), ("spheres", C.c_void_p)]
+
+
+class SphereSet(C.Structure):
+    _fields_ = [("n_spheres", C.c_uint32), ("spheres", C.c_void_p), ("mat_id", C.c_void_p), ("tex_ids", C.c_void_p),
+                ("pos", C.c_void_p)]
+
+
+def pack_sphere_set(scene):
+    """scene["spheres"] (n,4) centre+radius, scene["sphere_mat_id"] (n,), optional scene["sphere_tex_ids"] (n,4),
+    scene["sphere_pos"] (n,) -> (TutuSphereSet or None, objects to keep alive)"""
+    if scene.get("spheres") is None or len(scene["spheres"]) == 0:
+        return None, []
+    sp = np.ascontiguousarray(scene["spheres"], dtype=np.float32).reshape(-1, 4)
+    mid = np.ascontiguousarray(scene["sphere_mat_id"], dtype=np.int32)
+    if len(mid) != len(sp):
+        raise ValueError("sphere_mat_id must have one entry per sphere")
+    ss = SphereSet()
+    ss.n_spheres, ss.spheres, ss.mat_id = len(sp), sp.ctypes.data, mid.ctypes.data
+    keep = [sp, mid]
+    if scene.get("sphere_tex_ids") is not None:
+        t = np.ascontiguousarray(scene["sphere_tex_ids"], dtype=np.int32).reshape(-1, 4)
+        ss.tex_ids = t.ctypes.data
+        keep.append(t)
+    if scene.get("sphere_pos") is not None:
+        q = np.ascontiguousarray(scene["sphere_pos"], dtype=np.int32)
+        ss.pos = q.ctypes.data
+        keep.append(q)
+    return ss, keep
 
 
 class Texture(C.Structure):
@@ -201,6 +229,8 @@ class Context:
         d.bkg = (C.c_float * 3)(*[float(x) for x in scene.get("bkg", (0, 0, 0))])
         self._texture_set, self._texture_keep = pack_texture_set(scene)
         d.textures = C.addressof(self._texture_set) if self._texture_set is not None else None
+        self._sphere_set, self._sphere_keep = pack_sphere_set(scene)
+        d.spheres = C.addressof(self._sphere_set) if self._sphere_set is not None else None
         self.h = C.c_void_p()
         _check(self.lib.tutu_hip_create(C.byref(d), C.c_int(device), C.byref(self.h)), "tutu_hip_create")
         self.cam = camera_frame(scene)

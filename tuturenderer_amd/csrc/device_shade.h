@@ -23,6 +23,7 @@ namespace tutu {
 
 #define TUTU_CLASS_EMISSIVE 6
 #define TUTU_CLASS_MISS 7
+#define TUTU_CLS_SPHERE 0x100  // GpuTriShade::cls flag: the record describes a sphere (n0 = centre, n1.x = radius)
 
 #define TUTU_FLAG_PREV_REFRACTIVE 1u  // vertex d-1 was PERFECT_REFRACTIVE / MICROFACET_T (calcForRefractive)
 #define TUTU_FLAG_PREV_MIRROR_PM1 2u  // vertex d-1 PERFECT_REFLECTIVE with mat_pdf == 1 (PathTracing.hpp:252-253)
@@ -137,6 +138,26 @@ TUTU_DEV LightSample sample_light(const ShadeTabs& tb, int size, Rng& rng) {
 	const float4 f = tb.lights[6 * index + 5];
 	const V3 v0 = mk(a.x, a.y, a.z), v1 = mk(a.w, b.x, b.y), v2 = mk(b.z, b.w, c.x);
 	const V3 n0 = mk(c.y, c.z, c.w), n1 = mk(d.x, d.y, d.z), n2 = mk(d.w, e.x, e.y);
+	if (__float_as_int(f.w)) {  // sphere light: v0 = centre, v1.x = radius.  Sphere::samplePoint, Sphere.hpp:144-163 --
+		// the two angles are drawn uniformly, not the area [sic]
+		const float theta = rng.next() * 2 * TUTU_PI;
+		const float phi = rng.next() * TUTU_PI;
+		// The point feeds a shadow ray that grazes the sphere it was sampled on: the sphere's own quadratic decides
+		// "blocked" within a few 1e-4 of the ray length, so a last-bit difference in sinf/cosf flips whole terms.
+		// Double-precision sin/cos rounded once reproduce the host's (correctly rounded in all but ~1e-3 of the
+		// cases) float results; this runs once per sample that picks a sphere light, not in the common path.
+		const float ct = (float)cos((double)theta), st = (float)sin((double)theta);
+		const float cp = (float)cos((double)phi), sp_ = (float)sin((double)phi);
+		LightSample s;
+		s.pos.x = v0.x + v1.x * ct * sp_;
+		s.pos.y = v0.y + v1.x * st * sp_;
+		s.pos.z = v0.z + v1.x * cp;
+		s.N = normalized(s.pos - v0);
+		s.emission = mk(e.z, e.w, f.x);
+		s.pdf = f.y;
+		s.tri = __float_as_int(f.z);
+		return s;
+	}
 	float u = rng.next();
 	float v = rng.next() * (1 - u);  // non-uniform over the triangle [sic]
 	LightSample s;
@@ -168,22 +189,38 @@ TUTU_DEV V3 texture_rgb(const SceneDev& sc, int list, int id, float u, float v) 
 
 // textureModify + changeNormalDir (triangle case), IIntegrator.hpp:27-63, 89-127; textPos as Triangle::intersect
 // interpolates it (Triangle.hpp:61-68).  Changes the per-hit material copy and the shading normal.
-TUTU_DEV void texture_modify(const SceneDev& sc, int tri, float b1, float b2, Mat& m, V3& Ns) {
+// For a sphere (is_sphere) textPos is the spherical parametrisation of Sphere::intersect (Sphere.hpp:54-74) and the
+// tangent frame is the SPEHRE case of changeNormalDir (IIntegrator.hpp:65-79), built from Ng.
+TUTU_DEV void texture_modify(const SceneDev& sc, int tri, float b1, float b2, bool is_sphere, V3 Ng, Mat& m, V3& Ns) {
 	const float4 x3 = sc.tri_tex[4 * tri + 3];
 	const int i_diffuse = __float_as_int(x3.x), i_normal = __float_as_int(x3.y);
 	const int i_rough = __float_as_int(x3.z), i_metal = __float_as_int(x3.w);
 	if (i_diffuse == -1 && i_normal == -1 && i_rough == -1 && i_metal == -1) return;  // !isTextureActivated
 	const float4 x0 = sc.tri_tex[4 * tri + 0];
 	const float4 x1 = sc.tri_tex[4 * tri + 1];
-	const float w0 = (1 - b1 - b2);
-	const float tu = (x0.x * w0 + x0.z * b1) + x1.x * b2;
-	const float tv = (x0.y * w0 + x0.w * b1) + x1.y * b2;
+	float tu, tv;
+	if (is_sphere) {
+		const float phi = acosf(Ng.z);
+		tv = phi / TUTU_PI;
+		float theta = atan2f(Ng.y, Ng.x);
+		if (theta < 0) theta += 2 * TUTU_PI;
+		tu = (theta / (2.f * TUTU_PI));
+	} else {
+		const float w0 = (1 - b1 - b2);
+		tu = (x0.x * w0 + x0.z * b1) + x1.x * b2;
+		tv = (x0.y * w0 + x0.w * b1) + x1.y * b2;
+	}
 	if (i_diffuse != -1) m.diffuse = texture_rgb(sc, 0, i_diffuse, tu, tv);
 	if (i_normal != -1) {
 		const float4 x2 = sc.tri_tex[4 * tri + 2];
 		const V3 color = texture_rgb(sc, 1, i_normal, tu, tv);
-		const V3 T = mk(x1.z, x1.w, x2.x), B = mk(x2.y, x2.z, x2.w);
-		const V3 nDir = normalized(Ns);
+		V3 T = mk(x1.z, x1.w, x2.x), B = mk(x2.y, x2.z, x2.w);
+		V3 nDir = normalized(Ns);
+		if (is_sphere) {
+			nDir = Ng;
+			T = mk(-nDir.y / sqrtf(nDir.x * nDir.x + nDir.y * nDir.y), nDir.x / sqrtf(nDir.x * nDir.x + nDir.y * nDir.y), 0.f);
+			B = cross(nDir, T);
+		}
 		V3 res;
 		res.x = T.x * color.x + B.x * color.y + nDir.x * color.z;
 		res.y = T.y * color.x + B.y * color.y + nDir.y * color.z;
@@ -206,9 +243,10 @@ TUTU_DEV void texture_modify(const SceneDev& sc, int tri, float b1, float b2, Ma
 // path's slot as soon as they exist, so few values stay live across the BSDF code.
 enum ShadeMode { SHADE_FIRST = 0, SHADE_LAMBERT = 1, SHADE_MIRROR = 2, SHADE_REFRACT = 3, SHADE_GGXR = 4, SHADE_TERMINAL = 5 };
 
-// TEX: the scene has textured triangles (textureModify runs between the refractive test and everything else,
-// PathTracing.hpp:152-158); the untextured instantiations do not contain that code at all.
-template <int MODE, int TAB, bool TEX>
+// EXT: the scene has textured objects (textureModify runs between the refractive test and everything else,
+// PathTracing.hpp:152-158) and/or spheres (hit point and normals from the sphere record, Sphere.hpp:44-53); the
+// plain instantiations do not contain that code at all.
+template <int MODE, int TAB, bool EXT>
 __global__ void __launch_bounds__(256) k_shade(PassParams pp) {
 	constexpr bool FIRST = MODE == SHADE_FIRST;
 	const SceneDev& sc = pp.sc;
@@ -307,6 +345,7 @@ __global__ void __launch_bounds__(256) k_shade(PassParams pp) {
 		V3 pos = mk1(0.f), Ns = mk1(0.f), Ng = mk1(0.f);
 		int mat_id = 0;
 		float hit_light_pdf = 0.f;
+		bool is_sphere = false;
 		if (hit) {
 			const float4 s0 = tb.tris[4 * tri + 0];
 			const float4 s1 = tb.tris[4 * tri + 1];
@@ -317,7 +356,13 @@ __global__ void __launch_bounds__(256) k_shade(PassParams pp) {
 			mat_id = __float_as_int(s3.x);
 			hit_light_pdf = s3.z;
 			pos = o + t * d;
-			Ns = normalized((n0 * (1 - b1 - b2)) + n1 * b1 + n2 * b2);
+			if (EXT && (__float_as_int(s3.w) & TUTU_CLS_SPHERE)) {  // n0 = centre
+				is_sphere = true;
+				Ng = normalized(pos - n0);
+				Ns = Ng;
+			} else {
+				Ns = normalized((n0 * (1 - b1 - b2)) + n1 * b1 + n2 * b2);
+			}
 		}
 
 		// ---- connect: finish vertex depth-1 now that the hit of its BSDF ray is known (PathTracing.hpp:234-278)
@@ -389,7 +434,7 @@ __global__ void __launch_bounds__(256) k_shade(PassParams pp) {
 			}
 			const V3 wo = -d;
 			const bool refractive = m.type == TUTU_PERFECT_REFRACTIVE || m.type == TUTU_MICROFACET_T;
-			if (TEX && !refractive) texture_modify(sc, tri, b1, b2, m, Ns);  // :157-158
+			if (EXT && sc.has_tex && !refractive) texture_modify(sc, tri, b1, b2, is_sphere, Ng, m, Ns);  // :157-158
 			if (terminal) {
 				if (m.type == TUTU_UNLIT) {  // :161
 					Ladd = beta * m.diffuse;
@@ -551,7 +596,7 @@ struct TraceParams {
 	int stack_entries;
 };
 
-template <typename S, bool ANY>
+template <typename S, bool ANY, bool SPH>
 TUTU_DEV void trace_persistent(const S& ss, const TraceParams& tp, int* stack, const uint8_t* tri_class) {
 	const SceneDev& sc = tp.sc;
 	const int lane = __lane_id();
@@ -652,9 +697,9 @@ TUTU_DEV void trace_persistent(const S& ss, const TraceParams& tp, int* stack, c
 			const bool has_pend = pend != TUTU_TRAV_IDLE;
 			const bool on_leaf = cur < 0 && cur > TUTU_TRAV_IDLE;
 			if (has_pend || on_leaf) {
-				const int ti = has_pend ? ~pend : ~cur;
+				int ti;
 				float t, u, v;
-				const bool h = tri_test(ss, ti, r, t, u, v);
+				const bool h = leaf_test<SPH>(ss, has_pend ? ~pend : ~cur, r, ti, t, u, v);
 				if (ANY) {
 					if (h && t < dis && !float_equal(t, dis)) blocked = true;  // BVH.hpp:186
 				} else if (h && (t < best_t || (t == best_t && ti < best_tri))) {
@@ -703,7 +748,8 @@ TUTU_DEV void trace_persistent(const S& ss, const TraceParams& tp, int* stack, c
 }
 
 // LDS carve-up with the per-triangle class table appended to the staged scene
-template <bool LDS_SCENE, bool ANY>
+// SPH: the scene has sphere leaves (the triangle-only instantiations do not contain the sphere test)
+template <bool LDS_SCENE, bool ANY, bool SPH>
 __global__ void __launch_bounds__(256) k_trace(TraceParams tp) {
 	extern __shared__ int lds[];  // [stack entries][256 lanes] | optional scene copy | optional class table
 	if (LDS_SCENE) {
@@ -713,12 +759,12 @@ __global__ void __launch_bounds__(256) k_trace(TraceParams tp) {
 			for (int i = threadIdx.x; i < tp.sc.n_tris; i += blockDim.x) cls[i] = tp.tri_class[i];
 			__syncthreads();
 		}
-		trace_persistent<SceneLds, ANY>(sl, tp, lds + threadIdx.x, cls);
+		trace_persistent<SceneLds, ANY, SPH>(sl, tp, lds + threadIdx.x, cls);
 	} else {
 		SceneGlobal sg;
 		sg.nodes = tp.sc.nodes;
 		sg.tris = tp.sc.tri_isect;
-		trace_persistent<SceneGlobal, ANY>(sg, tp, lds + threadIdx.x, tp.tri_class);
+		trace_persistent<SceneGlobal, ANY, SPH>(sg, tp, lds + threadIdx.x, tp.tri_class);
 	}
 }
 

@@ -49,6 +49,7 @@ struct SceneDev {
 	const float4* texels;   // rgb | pad per texel, all maps back to back
 	const int4* tex_desc;   // offset, width, height, size per map; the four lists back to back
 	int tex_base[4];        // first descriptor of the diffuse / normal / roughness / metallic list
+	int has_tex, has_spheres;
 };
 
 struct SceneGlobal {
@@ -144,6 +145,61 @@ TUTU_DEV bool tri_test(const S& sc, int ti, const RayPre& r, float& t, float& u,
 	return (t > 0 && 1 - u - v > 0 && u > 0 && v > 0);
 }
 
+// Sphere leaves: the leaf reference carries TUTU_SPHERE_BIT, the 48-B record holds centre | radius | radius*radius.
+// Sphere::intersect, Sphere.hpp:26-131 + solveQuadratic, global.hpp:147-167: A = 1 whatever the length of dir [sic];
+// C is computed through pow(float, int), i.e. in double, and rounded to float once.
+#define TUTU_SPHERE_BIT 0x40000000
+template <typename S>
+TUTU_DEV bool sphere_test(const S& sc, int pi, const RayPre& r, float& t) {
+	float4 q0, q1, q2;
+	sc.tri(pi, q0, q1, q2);
+	const float ox = r.o.x - q0.x, oy = r.o.y - q0.y, oz = r.o.z - q0.z;
+	const float A = 1.f;
+	const float B = 2 * (r.d.x * ox + r.d.y * oy + r.d.z * oz);
+	const double dx = (double)ox, dy = (double)oy, dz = (double)oz;
+	const float C = (float)(dx * dx + dy * dy + dz * dz - (double)q1.x);  // q1.x = radius * radius (float product)
+	const float discriminant = B * B - 4 * A * C;
+	float t1, t2;
+	if (discriminant < 0) {
+		t1 = FLT_MAX;
+		t2 = FLT_MAX;
+	} else if (discriminant == 0) {
+		t1 = (-B + sqrtf(discriminant)) / (2 * A);
+		t2 = t1;
+	} else {
+		t1 = (-B + sqrtf(discriminant)) / (2 * A);
+		t2 = (-B - sqrtf(discriminant)) / (2 * A);
+	}
+	if (t1 > t2) {
+		const float s = t1;
+		t1 = t2;
+		t2 = s;
+	}
+	if (float_equal(t1, FLT_MAX) && float_equal(t2, FLT_MAX)) return false;
+	if (float_equal(t1, t2)) {
+		if (t1 < 0) return false;
+		t = t1;
+		return true;
+	}
+	if (t1 > 0 && t2 > 0) t = t1;
+	else if (t1 > 0 && t2 < 0) t = t1;
+	else if (t1 < 0 && t2 > 0) t = t2;
+	else return false;
+	return true;
+}
+// one leaf: p = ~ref.  Returns the clean leaf-order index through `pi`.
+template <bool SPH, typename S>
+TUTU_DEV bool leaf_test(const S& sc, int p, const RayPre& r, int& pi, float& t, float& u, float& v) {
+	if (SPH && (p & TUTU_SPHERE_BIT)) {
+		pi = p & ~TUTU_SPHERE_BIT;
+		u = 0.f;
+		v = 0.f;
+		return sphere_test(sc, pi, r, t);
+	}
+	pi = p;
+	return tri_test(sc, p, r, t, u, v);
+}
+
 struct ChildTest {
 	bool hl, hr;
 	float tl, tr;
@@ -198,9 +254,9 @@ TUTU_DEV void trace_closest(const S& ss, const SceneDev& sc, V3 o, V3 d, int* st
 			}
 		}
 		if (cur == TUTU_TRAV_DONE) break;
-		const int ti = ~cur;
+		int ti;
 		float t, u, v;
-		if (tri_test(ss, ti, r, t, u, v)) {
+		if (leaf_test<true>(ss, ~cur, r, ti, t, u, v)) {
 			if (t < best_t || (t == best_t && ti < best_tri)) {
 				best_t = t;
 				best_u = u;
@@ -246,8 +302,9 @@ TUTU_DEV bool trace_any(const S& ss, const SceneDev& sc, V3 orig, V3 lightPos, i
 			}
 		}
 		if (cur == TUTU_TRAV_DONE) break;
+		int ti;
 		float t, u, v;
-		if (tri_test(ss, ~cur, r, t, u, v)) {
+		if (leaf_test<true>(ss, ~cur, r, ti, t, u, v)) {
 			if (t < dis && !float_equal(t, dis)) {
 				blocked = true;
 				break;

@@ -11,6 +11,9 @@ namespace tutu {
 
 namespace {
 
+const int32_t kSphereBit = 0x40000000;  // device_trace.h: TUTU_SPHERE_BIT
+const int32_t kClsSphere = 0x100;       // device_shade.h: TUTU_CLS_SPHERE
+
 struct Box {
 	float mn[3], mx[3];
 };
@@ -126,32 +129,68 @@ inline void normalize3(float* v) {  // Vector.hpp:213-220
 
 }  // namespace
 
+namespace {
+inline Box triangle_box(const float* v) { return box_union_pt(box2(v, v + 3), v + 6); }  // Triangle::initializeBound  Triangle.hpp:104-107
+inline Box sphere_box(const float* c4) {                                                  // Sphere::initializeBound  Sphere.hpp:133-138
+	const float mn[3] = {c4[0] - c4[3], c4[1] - c4[3], c4[2] - c4[3]};
+	const float mx[3] = {c4[0] + c4[3], c4[1] + c4[3], c4[2] + c4[3]};
+	return box2(mn, mx);
+}
+int build_tree_of_boxes(const std::vector<Box>& tb, std::vector<BuildNode>& out, uint32_t* depth) {
+	out.clear();
+	if (depth) *depth = 0;
+	if (tb.empty()) return TUTU_OK;
+	std::vector<int32_t> idx(tb.size());
+	for (size_t i = 0; i < tb.size(); i++) idx[i] = (int32_t)i;
+	out.reserve(2 * tb.size());
+	Builder b{tb, out};
+	b.build(idx.data(), idx.data() + tb.size(), 0);
+	if (depth) *depth = b.max_depth;
+	return TUTU_OK;
+}
+}  // namespace
+
 int build_reference_tree(uint32_t n_tris, const float* verts, std::vector<BuildNode>& out, uint32_t* depth) {
 	out.clear();
 	if (depth) *depth = 0;
 	if (n_tris == 0) return TUTU_OK;
 	if (!verts) return TUTU_E_INVALID;
 	std::vector<Box> tb(n_tris);
-	for (uint32_t i = 0; i < n_tris; i++) {
-		const float* v = verts + 9 * (size_t)i;
-		tb[i] = box_union_pt(box2(v, v + 3), v + 6);  // Triangle::initializeBound  Triangle.hpp:104-107
-	}
-	std::vector<int32_t> idx(n_tris);
-	for (uint32_t i = 0; i < n_tris; i++) idx[i] = (int32_t)i;
-	out.reserve(2 * (size_t)n_tris);
-	Builder b{tb, out};
-	b.build(idx.data(), idx.data() + n_tris, 0);
-	if (depth) *depth = b.max_depth;
-	return TUTU_OK;
+	for (uint32_t i = 0; i < n_tris; i++) tb[i] = triangle_box(verts + 9 * (size_t)i);
+	return build_tree_of_boxes(tb, out, depth);
 }
 
 int build_host_scene(const TutuSceneDesc* d, HostScene& hs) {
 	if (!d) return TUTU_E_INVALID;
-	const uint32_t n = d->n_tris;
-	if (n > 0 && (!d->verts || !d->normals || !d->mat_id)) return TUTU_E_INVALID;
+	const uint32_t n_tri_in = d->n_tris;
+	if (n_tri_in > 0 && (!d->verts || !d->normals || !d->mat_id)) return TUTU_E_INVALID;
 	if (d->n_mats > 0 && !d->mats) return TUTU_E_INVALID;
-	for (uint32_t i = 0; i < n; i++)
+	for (uint32_t i = 0; i < n_tri_in; i++)
 		if (d->mat_id[i] < 0 || (uint32_t)d->mat_id[i] >= d->n_mats) return TUTU_E_INVALID;
+	// Scene::objList: the triangles with the spheres inserted at their positions.  obj_tri[o] / obj_sph[o] = index into
+	// the caller's triangle / sphere arrays (-1 = the other kind).
+	const TutuSphereSet* ss = d->spheres;
+	const uint32_t n_sph = ss ? ss->n_spheres : 0;
+	if (n_sph > 0 && (!ss->spheres || !ss->mat_id)) return TUTU_E_INVALID;
+	if ((uint64_t)n_tri_in + n_sph >= (uint64_t)0x3FFFFFFF) return TUTU_E_INVALID;
+	const uint32_t n = n_tri_in + n_sph;
+	std::vector<int32_t> obj_tri(n, -1), obj_sph(n, -1);
+	for (uint32_t j = 0; j < n_sph; j++) {
+		if (ss->mat_id[j] < 0 || (uint32_t)ss->mat_id[j] >= d->n_mats) return TUTU_E_INVALID;
+		const int64_t pos = ss->pos ? (int64_t)ss->pos[j] : (int64_t)n_tri_in + j;
+		if (pos < 0 || pos >= (int64_t)n || obj_sph[(size_t)pos] != -1) return TUTU_E_INVALID;
+		obj_sph[(size_t)pos] = (int32_t)j;
+	}
+	{
+		int32_t k = 0;
+		for (uint32_t o = 0; o < n; o++)
+			if (obj_sph[o] < 0) obj_tri[o] = k++;
+	}
+	hs.has_spheres = n_sph > 0;
+	if (n_sph > 0 && ss->tex_ids && !d->textures)
+		for (size_t k = 0; k < 4 * (size_t)n_sph; k++)
+			if (ss->tex_ids[k] != -1) return TUTU_E_INVALID;  // a map index without any map list
+	auto mat_of = [&](uint32_t o) -> int32_t { return obj_sph[o] >= 0 ? ss->mat_id[obj_sph[o]] : d->mat_id[obj_tri[o]]; };
 
 	hs.eta = d->eta;
 	memcpy(hs.bkg, d->bkg, sizeof(hs.bkg));
@@ -172,7 +211,13 @@ int build_host_scene(const TutuSceneDesc* d, HostScene& hs) {
 	}
 
 	std::vector<BuildNode> tree;
-	int rc = build_reference_tree(n, d->verts, tree, &hs.depth);
+	int rc;
+	{
+		std::vector<Box> tb(n);
+		for (uint32_t o = 0; o < n; o++)
+			tb[o] = obj_sph[o] >= 0 ? sphere_box(ss->spheres + 4 * (size_t)obj_sph[o]) : triangle_box(d->verts + 9 * (size_t)obj_tri[o]);
+		rc = build_tree_of_boxes(tb, tree, &hs.depth);
+	}
 	if (rc != TUTU_OK) return rc;
 	if (hs.depth > TUTU_MAX_BVH_DEPTH) return TUTU_E_BVH_DEPTH;
 
@@ -209,7 +254,8 @@ int build_host_scene(const TutuSceneDesc* d, HostScene& hs) {
 	}
 	auto ref_of = [&](int32_t bn) -> int32_t {
 		if (tree[bn].left >= 0 || tree[bn].right >= 0) return inner_id[bn];
-		return ~hs.leaf_of_orig[tree[bn].tri];
+		const int32_t leaf = hs.leaf_of_orig[tree[bn].tri];
+		return obj_sph[tree[bn].tri] >= 0 ? ~(leaf | kSphereBit) : ~leaf;  // device_trace.h: TUTU_SPHERE_BIT
 	};
 	for (size_t i = 0; i < tree.size(); i++) {
 		if (inner_id[i] < 0) continue;
@@ -237,8 +283,9 @@ int build_host_scene(const TutuSceneDesc* d, HostScene& hs) {
 	// lights: PPMGenerator::initializeLights order = object-list order (PPMGenerator.hpp:317-324)
 	std::vector<int32_t> light_orig;
 	for (uint32_t i = 0; i < n; i++)
-		if (hs.mats[d->mat_id[i]].has_emission) light_orig.push_back((int32_t)i);
+		if (hs.mats[mat_of(i)].has_emission) light_orig.push_back((int32_t)i);
 	const int size = (int)light_orig.size();
+	const float kPi = 3.1415926535897f;  // the reference's M_PI (global.hpp:15)
 
 	hs.tri_isect.resize(n);
 	hs.tri_shade.resize(n);
@@ -246,8 +293,31 @@ int build_host_scene(const TutuSceneDesc* d, HostScene& hs) {
 	std::vector<float> area(n, 0.f);
 	for (uint32_t li = 0; li < n; li++) {
 		const int32_t o = order[li];
-		const float* v = d->verts + 9 * (size_t)o;
-		const float* nn = d->normals + 9 * (size_t)o;
+		if (obj_sph[o] >= 0) {
+			// sphere leaf: centre | radius | radius*radius in the intersection record, centre | radius in the shading record
+			const float* c4 = ss->spheres + 4 * (size_t)obj_sph[o];
+			GpuTriIsect& t = hs.tri_isect[li];
+			memset(&t, 0, sizeof(t));
+			memcpy(t.v0, c4, 12);
+			t.e1[0] = c4[3];
+			t.e1[1] = c4[3] * c4[3];  // `radius * radius` of Sphere.hpp:30, a float product
+			area[li] = c4[3] * c4[3] * kPi;  // Sphere::getArea [sic]  Sphere.hpp:140-142
+			GpuTriShade& s = hs.tri_shade[li];
+			memset(&s, 0, sizeof(s));
+			memcpy(s.n0, c4, 12);
+			s.n1[0] = c4[3];
+			s.mat = mat_of((uint32_t)o);
+			s.orig = o;
+			s.light_pdf = hs.mats[s.mat].has_emission ? 1 / (size * area[li]) : 0.f;
+			const GpuMaterial& gm = hs.mats[s.mat];
+			int cls = (gm.has_emission && gm.type != TUTU_PERFECT_REFRACTIVE && gm.type != TUTU_MICROFACET_T) ? 6 : gm.type;
+			if (cls < 0 || cls > 6) cls = TUTU_UNLIT;
+			hs.tri_class[li] = (uint8_t)cls;
+			s.cls = cls | kClsSphere;
+			continue;
+		}
+		const float* v = d->verts + 9 * (size_t)obj_tri[o];
+		const float* nn = d->normals + 9 * (size_t)obj_tri[o];
 		GpuTriIsect& t = hs.tri_isect[li];
 		memcpy(t.v0, v, 12);
 		sub3(v + 3, v, t.e1);      // E1 = v1 - v0            Triangle.hpp:25
@@ -261,7 +331,7 @@ int build_host_scene(const TutuSceneDesc* d, HostScene& hs) {
 		memcpy(s.n1, nn + 3, 12);
 		memcpy(s.n2, nn + 6, 12);
 		memcpy(s.ng, t.n, 12);
-		s.mat = d->mat_id[o];
+		s.mat = mat_of((uint32_t)o);
 		s.orig = o;
 		s.light_pdf = hs.mats[s.mat].has_emission ? 1 / (size * area[li]) : 0.f;  // getLightPdf  IIntegrator.hpp:166-167
 		{
@@ -280,7 +350,7 @@ int build_host_scene(const TutuSceneDesc* d, HostScene& hs) {
 	hs.tex_desc.clear();
 	if (d->textures) {
 		const TutuTextureSet* ts = d->textures;
-		if (n > 0 && (!ts->uvs || !ts->tex_ids)) return TUTU_E_INVALID;
+		if (n_tri_in > 0 && (!ts->uvs || !ts->tex_ids)) return TUTU_E_INVALID;
 		for (int k = 0; k < 4; k++) {
 			hs.tex_base[k] = (int32_t)hs.tex_desc.size();
 			if (ts->n_maps[k] > 0 && !ts->maps[k]) return TUTU_E_INVALID;
@@ -309,21 +379,26 @@ int build_host_scene(const TutuSceneDesc* d, HostScene& hs) {
 		hs.tri_tex.resize(n);
 		for (uint32_t li = 0; li < n; li++) {
 			const int32_t o = order[li];
-			const float* v = d->verts + 9 * (size_t)o;
-			const float* uv = ts->uvs + 6 * (size_t)o;
+			const bool sph = obj_sph[o] >= 0;
+			static const float no_uv[6] = {-1.f, -1.f, -1.f, -1.f, -1.f, -1.f};
+			static const float no_v[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+			const float* v = sph ? no_v : d->verts + 9 * (size_t)obj_tri[o];
+			const float* uv = sph ? no_uv : ts->uvs + 6 * (size_t)obj_tri[o];
 			GpuTriTex& tt = hs.tri_tex[li];
 			memcpy(tt.uv0, uv, 8);
 			memcpy(tt.uv1, uv + 2, 8);
 			memcpy(tt.uv2, uv + 4, 8);
 			for (int k = 0; k < 4; k++) {
-				const int32_t id = ts->tex_ids[4 * (size_t)o + k];
+				int32_t id;
+				if (sph) id = ss->tex_ids ? ss->tex_ids[4 * (size_t)obj_sph[o] + k] : -1;
+				else id = ts->tex_ids[4 * (size_t)obj_tri[o] + k];
 				// the reference exits when an index is beyond its list (IIntegrator.hpp:92-96, 106-110, 117-121)
 				if (id < -1 || (id >= 0 && (uint32_t)id >= ts->n_maps[k])) return TUTU_E_INVALID;
 				tt.ids[k] = id;
 			}
 			memset(tt.T, 0, 12);
 			memset(tt.B, 0, 12);
-			if (tt.ids[1] != -1) {  // changeNormalDir, IIntegrator.hpp:36-54
+			if (tt.ids[1] != -1 && !sph) {  // changeNormalDir, IIntegrator.hpp:36-54 (a sphere's frame depends on the hit)
 				float e1[3], e2[3];
 				sub3(v + 3, v, e1);
 				sub3(v + 6, v, e2);
@@ -346,16 +421,27 @@ int build_host_scene(const TutuSceneDesc* d, HostScene& hs) {
 	for (size_t k = 0; k < light_orig.size(); k++) {
 		const int32_t o = light_orig[k];
 		const int32_t li = hs.leaf_of_orig[o];
-		const float* v = d->verts + 9 * (size_t)o;
-		const float* nn = d->normals + 9 * (size_t)o;
 		GpuLight& L = hs.lights[k];
+		if (obj_sph[o] >= 0) {  // sphere light: v0 = centre, v1.x = radius, pad = 1 (Sphere::samplePoint, Sphere.hpp:144-163)
+			const float* c4 = ss->spheres + 4 * (size_t)obj_sph[o];
+			memset(&L, 0, sizeof(L));
+			memcpy(L.v0, c4, 12);
+			L.v1[0] = c4[3];
+			memcpy(L.emission, hs.mats[mat_of((uint32_t)o)].emission, 12);
+			L.pdf = (1.f / (size * area[li]));
+			L.tri = li;
+			L.pad = 1;
+			continue;
+		}
+		const float* v = d->verts + 9 * (size_t)obj_tri[o];
+		const float* nn = d->normals + 9 * (size_t)obj_tri[o];
 		memcpy(L.v0, v, 12);
 		memcpy(L.v1, v + 3, 12);
 		memcpy(L.v2, v + 6, 12);
 		memcpy(L.n0, nn, 12);
 		memcpy(L.n1, nn + 3, 12);
 		memcpy(L.n2, nn + 6, 12);
-		memcpy(L.emission, hs.mats[d->mat_id[o]].emission, 12);
+		memcpy(L.emission, hs.mats[mat_of((uint32_t)o)].emission, 12);
 		L.pdf = (1.f / (size * area[li]));  // sampleLight  IIntegrator.hpp:191
 		L.tri = li;
 		L.pad = 0;

@@ -87,6 +87,7 @@ struct HostScene {
 	std::vector<float> texels;         // 4 floats per texel (rgb, pad): one dwordx4 per lookup
 	std::vector<GpuTexDesc> tex_desc;  // the four map lists back to back
 	int32_t tex_base[4] = {0, 0, 0, 0};  // first descriptor of each list
+	bool has_spheres = false;
 	std::vector<GpuNode> nodes;       // inner nodes; nodes[0] is the root when n_tris >= 2
 	std::vector<GpuTriIsect> tri_isect;  // leaf order
 	std::vector<GpuTriShade> tri_shade;  // leaf order

@@ -77,7 +77,8 @@ struct TutuCtx {
 	HostScene hs;
 	SceneDev sc;
 	DevBuf<float4> d_nodes, d_tri_isect, d_tri_shade, d_mats, d_lights;
-	bool textured = false;
+	bool textured = false;     // the scene has textured objects -> k_shade<.., EXT = true>
+	bool has_spheres = false;  // the scene has sphere leaves    -> k_trace<.., SPH = true>, k_shade<.., EXT = true>
 	DevBuf<float4> d_tri_tex, d_texels, d_tex_desc;
 	DevBuf<uint8_t> d_tri_class;
 	// work buffers: two sets, so that consecutive passes run on two streams and a memory-bound stage of one pass
@@ -176,6 +177,20 @@ int ev_end(TutuCtx* c, hipStream_t s, size_t idx) {
 		if (_rc != TUTU_OK) return _rc;                       \
 	} while (0)
 
+// the traversal kernel for this scene: BVH in LDS or HBM, closest- or any-hit, with or without sphere leaves
+template <bool ANY>
+void launch_trace(TutuCtx* c, hipStream_t s, int grid, const TraceParams& tp) {
+	const dim3 g((unsigned)grid), b(256);
+	const unsigned lds = c->trace_lds_bytes;
+	if (c->has_spheres) {
+		if (c->lds_scene) k_trace<true, ANY, true><<<g, b, lds, s>>>(tp);
+		else k_trace<false, ANY, true><<<g, b, lds, s>>>(tp);
+	} else {
+		if (c->lds_scene) k_trace<true, ANY, false><<<g, b, lds, s>>>(tp);
+		else k_trace<false, ANY, false><<<g, b, lds, s>>>(tp);
+	}
+}
+
 int persistent_grid(size_t upper_items, int n_cu, int blocks_per_cu) {
 	size_t blocks = (upper_items + 255) / 256;
 	size_t maxb = (size_t)n_cu * (size_t)blocks_per_cu;
@@ -208,7 +223,7 @@ int build_lists(TutuCtx* c, WorkSet& w, hipStream_t s, uint32_t n_slots_padded, 
 template <int MODE>
 int launch_shade_tab(TutuCtx* c, hipStream_t s, dim3 grid, const PassParams& pp) {
 	const int ev = MODE == SHADE_FIRST ? EV_SHADE_FIRST : (MODE == SHADE_TERMINAL ? EV_SHADE_TERM : EV_SHADE);
-	if (c->textured) {
+	if (c->textured || c->has_spheres) {
 		switch (c->shade_tab) {
 		case 2: TIMED(ev, k_shade<MODE, 2, true><<<grid, dim3(256), c->shade_lds_bytes, s>>>(pp)); break;
 		case 1: TIMED(ev, k_shade<MODE, 1, true><<<grid, dim3(256), c->shade_lds_bytes, s>>>(pp)); break;
@@ -311,13 +326,11 @@ int run_pass(TutuCtx* c, WorkSet& w, hipStream_t s, const TutuCameraFrame* cam, 
 		tp.kB = w.kB.p;
 		tp.tri_class = c->d_tri_class.p;
 		tp.stack_entries = c->stack_entries;
-		if (c->lds_scene) TIMED(EV_TRACE_CLOSEST, k_trace<true, false><<<dim3(trace_grid), dim3(256), c->trace_lds_bytes, s>>>(tp));
-		else TIMED(EV_TRACE_CLOSEST, k_trace<false, false><<<dim3(trace_grid), dim3(256), c->trace_lds_bytes, s>>>(tp));
+		TIMED(EV_TRACE_CLOSEST, launch_trace<false>(c, s, trace_grid, tp));
 		(*n_trace_launches)++;
 		tp.list = w.flag_lists.p + w.cap;
 		tp.n_ptr = meta + 1;
-		if (c->lds_scene) TIMED(EV_TRACE_ANY, k_trace<true, true><<<dim3(trace_grid), dim3(256), c->trace_lds_bytes, s>>>(tp));
-		else TIMED(EV_TRACE_ANY, k_trace<false, true><<<dim3(trace_grid), dim3(256), c->trace_lds_bytes, s>>>(tp));
+		TIMED(EV_TRACE_ANY, launch_trace<true>(c, s, trace_grid, tp));
 		rc = build_lists<LIST_CLASS>(c, w, s, n_pad, meta + 16, w.perm.p, nullptr, nullptr);
 		if (rc != TUTU_OK) return rc;
 	}
@@ -525,6 +538,9 @@ int tutu_hip_create(const TutuSceneDesc* scene, int device, TutuCtx** out) {
 	sc.texels = c->d_texels.p;
 	sc.tex_desc = reinterpret_cast<const int4*>(c->d_tex_desc.p);
 	memcpy(sc.tex_base, c->hs.tex_base, sizeof(sc.tex_base));
+	c->has_spheres = c->hs.has_spheres;
+	sc.has_tex = c->textured ? 1 : 0;
+	sc.has_spheres = c->has_spheres ? 1 : 0;
 	sc.nodes = c->d_nodes.p;
 	sc.tri_isect = c->d_tri_isect.p;
 	sc.tri_shade = c->d_tri_shade.p;
@@ -800,13 +816,8 @@ static int run_trace_kernel(TutuCtx* c, uint32_t n, bool any) {
 	tp.tri_class = c->d_tri_class.p;
 	tp.stack_entries = c->stack_entries;
 	const int grid = persistent_grid(n, c->n_cu, c->trace_blocks_per_cu);
-	if (any) {
-		if (c->lds_scene) k_trace<true, true><<<dim3(grid), dim3(256), c->trace_lds_bytes, s>>>(tp);
-		else k_trace<false, true><<<dim3(grid), dim3(256), c->trace_lds_bytes, s>>>(tp);
-	} else {
-		if (c->lds_scene) k_trace<true, false><<<dim3(grid), dim3(256), c->trace_lds_bytes, s>>>(tp);
-		else k_trace<false, false><<<dim3(grid), dim3(256), c->trace_lds_bytes, s>>>(tp);
-	}
+	if (any) launch_trace<true>(c, s, grid, tp);
+	else launch_trace<false>(c, s, grid, tp);
 	HIP_TRY(hipGetLastError());
 	HIP_TRY(hipStreamSynchronize(s));
 	return TUTU_OK;
