@@ -21,6 +21,7 @@ CFG = {
     "bunny": (lambda: scenes.bunny_box(1024, 1024), 3, 16),
     "broom": (lambda: scenes.broom_room(1600, 900), 4, 4),
     "cornell_textured": (lambda: scenes.cornell_textured(800, 800), 11, 64),
+    "cornell_spheres": (lambda: scenes.cornell_spheres(800, 800), 12, 64),
 }
 
 

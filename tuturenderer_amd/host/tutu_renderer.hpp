@@ -128,6 +128,18 @@ public:
 	float getArea() override { return crossProduct(v1 - v0, v2 - v0).norm() * 0.5f; }
 };
 
+class Sphere : public Object {  // Sphere.hpp:6-21, 133-142
+public:
+	Vector3f centerPos;
+	float radius = 1.f;
+	Sphere() { objectType = SPEHRE; }
+	void initializeBound() override {
+		bound.pMin = {centerPos.x - radius, centerPos.y - radius, centerPos.z - radius};
+		bound.pMax = {centerPos.x + radius, centerPos.y + radius, centerPos.z + radius};
+	}
+	float getArea() override { return radius * radius * 3.1415926535897f; }  // [sic]
+};
+
 // ---------------------------------------------------------------------------------------------- framebuffer / camera
 class Texture {
 public:
@@ -453,8 +465,7 @@ private:
 		else if (key == "bump") bumpIndex = textureKeyword(normalMaps, true);
 		else if (key == "roughnessTexture") roughnessIndex = textureKeyword(roughnessMaps, false);
 		else if (key == "metallicTexture") metallicIndex = textureKeyword(metallicMaps, false);
-		else if (key == "sphere")
-			throw std::runtime_error("`" + key + "` is outside the GPU PathTracing path of this build (SURVEY.md 8f)\n");
+		else if (key == "sphere") sphere();
 		else throw std::runtime_error("extraneous string in the input file\n");
 	}
 
@@ -480,6 +491,34 @@ private:
 				c.z = c.z - 1.f;
 			}
 		return idx;
+	}
+
+	// sphere cx cy cz r  (PPMGenerator.hpp:358-402): takes the current material, the active albedo map and, once each, the
+	// pending normal / roughness / metallic maps
+	void sphere() {
+		auto s = std::make_unique<Sphere>();
+		s->mtlcolor = mtlcolor;
+		s->centerPos = triple();
+		s->radius = number();
+		s->objectType = SPEHRE;
+		if (isTextureOn) {
+			s->isTextureActivated = true;
+			s->textureIndex = textIndex;
+			if (bumpIndex != -1) {
+				s->normalMapIndex = bumpIndex;
+				bumpIndex = -1;
+			}
+			if (roughnessIndex != -1) {
+				s->roughnessMapIndex = roughnessIndex;
+				roughnessIndex = -1;
+			}
+			if (metallicIndex != -1) {
+				s->metallicMapIndex = metallicIndex;
+				metallicIndex = -1;
+			}
+		}
+		s->initializeBound();
+		scene.add(std::move(s));
 	}
 
 	// f a b c | a//n .. | a/t .. | a/t/n ..   (PPMGenerator.hpp:404-452, 879-1023)
@@ -592,15 +631,44 @@ public:
 	int device = 0;
 
 	void integrate(PPMGenerator* gen) override {
-		const size_t n = gen->scene.objList.size();
+		const size_t n_obj = gen->scene.objList.size();
+		size_t n = 0;  // triangles
+		for (auto& o : gen->scene.objList) n += o->objectType == TRIANGLE ? 1 : 0;
 		std::vector<float> verts(9 * n), normals(9 * n);
 		std::vector<int32_t> mat_id(n);
 		std::vector<TutuMaterial> mats;
 		std::vector<float> uvs(6 * n, -1.f);
 		std::vector<int32_t> tex_ids(4 * n, -1);
+		std::vector<float> spheres;
+		std::vector<int32_t> sphere_mat, sphere_tex, sphere_pos;
 		bool any_texture = false;
-		for (size_t i = 0; i < n; i++) {
-			Object* o = gen->scene.objList[i].get();
+		auto material_index = [&mats](const Material& s) -> int32_t {
+			TutuMaterial m;
+			std::memset(&m, 0, sizeof(m));
+			m.diffuse[0] = s.diffuse.x; m.diffuse[1] = s.diffuse.y; m.diffuse[2] = s.diffuse.z;
+			m.specular[0] = s.specular.x; m.specular[1] = s.specular.y; m.specular[2] = s.specular.z;
+			m.emission[0] = s.emission.x; m.emission[1] = s.emission.y; m.emission[2] = s.emission.z;
+			m.type = (int32_t)s.mType;
+			m.alpha = s.alpha; m.eta = s.eta; m.roughness = s.roughness; m.metallic = s.metallic;
+			// consecutive objects of one loadObj share a material: check the last few entries
+			for (int k = (int)mats.size() - 1; k >= 0 && k >= (int)mats.size() - 8; k--)
+				if (std::memcmp(&mats[(size_t)k], &m, sizeof(m)) == 0) return k;
+			mats.push_back(m);
+			return (int32_t)mats.size() - 1;
+		};
+		size_t i = 0;  // running triangle index
+		for (size_t slot = 0; slot < n_obj; slot++) {
+			Object* o = gen->scene.objList[slot].get();
+			if (o->objectType == SPEHRE) {
+				const Sphere* sp = static_cast<const Sphere*>(o);
+				spheres.insert(spheres.end(), {sp->centerPos.x, sp->centerPos.y, sp->centerPos.z, sp->radius});
+				sphere_mat.push_back(material_index(o->mtlcolor));
+				const int32_t ids[4] = {o->textureIndex, o->normalMapIndex, o->roughnessMapIndex, o->metallicMapIndex};
+				for (int k = 0; k < 4; k++) sphere_tex.push_back(o->isTextureActivated ? ids[k] : -1);
+				if (o->isTextureActivated) any_texture = true;
+				sphere_pos.push_back((int32_t)slot);
+				continue;
+			}
 			if (o->objectType != TRIANGLE) die(TUTU_E_UNSUPPORTED, "scene");
 			const Triangle* t = static_cast<const Triangle*>(o);
 			if (o->isTextureActivated) {
@@ -619,25 +687,8 @@ public:
 				verts[9 * i + 3 * k + 0] = pv[k]->x; verts[9 * i + 3 * k + 1] = pv[k]->y; verts[9 * i + 3 * k + 2] = pv[k]->z;
 				normals[9 * i + 3 * k + 0] = pn[k]->x; normals[9 * i + 3 * k + 1] = pn[k]->y; normals[9 * i + 3 * k + 2] = pn[k]->z;
 			}
-			TutuMaterial m;
-			std::memset(&m, 0, sizeof(m));
-			const Material& s = o->mtlcolor;
-			m.diffuse[0] = s.diffuse.x; m.diffuse[1] = s.diffuse.y; m.diffuse[2] = s.diffuse.z;
-			m.specular[0] = s.specular.x; m.specular[1] = s.specular.y; m.specular[2] = s.specular.z;
-			m.emission[0] = s.emission.x; m.emission[1] = s.emission.y; m.emission[2] = s.emission.z;
-			m.type = (int32_t)s.mType;
-			m.alpha = s.alpha; m.eta = s.eta; m.roughness = s.roughness; m.metallic = s.metallic;
-			int found = -1;  // consecutive triangles of one loadObj share a material: check the last few entries
-			for (int k = (int)mats.size() - 1; k >= 0 && k >= (int)mats.size() - 8; k--)
-				if (std::memcmp(&mats[(size_t)k], &m, sizeof(m)) == 0) {
-					found = k;
-					break;
-				}
-			if (found < 0) {
-				mats.push_back(m);
-				found = (int)mats.size() - 1;
-			}
-			mat_id[i] = found;
+			mat_id[i] = material_index(o->mtlcolor);
+			i++;
 		}
 		TutuSceneDesc sd;
 		std::memset(&sd, 0, sizeof(sd));
@@ -670,6 +721,16 @@ public:
 			ts.uvs = uvs.data();
 			ts.tex_ids = tex_ids.data();
 			sd.textures = &ts;
+		}
+		TutuSphereSet sps;
+		std::memset(&sps, 0, sizeof(sps));
+		if (!sphere_mat.empty()) {
+			sps.n_spheres = (uint32_t)sphere_mat.size();
+			sps.spheres = spheres.data();
+			sps.mat_id = sphere_mat.data();
+			sps.tex_ids = sphere_tex.data();
+			sps.pos = sphere_pos.data();
+			sd.spheres = &sps;
 		}
 
 		TutuCameraDesc cd;
