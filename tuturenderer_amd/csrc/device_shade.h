@@ -615,6 +615,7 @@ TUTU_DEV void trace_persistent(const S& ss, const TraceParams& tp, int* stack, c
 	RayPre r = make_ray(mk1(0.f), mk1(1.f));
 	float best_t = FLT_MAX, best_u = 0.f, best_v = 0.f;
 	int best_tri = -1;
+	bool validate = false;  // this lane walks the SAH tree: candidates are checked against the reference's leaf box
 	// any-hit only
 	float dis = 0.f;
 	V3 contrib = mk1(0.f);
@@ -647,10 +648,11 @@ TUTU_DEV void trace_persistent(const S& ss, const TraceParams& tp, int* stack, c
 				}
 				sp = 0;
 				float te;
+				validate = sc.has_fast && ray_is_plain(r);
 				if (sc.root_ref == INT_MIN ||
 				    !slab(r, sc.root_min[0], sc.root_min[1], sc.root_min[2], sc.root_max[0], sc.root_max[1], sc.root_max[2], te))
 					cur = TUTU_TRAV_DONE;
-				else cur = sc.root_ref;
+				else cur = validate ? sc.root_ref : sc.root_ref_exact;
 			}
 			next += (uint32_t)__popcll(idle);
 		}
@@ -701,8 +703,8 @@ TUTU_DEV void trace_persistent(const S& ss, const TraceParams& tp, int* stack, c
 				float t, u, v;
 				const bool h = leaf_test<SPH>(ss, has_pend ? ~pend : ~cur, r, ti, t, u, v);
 				if (ANY) {
-					if (h && t < dis && !float_equal(t, dis)) blocked = true;  // BVH.hpp:186
-				} else if (h && (t < best_t || (t == best_t && ti < best_tri))) {
+					if (h && t < dis && !float_equal(t, dis) && (!validate || leaf_box_hit(sc, ti, r))) blocked = true;  // BVH.hpp:186
+				} else if (h && (t < best_t || (t == best_t && ti < best_tri)) && (!validate || leaf_box_hit(sc, ti, r))) {
 					best_t = t; best_u = u; best_v = v; best_tri = ti;
 				}
 				if (has_pend) {

@@ -50,6 +50,12 @@ struct SceneDev {
 	const int4* tex_desc;   // offset, width, height, size per map; the four lists back to back
 	int tex_base[4];        // first descriptor of the diffuse / normal / roughness / metallic list
 	int has_tex, has_spheres;
+	// two trees in `nodes`: the kernels walk the SAH tree (root_ref) and validate every candidate hit against the
+	// reference's leaf box; rays for which the slab arithmetic is not monotone (a zero or non-finite component in
+	// 1/dir or the origin) walk the reference's own tree (root_ref_exact) instead
+	int root_ref_exact;
+	int has_fast;
+	const float4* leaf_boxes;  // 2 x float4 per leaf (leaf order): min xyz, max xyz
 };
 
 struct SceneGlobal {
@@ -121,6 +127,21 @@ TUTU_DEV bool slab(const RayPre& r, float minx, float miny, float minz, float ma
 	buffer = tmax_y < tmax_z ? tmax_y : tmax_z;
 	float t_exit = tmax_x < buffer ? tmax_x : buffer;
 	return (t_enter <= t_exit && t_exit >= 0.f);
+}
+
+// A ray is "plain" when every slab product is an ordinary number: then a box that contains another is hit whenever
+// the inner one is (rounded subtraction and multiplication by a fixed finite factor are monotone), so the walked tree
+// may differ from the reference's as long as every candidate is validated against the reference's leaf box.
+TUTU_DEV bool ray_is_plain(const RayPre& r) {
+	const float inf = __builtin_inff();
+	return fabsf(r.inv.x) < inf && fabsf(r.inv.y) < inf && fabsf(r.inv.z) < inf && fabsf(r.o.x) < inf && fabsf(r.o.y) < inf &&
+	       fabsf(r.o.z) < inf && r.d.x != 0.f && r.d.y != 0.f && r.d.z != 0.f;
+}
+// BVHAccel::getIntersection reaches a leaf's intersect() only through the slab test of the leaf node itself (BVH.hpp:150)
+TUTU_DEV bool leaf_box_hit(const SceneDev& sc, int leaf, const RayPre& r) {
+	const float4 lo = sc.leaf_boxes[2 * leaf], hi = sc.leaf_boxes[2 * leaf + 1];
+	float te;
+	return slab(r, lo.x, lo.y, lo.z, hi.x, hi.y, hi.z, te);
 }
 
 // Triangle::intersect, Triangle.hpp:23-59 (E1, E2 and the normalised normal are hoisted to the host)
@@ -231,7 +252,8 @@ TUTU_DEV void trace_closest(const S& ss, const SceneDev& sc, V3 o, V3 d, int* st
 	const RayPre r = make_ray(o, d);
 	float te;
 	if (!slab(r, sc.root_min[0], sc.root_min[1], sc.root_min[2], sc.root_max[0], sc.root_max[1], sc.root_max[2], te)) return;
-	int cur = sc.root_ref;
+	const bool validate = sc.has_fast && ray_is_plain(r);
+	int cur = validate ? sc.root_ref : sc.root_ref_exact;
 	int sp = 0;
 	for (;;) {
 		while (cur >= 0) {
@@ -257,7 +279,7 @@ TUTU_DEV void trace_closest(const S& ss, const SceneDev& sc, V3 o, V3 d, int* st
 		int ti;
 		float t, u, v;
 		if (leaf_test<true>(ss, ~cur, r, ti, t, u, v)) {
-			if (t < best_t || (t == best_t && ti < best_tri)) {
+			if ((t < best_t || (t == best_t && ti < best_tri)) && (!validate || leaf_box_hit(sc, ti, r))) {
 				best_t = t;
 				best_u = u;
 				best_v = v;
@@ -280,7 +302,8 @@ TUTU_DEV bool trace_any(const S& ss, const SceneDev& sc, V3 orig, V3 lightPos, i
 	float te;
 	if (!slab(r, sc.root_min[0], sc.root_min[1], sc.root_min[2], sc.root_max[0], sc.root_max[1], sc.root_max[2], te)) return false;
 	const float lim = dis * TUTU_PRUNE_SLACK;
-	int cur = sc.root_ref;
+	const bool validate = sc.has_fast && ray_is_plain(r);
+	int cur = validate ? sc.root_ref : sc.root_ref_exact;
 	int sp = 0;
 	bool blocked = false;
 	for (;;) {
@@ -305,7 +328,7 @@ TUTU_DEV bool trace_any(const S& ss, const SceneDev& sc, V3 orig, V3 lightPos, i
 		int ti;
 		float t, u, v;
 		if (leaf_test<true>(ss, ~cur, r, ti, t, u, v)) {
-			if (t < dis && !float_equal(t, dis)) {
+			if (t < dis && !float_equal(t, dis) && (!validate || leaf_box_hit(sc, ti, r))) {
 				blocked = true;
 				break;
 			}

@@ -5,6 +5,7 @@
 #include <algorithm>
 #include <climits>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 
 namespace tutu {
@@ -148,6 +149,150 @@ int build_tree_of_boxes(const std::vector<Box>& tb, std::vector<BuildNode>& out,
 	if (depth) *depth = b.max_depth;
 	return TUTU_OK;
 }
+
+// ---- the tree the kernels actually walk ------------------------------------------------------------------------
+// Binned surface-area-heuristic binary tree over the same object boxes, one object per leaf.  It only decides WHERE
+// the traversal looks: which objects count as hit is still decided by the reference's own leaf-box slab test plus
+// its intersection routine (device_trace.h), and exact-t ties are still resolved by the reference tree's leaf order.
+// A box that contains a leaf box is hit whenever the leaf box is (the slab arithmetic is monotone in the box planes
+// for finite, non-zero direction components), so replacing the reference's ancestors by other enclosing boxes
+// cannot change which leaves are reached.
+struct SahBuilder {
+	const std::vector<Box>& tb;
+	std::vector<BuildNode>& out;
+	uint32_t max_depth = 0;
+	static constexpr int kBins = 16;
+
+	static double area(const Box& b) {
+		const double dx = (double)b.mx[0] - b.mn[0], dy = (double)b.mx[1] - b.mn[1], dz = (double)b.mx[2] - b.mn[2];
+		return 2.0 * (dx * dy + dy * dz + dz * dx);
+	}
+	void set_bounds(int id, const Box& b) {
+		memcpy(out[id].pmin, b.mn, 12);
+		memcpy(out[id].pmax, b.mx, 12);
+	}
+	int build(int32_t* first, int32_t* last, uint32_t depth) {
+		const int id = (int)out.size();
+		out.push_back(BuildNode{{0, 0, 0}, {0, 0, 0}, -1, -1, -1});
+		if (depth > max_depth) max_depth = depth;
+		const size_t n = (size_t)(last - first);
+		if (n == 1) {
+			set_bounds(id, tb[first[0]]);
+			out[id].tri = first[0];
+			return id;
+		}
+		Box nb = tb[first[0]];
+		float cmin[3], cmax[3];
+		for (int k = 0; k < 3; k++) cmin[k] = cmax[k] = centroid(tb[first[0]], k);
+		for (size_t i = 1; i < n; i++) {
+			nb = box_union(nb, tb[first[i]]);
+			for (int k = 0; k < 3; k++) {
+				const float c = centroid(tb[first[i]], k);
+				cmin[k] = fminf(cmin[k], c);
+				cmax[k] = fmaxf(cmax[k], c);
+			}
+		}
+		// the remaining levels must fit the traversal stack: close to the limit, split by count
+		uint32_t need = 0;
+		while (((size_t)1 << need) < n) need++;
+		const bool force_median = depth + need + 2 >= (uint32_t)TUTU_MAX_BVH_DEPTH;
+		int best_axis = -1, best_split = -1;
+		double best_cost = 1e300;
+		if (!force_median && n > 2) {
+			for (int axis = 0; axis < 3; axis++) {
+				const float lo = cmin[axis], ext = cmax[axis] - cmin[axis];
+				if (!(ext > 0)) continue;
+				Box bb[kBins];
+				int cnt[kBins];
+				bool used[kBins];
+				for (int b = 0; b < kBins; b++) {
+					cnt[b] = 0;
+					used[b] = false;
+				}
+				const float scale = (float)kBins / ext;
+				for (size_t i = 0; i < n; i++) {
+					int b = (int)((centroid(tb[first[i]], axis) - lo) * scale);
+					b = b < 0 ? 0 : (b >= kBins ? kBins - 1 : b);
+					bb[b] = used[b] ? box_union(bb[b], tb[first[i]]) : tb[first[i]];
+					used[b] = true;
+					cnt[b]++;
+				}
+				double right_area[kBins];
+				int right_cnt[kBins];
+				Box acc;
+				bool have = false;
+				int c = 0;
+				for (int b = kBins - 1; b >= 1; b--) {
+					if (used[b]) {
+						acc = have ? box_union(acc, bb[b]) : bb[b];
+						have = true;
+					}
+					c += cnt[b];
+					right_area[b] = have ? area(acc) : 0.0;
+					right_cnt[b] = c;
+				}
+				have = false;
+				c = 0;
+				for (int b = 0; b < kBins - 1; b++) {
+					if (used[b]) {
+						acc = have ? box_union(acc, bb[b]) : bb[b];
+						have = true;
+					}
+					c += cnt[b];
+					if (c == 0 || right_cnt[b + 1] == 0) continue;
+					const double cost = area(acc) * c + right_area[b + 1] * right_cnt[b + 1];
+					if (cost < best_cost) {
+						best_cost = cost;
+						best_axis = axis;
+						best_split = b;
+					}
+				}
+			}
+		}
+		int32_t* middle;
+		if (best_axis >= 0) {
+			const float lo = cmin[best_axis], scale = (float)kBins / (cmax[best_axis] - cmin[best_axis]);
+			const std::vector<Box>& b = tb;
+			const int axis = best_axis, split = best_split;
+			middle = std::stable_partition(first, last, [&b, axis, lo, scale, split](int32_t o) {
+				int bin = (int)((centroid(b[o], axis) - lo) * scale);
+				bin = bin < 0 ? 0 : (bin >= kBins ? kBins - 1 : bin);
+				return bin <= split;
+			});
+		} else {
+			// no usable SAH split (coincident centroids, two objects, or depth pressure): split the list in half
+			// along the widest axis of the centroids
+			int axis = 0;
+			for (int k = 1; k < 3; k++)
+				if (cmax[k] - cmin[k] > cmax[axis] - cmin[axis]) axis = k;
+			const std::vector<Box>& b = tb;
+			middle = first + n / 2;
+			std::nth_element(first, middle, last, [&b, axis](int32_t o1, int32_t o2) {
+				const float c1 = centroid(b[o1], axis), c2 = centroid(b[o2], axis);
+				return c1 < c2 || (c1 == c2 && o1 < o2);
+			});
+		}
+		const int l = build(first, middle, depth + 1);
+		const int r = build(middle, last, depth + 1);
+		out[id].left = l;
+		out[id].right = r;
+		set_bounds(id, nb);
+		return id;
+	}
+};
+
+int build_sah_tree(const std::vector<Box>& tb, std::vector<BuildNode>& out, uint32_t* depth) {
+	out.clear();
+	if (depth) *depth = 0;
+	if (tb.empty()) return TUTU_OK;
+	std::vector<int32_t> idx(tb.size());
+	for (size_t i = 0; i < tb.size(); i++) idx[i] = (int32_t)i;
+	out.reserve(2 * tb.size());
+	SahBuilder b{tb, out};
+	b.build(idx.data(), idx.data() + tb.size(), 0);
+	if (depth) *depth = b.max_depth;
+	return TUTU_OK;
+}
 }  // namespace
 
 int build_reference_tree(uint32_t n_tris, const float* verts, std::vector<BuildNode>& out, uint32_t* depth) {
@@ -212,72 +357,101 @@ int build_host_scene(const TutuSceneDesc* d, HostScene& hs) {
 
 	std::vector<BuildNode> tree;
 	int rc;
-	{
-		std::vector<Box> tb(n);
-		for (uint32_t o = 0; o < n; o++)
-			tb[o] = obj_sph[o] >= 0 ? sphere_box(ss->spheres + 4 * (size_t)obj_sph[o]) : triangle_box(d->verts + 9 * (size_t)obj_tri[o]);
-		rc = build_tree_of_boxes(tb, tree, &hs.depth);
-	}
+	std::vector<Box> tb(n);
+	for (uint32_t o = 0; o < n; o++)
+		tb[o] = obj_sph[o] >= 0 ? sphere_box(ss->spheres + 4 * (size_t)obj_sph[o]) : triangle_box(d->verts + 9 * (size_t)obj_tri[o]);
+	rc = build_tree_of_boxes(tb, tree, &hs.depth);
 	if (rc != TUTU_OK) return rc;
 	if (hs.depth > TUTU_MAX_BVH_DEPTH) return TUTU_E_BVH_DEPTH;
+	hs.ref_depth = hs.depth;
 
 	// leaf order = left-to-right walk = the order in which getIntersection's `<=` resolves exact-t ties
 	// (BVH.hpp:165).  Triangles are stored in that order so the kernels break ties by index.
 	std::vector<int32_t> order;  // leaf-order -> original
 	order.reserve(n);
 	hs.leaf_of_orig.assign(n, -1);
-	std::vector<int32_t> inner_id(tree.size(), -1);
-	{
-		// leaves: pre-order walk = left-to-right order
-		for (size_t i = 0; i < tree.size(); i++) {
-			if (!(tree[i].left >= 0 || tree[i].right >= 0) && tree[i].tri >= 0) {
-				hs.leaf_of_orig[tree[i].tri] = (int32_t)order.size();
-				order.push_back(tree[i].tri);
-			}
+	// leaves: pre-order walk of the REFERENCE tree = left-to-right order
+	for (size_t i = 0; i < tree.size(); i++) {
+		if (!(tree[i].left >= 0 || tree[i].right >= 0) && tree[i].tri >= 0) {
+			hs.leaf_of_orig[tree[i].tri] = (int32_t)order.size();
+			order.push_back(tree[i].tri);
 		}
-		// inner nodes: breadth-first numbering, so that the first K ids are the top of the tree -- the part every
-		// ray walks, which the traversal kernels keep in LDS when the whole tree does not fit
-		int32_t next_inner = 0;
+	}
+	// Flatten a build tree into hs.nodes (appending); returns the reference of its root.  Inner nodes are numbered
+	// breadth-first, so that the first ids are the top of the tree -- the part every ray walks.
+	auto flatten = [&](const std::vector<BuildNode>& t) -> int32_t {
+		if (t.empty()) return INT_MIN;
+		std::vector<int32_t> inner_id(t.size(), -1);
+		int32_t next_inner = (int32_t)hs.nodes.size();
 		std::vector<int32_t> level;
-		if (!tree.empty() && (tree[0].left >= 0 || tree[0].right >= 0)) level.push_back(0);
+		if (t[0].left >= 0 || t[0].right >= 0) level.push_back(0);
 		while (!level.empty()) {
 			std::vector<int32_t> next_level;
 			for (int32_t bn : level) {
 				inner_id[bn] = next_inner++;
-				const int32_t ch[2] = {tree[bn].left, tree[bn].right};
+				const int32_t ch[2] = {t[bn].left, t[bn].right};
 				for (int k = 0; k < 2; k++)
-					if (ch[k] >= 0 && (tree[ch[k]].left >= 0 || tree[ch[k]].right >= 0)) next_level.push_back(ch[k]);
+					if (ch[k] >= 0 && (t[ch[k]].left >= 0 || t[ch[k]].right >= 0)) next_level.push_back(ch[k]);
 			}
 			level.swap(next_level);
 		}
-		hs.nodes.assign((size_t)next_inner, GpuNode{});
-	}
-	auto ref_of = [&](int32_t bn) -> int32_t {
-		if (tree[bn].left >= 0 || tree[bn].right >= 0) return inner_id[bn];
-		const int32_t leaf = hs.leaf_of_orig[tree[bn].tri];
-		return obj_sph[tree[bn].tri] >= 0 ? ~(leaf | kSphereBit) : ~leaf;  // device_trace.h: TUTU_SPHERE_BIT
+		hs.nodes.resize((size_t)next_inner, GpuNode{});
+		auto ref_of = [&](int32_t bn) -> int32_t {
+			if (t[bn].left >= 0 || t[bn].right >= 0) return inner_id[bn];
+			const int32_t leaf = hs.leaf_of_orig[t[bn].tri];
+			return obj_sph[t[bn].tri] >= 0 ? ~(leaf | kSphereBit) : ~leaf;  // device_trace.h: TUTU_SPHERE_BIT
+		};
+		for (size_t i = 0; i < t.size(); i++) {
+			if (inner_id[i] < 0) continue;
+			GpuNode& g = hs.nodes[inner_id[i]];
+			const BuildNode& l = t[t[i].left];
+			const BuildNode& r = t[t[i].right];
+			memcpy(g.lmin, l.pmin, 12);
+			memcpy(g.lmax, l.pmax, 12);
+			memcpy(g.rmin, r.pmin, 12);
+			memcpy(g.rmax, r.pmax, 12);
+			g.left = ref_of(t[i].left);
+			g.right = ref_of(t[i].right);
+			g.pad0 = g.pad1 = 0;
+		}
+		return ref_of(0);
 	};
-	for (size_t i = 0; i < tree.size(); i++) {
-		if (inner_id[i] < 0) continue;
-		GpuNode& g = hs.nodes[inner_id[i]];
-		const BuildNode& l = tree[tree[i].left];
-		const BuildNode& r = tree[tree[i].right];
-		memcpy(g.lmin, l.pmin, 12);
-		memcpy(g.lmax, l.pmax, 12);
-		memcpy(g.rmin, r.pmin, 12);
-		memcpy(g.rmax, r.pmax, 12);
-		g.left = ref_of(tree[i].left);
-		g.right = ref_of(tree[i].right);
-		g.pad0 = g.pad1 = 0;
+	hs.nodes.clear();
+	// The tree the kernels walk first in the node array (so that a partial LDS copy holds ITS top), then the
+	// reference's own tree, which rays with a zero / non-finite direction component fall back to.
+	const bool want_sah = n > 2 && !getenv("TUTU_NO_SAH");
+	hs.has_fast_tree = false;
+	if (want_sah) {
+		std::vector<BuildNode> sah;
+		uint32_t sah_depth = 0;
+		rc = build_sah_tree(tb, sah, &sah_depth);
+		if (rc != TUTU_OK) return rc;
+		if (sah_depth <= TUTU_MAX_BVH_DEPTH) {
+			hs.root_ref = flatten(sah);
+			hs.n_fast_inner = (int32_t)hs.nodes.size();
+			hs.has_fast_tree = true;
+			hs.depth = std::max(hs.depth, sah_depth);
+			hs.fast_depth = sah_depth;
+		}
+	}
+	hs.root_ref_exact = flatten(tree);
+	if (!hs.has_fast_tree) {
+		hs.root_ref = hs.root_ref_exact;
+		hs.n_fast_inner = (int32_t)hs.nodes.size();
+		hs.fast_depth = hs.ref_depth;
 	}
 	if (tree.empty()) {
-		hs.root_ref = INT_MIN;
 		memset(hs.root_min, 0, 12);
 		memset(hs.root_max, 0, 12);
 	} else {
-		hs.root_ref = ref_of(0);
 		memcpy(hs.root_min, tree[0].pmin, 12);
 		memcpy(hs.root_max, tree[0].pmax, 12);
+	}
+	// the reference's leaf boxes, in leaf order: what a candidate hit is validated against when the fast tree is walked
+	hs.leaf_boxes.assign((size_t)n * 8, 0.f);
+	for (uint32_t li = 0; li < n; li++) {
+		memcpy(&hs.leaf_boxes[(size_t)li * 8], tb[order[li]].mn, 12);
+		memcpy(&hs.leaf_boxes[(size_t)li * 8 + 4], tb[order[li]].mx, 12);
 	}
 
 	// lights: PPMGenerator::initializeLights order = object-list order (PPMGenerator.hpp:317-324)

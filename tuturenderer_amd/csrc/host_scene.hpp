@@ -96,8 +96,13 @@ struct HostScene {
 	std::vector<GpuLight> lights;
 	std::vector<int32_t> leaf_of_orig;  // original triangle index -> leaf-order index
 	float root_min[3], root_max[3];
-	int32_t root_ref;  // >=0 inner node index, <0 leaf (~tri), or INT32_MIN for an empty scene
-	uint32_t depth;
+	int32_t root_ref;  // >=0 inner node index, <0 leaf (~tri), or INT32_MIN for an empty scene: the tree the kernels walk
+	int32_t root_ref_exact = 0;  // root of the reference's own tree (fallback for rays with a zero / non-finite direction component)
+	bool has_fast_tree = false;  // root_ref is the SAH tree (else both roots are the reference tree)
+	int32_t n_fast_inner = 0;    // nodes [0, n_fast_inner) belong to the walked tree
+	uint32_t fast_depth = 0, ref_depth = 0;
+	std::vector<float> leaf_boxes;  // [leaf][8]: min xyz pad, max xyz pad -- the reference's leaf boxes
+	uint32_t depth;  // max over both trees: sizes the traversal stack
 	float eta;
 	float bkg[3];
 };

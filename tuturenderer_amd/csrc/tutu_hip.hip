@@ -79,7 +79,7 @@ struct TutuCtx {
 	DevBuf<float4> d_nodes, d_tri_isect, d_tri_shade, d_mats, d_lights;
 	bool textured = false;     // the scene has textured objects -> k_shade<.., EXT = true>
 	bool has_spheres = false;  // the scene has sphere leaves    -> k_trace<.., SPH = true>, k_shade<.., EXT = true>
-	DevBuf<float4> d_tri_tex, d_texels, d_tex_desc;
+	DevBuf<float4> d_tri_tex, d_texels, d_tex_desc, d_leaf_boxes;
 	DevBuf<uint8_t> d_tri_class;
 	// work buffers: two sets, so that consecutive passes run on two streams and a memory-bound stage of one pass
 	// overlaps a compute-bound stage of the other
@@ -422,7 +422,8 @@ int render_impl(TutuCtx* c, const TutuCameraFrame* cam, const TutuRenderParams* 
 	spp_pass = std::min(spp_pass, rp->spp);
 	spp_pass = std::min(spp_pass, 65535);  // grid.y limit
 	const int n_passes = (rp->spp + spp_pass - 1) / spp_pass;
-	const int n_sets = n_passes > 1 ? 2 : 1;
+	static const bool one_set = getenv("TUTU_ONE_SET") != nullptr;  // profiling aid: no overlap, clean per-kernel times
+	const int n_sets = (n_passes > 1 && !one_set) ? 2 : 1;
 	const size_t cap = (size_t)npix * (size_t)spp_pass;
 	int rc = ensure_work(c, cap, (size_t)npix, n_sets);
 	if (rc != TUTU_OK) return rc;
@@ -526,6 +527,7 @@ int tutu_hip_create(const TutuSceneDesc* scene, int device, TutuCtx** out) {
 	if ((rc = c->d_tri_class.ensure(std::max<size_t>(16, c->hs.tri_class.size()))) != TUTU_OK) return fail(rc);
 	if (!c->hs.tri_class.empty() && hipMemcpyAsync(c->d_tri_class.p, c->hs.tri_class.data(), c->hs.tri_class.size(), hipMemcpyHostToDevice, s) != hipSuccess)
 		return fail(TUTU_E_HIP);
+	if ((rc = upload(c->d_leaf_boxes, c->hs.leaf_boxes, s)) != TUTU_OK) return fail(rc);
 	c->textured = !c->hs.tri_tex.empty();
 	if (c->textured) {
 		if ((rc = upload(c->d_tri_tex, c->hs.tri_tex, s)) != TUTU_OK) return fail(rc);
@@ -539,6 +541,9 @@ int tutu_hip_create(const TutuSceneDesc* scene, int device, TutuCtx** out) {
 	sc.tex_desc = reinterpret_cast<const int4*>(c->d_tex_desc.p);
 	memcpy(sc.tex_base, c->hs.tex_base, sizeof(sc.tex_base));
 	c->has_spheres = c->hs.has_spheres;
+	sc.root_ref_exact = c->hs.root_ref_exact;
+	sc.has_fast = c->hs.has_fast_tree ? 1 : 0;
+	sc.leaf_boxes = c->d_leaf_boxes.p;
 	sc.has_tex = c->textured ? 1 : 0;
 	sc.has_spheres = c->has_spheres ? 1 : 0;
 	sc.nodes = c->d_nodes.p;
@@ -593,7 +598,7 @@ int tutu_hip_destroy(TutuCtx* c) {
 		(void)hipEventDestroy(e.a);
 		(void)hipEventDestroy(e.b);
 	}
-	c->d_tri_tex.release(); c->d_texels.release(); c->d_tex_desc.release();
+	c->d_tri_tex.release(); c->d_texels.release(); c->d_tex_desc.release(); c->d_leaf_boxes.release();
 	c->d_tri_class.release(); c->d_nodes.release(); c->d_tri_isect.release(); c->d_tri_shade.release(); c->d_mats.release(); c->d_lights.release();
 	if (c->stream2) (void)hipStreamSynchronize(c->stream2);
 	for (int k = 0; k < 2; k++) {
@@ -617,8 +622,9 @@ int tutu_hip_scene_info(TutuCtx* c, TutuBvhInfo* bvh, uint32_t* n_lights) {
 	if (!c) return TUTU_E_INVALID;
 	if (bvh) {
 		bvh->n_tris = (uint32_t)c->hs.tri_isect.size();
-		bvh->n_inner = (uint32_t)c->hs.nodes.size();
-		bvh->depth = c->hs.depth;
+		// the reference's tree (the walked SAH tree is an implementation detail)
+		bvh->n_inner = (uint32_t)(c->hs.has_fast_tree ? c->hs.nodes.size() - (size_t)c->hs.n_fast_inner : c->hs.nodes.size());
+		bvh->depth = c->hs.ref_depth;
 		memcpy(bvh->root_bounds, c->hs.root_min, 12);
 		memcpy(bvh->root_bounds + 3, c->hs.root_max, 12);
 	}
