@@ -12,7 +12,7 @@ fixed, so the scaling is "strong".
 
 Prints ONE JSON line on rank 0:  metric = Msamples/s (= width*height*spp / wall-seconds), plus
   roofline     -- the dominant kernel, priced in ALGORITHMIC bytes (per ray = 32 B ray + 16 B hit
-                  + N*32 B nodes entered + T*48 B triangle tests, N and T from the CPU restatement's counters)
+                  + N*32 B nodes entered + T*48 B triangle tests, N and T counted by the traversal kernels)
                   over its average launch duration measured with HIP events on the library's stream;
   cpu_baseline -- the reference's own integrator (oracle/_ref, kind "reference"; falls back to the CPU restatement,
                   kind "port") timed on this box's host cores on a bounded sample of the same workload.
@@ -124,7 +124,7 @@ def main():
     t0 = time.perf_counter()
     agg = {"ms_trace_closest": 0.0, "ms_trace_any": 0.0, "ms_shade": 0.0, "ms_other": 0.0, "trace_launches": 0, "closest_rays": 0,
            "shadow_rays": 0, "passes": 0, "ms_shade_first": 0.0, "ms_shade_material": 0.0, "ms_shade_terminal": 0.0,
-           "shade_material_launches": 0}
+           "shade_material_launches": 0, "nodes_closest": 0, "leaves_closest": 0, "nodes_any": 0, "leaves_any": 0}
     for _ in range(args.steps):
         st = step()
         for k in agg:
@@ -139,16 +139,22 @@ def main():
     if rank == 0:
         total_samples = W * H * spp * args.steps
         value = total_samples / dt / 1e6
-        counters = json.load(open(os.path.join(ROOT, "tuturenderer_amd", "scenes", "workload_counters.json")))
-        wc = counters.get(f"cornell_{W}x{H}", counters["cornell_800x800"])
         # per-kernel algorithmic bytes per unit (the 288 B of state per segment split by stage)
-        per_unit = {
-            "k_trace_closest": 32 + 16 + wc["N_closest"] * 32 + wc["T_closest"] * 48,  # per closest-hit ray
-            "k_trace_any": 48 + wc["N_shadow"] * 32 + wc["T_shadow"] * 48,            # per shadow ray
-            "k_shade": 192.0,                                                          # per segment
-        }
         prim = len(mine) * args.steps  # primary rays go through k_primary, not the queue kernel
         ext = agg["closest_rays"] - prim  # extension rays = path vertices shaded at depth >= 1
+        # per ray 32 B ray + 16 B hit + N*32 B nodes entered + T*48 B leaf tests.  N and T are counted
+        # by the traversal kernels themselves on the tree they actually walk (TutuStats.nodes_* / leaves_*; a node
+        # entered = an inner node visited or a leaf reached), not taken from the CPU restatement's walk of the
+        # reference tree (tuturenderer_amd/scenes/workload_counters.json: N 17.2 / T 2.65 there).
+        n_c = (agg["nodes_closest"] + agg["leaves_closest"]) / max(ext, 1)
+        t_c = agg["leaves_closest"] / max(ext, 1)
+        n_s = (agg["nodes_any"] + agg["leaves_any"]) / max(agg["shadow_rays"], 1)
+        t_s = agg["leaves_any"] / max(agg["shadow_rays"], 1)
+        per_unit = {
+            "k_trace_closest": 32 + 16 + n_c * 32 + t_c * 48,  # per closest-hit ray
+            "k_trace_any": 48 + n_s * 32 + t_s * 48,            # per shadow ray
+            "k_shade": 192.0,                                    # per segment
+        }
         # k_shade here = the per-material-class launches at depth >= 1 (one kernel name per class group; the Cornell
         # box has one group, LAMBERTIAN: rocprof's `k_shade<1, 2>`); the depth-0 and connect-only launches are separate
         units = {"k_trace_closest": ext, "k_trace_any": agg["shadow_rays"], "k_shade": ext}
@@ -169,8 +175,13 @@ def main():
                     "kernel_ms_per_step": dict({k: v / args.steps for k, v in ms.items()}, k_shade_depth0=agg["ms_shade_first"] / args.steps,
                                                k_shade_connect_only=agg["ms_shade_terminal"] / args.steps, other=agg["ms_other"] / args.steps),
                     "note": "consecutive passes run on two streams, so stage times overlap: their sum exceeds ms_per_step",
-                    "pipeline_B_sample": wc["B_sample_bytes_at_512spp"],
-                    "pipeline_frac": value * 1e6 * wc["B_sample_bytes_at_512spp"] / (HBM_PEAK_GBS * 1e9)}
+                    "measured_per_ray": {"N_closest": n_c, "T_closest": t_c, "N_shadow": n_s, "T_shadow": t_s}}
+        # whole-pipeline algorithmic bytes per sample with the measured N and T
+        seg_per_sample = ext / max(W * H * spp * args.steps, 1)
+        sh_per_sample = agg["shadow_rays"] / max(W * H * spp * args.steps, 1)
+        b_sample = seg_per_sample * (per_unit["k_trace_closest"] + per_unit["k_shade"]) + sh_per_sample * per_unit["k_trace_any"]
+        roofline["pipeline_B_sample"] = b_sample
+        roofline["pipeline_frac"] = value * 1e6 * b_sample / (HBM_PEAK_GBS * 1e9)
         line = {
             "metric": "Msamples/sec (rays traced/sec) + wall-clock to 512spp, Cornell box 800x800",
             "value": value, "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

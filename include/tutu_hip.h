@@ -150,6 +150,9 @@ typedef struct TutuStats {
 	float ms_shade_material; /* per-material-class launches at depth >= 1 */
 	float ms_shade_terminal; /* launches that only connect (last depth; scenes without scattering materials) */
 	uint32_t shade_material_launches;
+	/* traversal work measured on the device, summed over the call's queue-stage rays (primary rays excluded):
+	 * nodes entered and leaf (triangle / sphere) tests, for closest-hit and any-hit rays */
+	uint64_t nodes_closest, leaves_closest, nodes_any, leaves_any;
 } TutuStats;
 
 typedef struct TutuHit {

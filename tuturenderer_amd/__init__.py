@@ -117,7 +117,8 @@ class Stats(C.Structure):
     _fields_ = [("samples", C.c_uint64), ("closest_rays", C.c_uint64), ("shadow_rays", C.c_uint64), ("segments", C.c_uint64),
                 ("passes", C.c_uint32), ("trace_launches", C.c_uint32), ("ms_total", C.c_float), ("ms_trace_closest", C.c_float),
                 ("ms_trace_any", C.c_float), ("ms_shade", C.c_float), ("ms_other", C.c_float), ("ms_shade_first", C.c_float),
-                ("ms_shade_material", C.c_float), ("ms_shade_terminal", C.c_float), ("shade_material_launches", C.c_uint32)]
+                ("ms_shade_material", C.c_float), ("ms_shade_terminal", C.c_float), ("shade_material_launches", C.c_uint32),
+                ("nodes_closest", C.c_uint64), ("leaves_closest", C.c_uint64), ("nodes_any", C.c_uint64), ("leaves_any", C.c_uint64)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

@@ -51,6 +51,7 @@ struct Queue {  // structure-of-arrays path records, one per slot
 struct Totals {  // accumulated over a render call
 	unsigned long long closest_rays, shadow_rays, segments, pad;
 };
+#define TUTU_PART_BLOCKS 4096  // upper bound of the traversal kernels' grid
 
 struct PassParams {
 	SceneDev sc;
@@ -594,6 +595,12 @@ struct TraceParams {
 	uint8_t* kB;            // closest-hit: material class of the hit
 	const uint8_t* tri_class;  // per triangle (leaf order): class of its material
 	int stack_entries;
+	// work counters, per block: [block][0] nodes entered, [1] leaf tests (SURVEY.md 8(d)'s N and T, measured on the tree
+	// that is actually walked).  Plain read-modify-write by one thread per block; each work set has its own array.
+	unsigned long long* part;
+	int refill_min;  // idle lanes a wave waits for before it fetches new rays (1 = refill at once)
+	int inner_steps;  // node visits between two leaf / finish / refill rounds
+	unsigned long long* util;  // optional [3]: wave-level node steps, leaf steps, outer iterations (TUTU_UTIL_STATS)
 };
 
 template <typename S, bool ANY, bool SPH>
@@ -616,6 +623,8 @@ TUTU_DEV void trace_persistent(const S& ss, const TraceParams& tp, int* stack, c
 	float best_t = FLT_MAX, best_u = 0.f, best_v = 0.f;
 	int best_tri = -1;
 	bool validate = false;  // this lane walks the SAH tree: candidates are checked against the reference's leaf box
+	uint32_t n_nodes = 0, n_leaves = 0;  // work counters of this lane
+	uint32_t w_node_steps = 0, w_leaf_steps = 0, w_outer = 0;  // wave-uniform: how often each phase ran (TUTU_UTIL_STATS)
 	// any-hit only
 	float dis = 0.f;
 	V3 contrib = mk1(0.f);
@@ -625,7 +634,7 @@ TUTU_DEV void trace_persistent(const S& ss, const TraceParams& tp, int* stack, c
 	for (;;) {
 		// ---- refill
 		const unsigned long long idle = __ballot(cur == TUTU_TRAV_IDLE);
-		if (idle != 0ull && next < end) {
+		if (idle != 0ull && next < end && (__popcll(idle) >= tp.refill_min || __ballot(cur != TUTU_TRAV_IDLE && cur != TUTU_TRAV_DONE) == 0ull)) {
 			const uint32_t i = next + (uint32_t)__popcll(idle & lt_mask);
 			if (cur == TUTU_TRAV_IDLE && i < end) {
 				slot = tp.list[i];
@@ -661,9 +670,11 @@ TUTU_DEV void trace_persistent(const S& ss, const TraceParams& tp, int* stack, c
 		// ---- inner nodes.  A lane that reaches a leaf parks it in `pend` and keeps descending, so that lanes are not
 		// idle while the wave's other lanes still walk inner nodes (postponed leaf test)
 #pragma unroll 1
-		for (int k = 0; k < TUTU_INNER_STEPS; k++) {
+		for (int k = 0; k < tp.inner_steps; k++) {
 			if (__ballot(cur >= 0) == 0ull) break;
+			w_node_steps++;
 			if (cur >= 0) {
+				n_nodes++;
 				float lim;
 				if (ANY) lim = dis * TUTU_PRUNE_SLACK;
 				else lim = best_tri >= 0 ? best_t * TUTU_PRUNE_SLACK : FLT_MAX;
@@ -698,7 +709,10 @@ TUTU_DEV void trace_persistent(const S& ss, const TraceParams& tp, int* stack, c
 		{
 			const bool has_pend = pend != TUTU_TRAV_IDLE;
 			const bool on_leaf = cur < 0 && cur > TUTU_TRAV_IDLE;
+			w_outer++;
+			if (__ballot(has_pend || on_leaf) != 0ull) w_leaf_steps++;
 			if (has_pend || on_leaf) {
+				n_leaves++;
 				int ti;
 				float t, u, v;
 				const bool h = leaf_test<SPH>(ss, has_pend ? ~pend : ~cur, r, ti, t, u, v);
@@ -745,6 +759,31 @@ TUTU_DEV void trace_persistent(const S& ss, const TraceParams& tp, int* stack, c
 				}
 			}
 			cur = TUTU_TRAV_IDLE;
+		}
+	}
+	// work counters: wave sum, then one plain add per wave leader into this block's slots (waves of a block take turns)
+	if (tp.part) {
+		unsigned long long a = n_nodes, b = n_leaves;
+		for (int off = 32; off > 0; off >>= 1) {
+			a += __shfl_xor(a, off);
+			b += __shfl_xor(b, off);
+		}
+		__shared__ unsigned long long acc[2];
+		if (threadIdx.x == 0) acc[0] = acc[1] = 0ull;
+		__syncthreads();
+		if (lane == 0) {
+			atomicAdd(&acc[0], a);
+			atomicAdd(&acc[1], b);
+		}
+		__syncthreads();
+		if (threadIdx.x == 0) {
+			tp.part[2 * blockIdx.x + 0] += acc[0];
+			tp.part[2 * blockIdx.x + 1] += acc[1];
+		}
+		if (tp.util && lane == 0) {  // profiling aid: phase executions per wave
+			atomicAdd(&tp.util[0], (unsigned long long)w_node_steps);
+			atomicAdd(&tp.util[1], (unsigned long long)w_leaf_steps);
+			atomicAdd(&tp.util[2], (unsigned long long)w_outer);
 		}
 	}
 }

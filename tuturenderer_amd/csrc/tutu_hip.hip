@@ -91,6 +91,7 @@ struct TutuCtx {
 		DevBuf<uint32_t> perm;        // [cap]: continuing slots sorted by class
 		DevBuf<uint32_t> tile_counts, tile_offsets;
 		DevBuf<uint32_t> list_meta;   // per depth: flag-list counts [8] | class-list counts [8]
+		DevBuf<unsigned long long> part;  // [2 kinds][TUTU_PART_BLOCKS][2] traversal work counters
 		hipEvent_t ev_resolved = nullptr;
 	} ws[2];
 	hipStream_t stream2 = nullptr;
@@ -133,6 +134,7 @@ int ensure_set(WorkSet& w, size_t want_slots) {
 		w.cap = cap;
 	}
 	if ((rc = w.list_meta.ensure(TUTU_META_STRIDE * (TUTU_MAX_DEPTH + 3))) != TUTU_OK) return rc;
+	if ((rc = w.part.ensure(2 * TUTU_PART_BLOCKS * 2 + 8)) != TUTU_OK) return rc;
 	if (!w.ev_resolved) HIP_TRY(hipEventCreateWithFlags(&w.ev_resolved, hipEventDisableTiming));
 	return TUTU_OK;
 }
@@ -193,7 +195,7 @@ void launch_trace(TutuCtx* c, hipStream_t s, int grid, const TraceParams& tp) {
 
 int persistent_grid(size_t upper_items, int n_cu, int blocks_per_cu) {
 	size_t blocks = (upper_items + 255) / 256;
-	size_t maxb = (size_t)n_cu * (size_t)blocks_per_cu;
+	size_t maxb = std::min<size_t>((size_t)n_cu * (size_t)blocks_per_cu, TUTU_PART_BLOCKS);
 	if (blocks < 1) blocks = 1;
 	return (int)std::min(blocks, maxb);
 }
@@ -326,10 +328,19 @@ int run_pass(TutuCtx* c, WorkSet& w, hipStream_t s, const TutuCameraFrame* cam, 
 		tp.kB = w.kB.p;
 		tp.tri_class = c->d_tri_class.p;
 		tp.stack_entries = c->stack_entries;
+		static const int refill_min = getenv("TUTU_REFILL_MIN") ? atoi(getenv("TUTU_REFILL_MIN")) : 16;
+		tp.refill_min = refill_min;
+		static const int inner_steps = getenv("TUTU_INNER_STEPS") ? atoi(getenv("TUTU_INNER_STEPS")) : TUTU_INNER_STEPS;
+		tp.inner_steps = inner_steps;
+		tp.part = w.part.p;
+		static const bool util_stats = getenv("TUTU_UTIL_STATS") != nullptr;
+		tp.util = util_stats ? w.part.p + 4 * TUTU_PART_BLOCKS : nullptr;
 		TIMED(EV_TRACE_CLOSEST, launch_trace<false>(c, s, trace_grid, tp));
 		(*n_trace_launches)++;
 		tp.list = w.flag_lists.p + w.cap;
 		tp.n_ptr = meta + 1;
+		tp.part = w.part.p + 2 * TUTU_PART_BLOCKS;
+		if (tp.util) tp.util += 4;
 		TIMED(EV_TRACE_ANY, launch_trace<true>(c, s, trace_grid, tp));
 		rc = build_lists<LIST_CLASS>(c, w, s, n_pad, meta + 16, w.perm.p, nullptr, nullptr);
 		if (rc != TUTU_OK) return rc;
@@ -373,6 +384,27 @@ int collect_stats(TutuCtx* c, hipStream_t s, TutuStats* st, uint64_t samples, ui
 	st->segments = samples + (t.closest_rays > (uint64_t)0 ? t.closest_rays : 0) - 0;  // vertices reached: depth-0 of every sample + every extension ray
 	st->passes = passes;
 	st->trace_launches = trace_launches;
+	{
+		std::vector<unsigned long long> h(2 * TUTU_PART_BLOCKS * 2 + 8);
+		unsigned long long util[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+		for (int k = 0; k < 2; k++) {
+			if (!c->ws[k].part.p) continue;
+			HIP_TRY(hipMemcpy(h.data(), c->ws[k].part.p, sizeof(unsigned long long) * h.size(), hipMemcpyDeviceToHost));
+			for (int b = 0; b < TUTU_PART_BLOCKS; b++) {
+				st->nodes_closest += h[2 * b];
+				st->leaves_closest += h[2 * b + 1];
+				st->nodes_any += h[2 * TUTU_PART_BLOCKS + 2 * b];
+				st->leaves_any += h[2 * TUTU_PART_BLOCKS + 2 * b + 1];
+			}
+			for (int j = 0; j < 8; j++) util[j] += h[4 * TUTU_PART_BLOCKS + j];
+		}
+		if (getenv("TUTU_UTIL_STATS"))
+			fprintf(stderr, "[tutu util] closest: lanes/node-step %.1f lanes/leaf-step %.1f node-steps/outer %.2f leaf-steps/outer %.2f | any: %.1f %.1f %.2f %.2f\n",
+			        util[0] ? (double)st->nodes_closest / util[0] : 0.0, util[1] ? (double)st->leaves_closest / util[1] : 0.0,
+			        util[2] ? (double)util[0] / util[2] : 0.0, util[2] ? (double)util[1] / util[2] : 0.0,
+			        util[4] ? (double)st->nodes_any / util[4] : 0.0, util[5] ? (double)st->leaves_any / util[5] : 0.0,
+			        util[6] ? (double)util[4] / util[6] : 0.0, util[6] ? (double)util[5] / util[6] : 0.0);
+	}
 	float ms[EV_NKIND] = {0, 0, 0, 0, 0, 0};
 	uint32_t launches[EV_NKIND] = {0, 0, 0, 0, 0, 0};
 	for (size_t i = 0; i < c->ev_used; i++) {
@@ -435,6 +467,8 @@ int render_impl(TutuCtx* c, const TutuCameraFrame* cam, const TutuRenderParams* 
 	}
 	c->ev_used = 0;
 	HIP_TRY(hipMemsetAsync(c->totals.p, 0, sizeof(Totals), s));
+	for (int k = 0; k < 2; k++)
+		if (c->ws[k].part.p) HIP_TRY(hipMemsetAsync(c->ws[k].part.p, 0, sizeof(unsigned long long) * (2 * TUTU_PART_BLOCKS * 2 + 8), s));
 	if ((rc = launch_primary(c, s, cam, npix, d_pixels, nullptr, x0, y0, rect_w)) != TUTU_OK) return rc;
 	HIP_TRY(hipMemsetAsync(c->accum.p, 0, sizeof(float4) * (size_t)npix, s));
 	hipStream_t streams[2] = {s, c->stream2};
@@ -670,6 +704,8 @@ int tutu_hip_trace_samples(TutuCtx* c, const TutuCameraFrame* cam, uint32_t n, c
 	HIP_TRY(hipMemcpyAsync(c->u32b.p, smp, sizeof(uint32_t) * n, hipMemcpyHostToDevice, s));
 	c->ev_used = 0;
 	HIP_TRY(hipMemsetAsync(c->totals.p, 0, sizeof(Totals), s));
+	for (int k = 0; k < 2; k++)
+		if (c->ws[k].part.p) HIP_TRY(hipMemsetAsync(c->ws[k].part.p, 0, sizeof(unsigned long long) * (2 * TUTU_PART_BLOCKS * 2 + 8), s));
 	if ((rc = launch_primary(c, s, cam, (int)n, nullptr, c->u32a.p, 0, 0, 1)) != TUTU_OK) return rc;
 	uint32_t tl = 0;
 	if ((rc = run_pass(c, c->ws[0], s, cam, key0, key1, (int)n, 0, 1, c->u32b.p, &tl)) != TUTU_OK) return rc;
@@ -821,6 +857,10 @@ static int run_trace_kernel(TutuCtx* c, uint32_t n, bool any) {
 	tp.kB = w.kB.p;
 	tp.tri_class = c->d_tri_class.p;
 	tp.stack_entries = c->stack_entries;
+	tp.part = nullptr;
+	tp.refill_min = 1;
+	tp.inner_steps = TUTU_INNER_STEPS;
+	tp.util = nullptr;
 	const int grid = persistent_grid(n, c->n_cu, c->trace_blocks_per_cu);
 	if (any) launch_trace<true>(c, s, grid, tp);
 	else launch_trace<false>(c, s, grid, tp);
