@@ -59,6 +59,10 @@ def main():
                           "create_s": round(t_create, 3), "mean": float(img.mean()), "nan_pixels": int(np.isnan(img).any(-1).sum()),
                           "ms": {k: round(v, 1) for k, v in st.items() if k.startswith("ms_")},
                           "rays_per_sample": round((st["closest_rays"] + st["shadow_rays"]) / st["samples"], 2),
+                          "N_T_closest": [round((st["nodes_closest"] + st["leaves_closest"]) / max(st["closest_rays"] - ctx.W * ctx.H, 1), 1),
+                                          round(st["leaves_closest"] / max(st["closest_rays"] - ctx.W * ctx.H, 1), 2)],
+                          "N_T_shadow": [round((st["nodes_any"] + st["leaves_any"]) / max(st["shadow_rays"], 1), 1),
+                                         round(st["leaves_any"] / max(st["shadow_rays"], 1), 2)],
                           "parity_bad_of_400": bad, "cpu_port_us_per_sample": round(t_cpu / n * 1e6, 1)}), flush=True)
         ctx.close()
 

@@ -62,6 +62,8 @@ struct DevBuf {
 
 }  // namespace
 
+#define TUTU_MAX_SETS 4  // work sets = passes in flight, one stream each
+
 struct TutuCtx {
 	int device = 0;
 	hipStream_t stream = nullptr;
@@ -93,8 +95,8 @@ struct TutuCtx {
 		DevBuf<uint32_t> list_meta;   // per depth: flag-list counts [8] | class-list counts [8]
 		DevBuf<unsigned long long> part;  // [2 kinds][TUTU_PART_BLOCKS][2] traversal work counters
 		hipEvent_t ev_resolved = nullptr;
-	} ws[2];
-	hipStream_t stream2 = nullptr;
+	} ws[TUTU_MAX_SETS];
+	hipStream_t extra_streams[TUTU_MAX_SETS - 1] = {};  // work set k > 0 runs on extra_streams[k - 1]
 	hipEvent_t ev_fork = nullptr;
 	DevBuf<float4> prim_dir, prim_hit, accum;
 	DevBuf<Totals> totals;
@@ -387,7 +389,7 @@ int collect_stats(TutuCtx* c, hipStream_t s, TutuStats* st, uint64_t samples, ui
 	{
 		std::vector<unsigned long long> h(2 * TUTU_PART_BLOCKS * 2 + 8);
 		unsigned long long util[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-		for (int k = 0; k < 2; k++) {
+		for (int k = 0; k < TUTU_MAX_SETS; k++) {
 			if (!c->ws[k].part.p) continue;
 			HIP_TRY(hipMemcpy(h.data(), c->ws[k].part.p, sizeof(unsigned long long) * h.size(), hipMemcpyDeviceToHost));
 			for (int b = 0; b < TUTU_PART_BLOCKS; b++) {
@@ -448,14 +450,17 @@ int render_impl(TutuCtx* c, const TutuCameraFrame* cam, const TutuRenderParams* 
 		npix = rect_w * (rp->y1 - rp->y0);
 	}
 	HIP_TRY(hipSetDevice(c->device));
-	// Paths in flight: max_paths in total, split over the two work sets that alternate passes on two streams.
-	const int64_t max_paths = rp->max_paths > 0 ? rp->max_paths : ((int64_t)16 << 20);
-	int spp_pass = rp->spp_per_pass > 0 ? rp->spp_per_pass : (int)std::max<int64_t>(1, (max_paths / 2) / npix);
+	// Paths in flight: max_paths in total, split over the work sets whose passes run concurrently, one stream each
+	// (measured on the Cornell box, 512 spp: 2 sets x 8 Mi 1518 Msamples/s, 3 x 8 Mi 1619, 4 x 8..12 Mi 1645, flat beyond).
+	const int64_t max_paths = rp->max_paths > 0 ? rp->max_paths : ((int64_t)32 << 20);
+	static const int sets_env = getenv("TUTU_SETS") ? atoi(getenv("TUTU_SETS")) : 4;
+	const int want_sets = std::max(1, std::min(sets_env, TUTU_MAX_SETS));
+	int spp_pass = rp->spp_per_pass > 0 ? rp->spp_per_pass : (int)std::max<int64_t>(1, (max_paths / want_sets) / npix);
 	spp_pass = std::min(spp_pass, rp->spp);
 	spp_pass = std::min(spp_pass, 65535);  // grid.y limit
 	const int n_passes = (rp->spp + spp_pass - 1) / spp_pass;
 	static const bool one_set = getenv("TUTU_ONE_SET") != nullptr;  // profiling aid: no overlap, clean per-kernel times
-	const int n_sets = (n_passes > 1 && !one_set) ? 2 : 1;
+	const int n_sets = one_set ? 1 : std::min(want_sets, n_passes);
 	const size_t cap = (size_t)npix * (size_t)spp_pass;
 	int rc = ensure_work(c, cap, (size_t)npix, n_sets);
 	if (rc != TUTU_OK) return rc;
@@ -467,34 +472,36 @@ int render_impl(TutuCtx* c, const TutuCameraFrame* cam, const TutuRenderParams* 
 	}
 	c->ev_used = 0;
 	HIP_TRY(hipMemsetAsync(c->totals.p, 0, sizeof(Totals), s));
-	for (int k = 0; k < 2; k++)
+	for (int k = 0; k < TUTU_MAX_SETS; k++)
 		if (c->ws[k].part.p) HIP_TRY(hipMemsetAsync(c->ws[k].part.p, 0, sizeof(unsigned long long) * (2 * TUTU_PART_BLOCKS * 2 + 8), s));
 	if ((rc = launch_primary(c, s, cam, npix, d_pixels, nullptr, x0, y0, rect_w)) != TUTU_OK) return rc;
 	HIP_TRY(hipMemsetAsync(c->accum.p, 0, sizeof(float4) * (size_t)npix, s));
-	hipStream_t streams[2] = {s, c->stream2};
-	if (n_sets == 2) {  // fork: the second stream starts after the primary hits exist
+	hipStream_t streams[TUTU_MAX_SETS];
+	streams[0] = s;
+	for (int k = 1; k < TUTU_MAX_SETS; k++) streams[k] = c->extra_streams[k - 1];
+	if (n_sets > 1) {  // fork: the other streams start after the primary hits exist
 		HIP_TRY(hipEventRecord(c->ev_fork, s));
-		HIP_TRY(hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
+		for (int k = 1; k < n_sets; k++) HIP_TRY(hipStreamWaitEvent(streams[k], c->ev_fork, 0));
 	}
 	uint32_t passes = 0, trace_launches = 0;
 	for (int s0 = 0, i = 0; s0 < rp->spp; s0 += spp_pass, i++) {
-		const int k = i & (n_sets - 1);
+		const int k = i % n_sets;
 		TutuCtx::WorkSet& w = c->ws[k];
 		hipStream_t sk = streams[k];
 		const int ns = std::min(spp_pass, rp->spp - s0);
 		if ((rc = run_pass(c, w, sk, cam, rp->key0, rp->key1, npix, s0, ns, nullptr, &trace_launches)) != TUTU_OK) return rc;
 		// samples are added to the estimate in sample order (PathTracing.hpp:507-513): pass i resolves after pass i-1
-		if (i > 0 && n_sets == 2) HIP_TRY(hipStreamWaitEvent(sk, c->ws[k ^ 1].ev_resolved, 0));
+		if (i > 0 && n_sets > 1) HIP_TRY(hipStreamWaitEvent(sk, c->ws[(k + n_sets - 1) % n_sets].ev_resolved, 0));
 		{
 			hipStream_t s = sk;  // TIMED records on `s`
 			TIMED(EV_OTHER, k_resolve<<<dim3((npix + 255) / 256), dim3(256), 0, s>>>(w.qbuf[5].p, c->accum.p, npix, ns));
 		}
-		if (n_sets == 2) HIP_TRY(hipEventRecord(w.ev_resolved, sk));
+		if (n_sets > 1) HIP_TRY(hipEventRecord(w.ev_resolved, sk));
 		passes++;
 	}
-	if (n_sets == 2) {  // join
-		const int last = (int)((passes - 1) & 1u);
-		if (last == 1) HIP_TRY(hipStreamWaitEvent(s, c->ws[1].ev_resolved, 0));
+	if (n_sets > 1) {  // join: the last pass's resolve (which waited for all earlier ones) happens before the finalize
+		const int last = (int)((passes - 1) % (uint32_t)n_sets);
+		if (last != 0) HIP_TRY(hipStreamWaitEvent(s, c->ws[last].ev_resolved, 0));
 	}
 	const float spp_inv = 1.f / rp->spp;  // SPP_inv, global.hpp:20
 	TIMED(EV_OTHER, k_finalize<<<dim3((npix + 255) / 256), dim3(256), 0, s>>>(c->accum.p, d_out, npix, spp_inv));
@@ -550,7 +557,8 @@ int tutu_hip_create(const TutuSceneDesc* scene, int device, TutuCtx** out) {
 	hipDeviceProp_t prop;
 	if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
 	if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) return fail(TUTU_E_HIP);
-	if (hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) != hipSuccess) return fail(TUTU_E_HIP);
+	for (int k = 0; k < TUTU_MAX_SETS - 1; k++)
+		if (hipStreamCreateWithFlags(&c->extra_streams[k], hipStreamNonBlocking) != hipSuccess) return fail(TUTU_E_HIP);
 	if (hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess) return fail(TUTU_E_HIP);
 	hipStream_t s = c->stream;
 	if ((rc = upload(c->d_nodes, c->hs.nodes, s)) != TUTU_OK) return fail(rc);
@@ -634,16 +642,18 @@ int tutu_hip_destroy(TutuCtx* c) {
 	}
 	c->d_tri_tex.release(); c->d_texels.release(); c->d_tex_desc.release(); c->d_leaf_boxes.release();
 	c->d_tri_class.release(); c->d_nodes.release(); c->d_tri_isect.release(); c->d_tri_shade.release(); c->d_mats.release(); c->d_lights.release();
-	if (c->stream2) (void)hipStreamSynchronize(c->stream2);
-	for (int k = 0; k < 2; k++) {
+	for (int k = 0; k < TUTU_MAX_SETS - 1; k++)
+		if (c->extra_streams[k]) (void)hipStreamSynchronize(c->extra_streams[k]);
+	for (int k = 0; k < TUTU_MAX_SETS; k++) {
 		TutuCtx::WorkSet& w = c->ws[k];
 		for (int f = 0; f < 11; f++) w.qbuf[f].release();
 		w.kA.release(); w.kB.release(); w.flag_lists.release(); w.perm.release(); w.tile_counts.release(); w.tile_offsets.release();
-		w.list_meta.release();
+		w.list_meta.release(); w.part.release();
 		if (w.ev_resolved) (void)hipEventDestroy(w.ev_resolved);
 	}
 	if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
-	if (c->stream2) (void)hipStreamDestroy(c->stream2);
+	for (int k = 0; k < TUTU_MAX_SETS - 1; k++)
+		if (c->extra_streams[k]) (void)hipStreamDestroy(c->extra_streams[k]);
 	c->prim_dir.release(); c->prim_hit.release(); c->accum.release();
 	c->totals.release(); c->pixels.release(); c->u32a.release(); c->u32b.release();
 	c->out_stage.release();
@@ -704,7 +714,7 @@ int tutu_hip_trace_samples(TutuCtx* c, const TutuCameraFrame* cam, uint32_t n, c
 	HIP_TRY(hipMemcpyAsync(c->u32b.p, smp, sizeof(uint32_t) * n, hipMemcpyHostToDevice, s));
 	c->ev_used = 0;
 	HIP_TRY(hipMemsetAsync(c->totals.p, 0, sizeof(Totals), s));
-	for (int k = 0; k < 2; k++)
+	for (int k = 0; k < TUTU_MAX_SETS; k++)
 		if (c->ws[k].part.p) HIP_TRY(hipMemsetAsync(c->ws[k].part.p, 0, sizeof(unsigned long long) * (2 * TUTU_PART_BLOCKS * 2 + 8), s));
 	if ((rc = launch_primary(c, s, cam, (int)n, nullptr, c->u32a.p, 0, 0, 1)) != TUTU_OK) return rc;
 	uint32_t tl = 0;
