@@ -108,6 +108,44 @@ def test_closest_hit_many_random_rays_vs_oracle(tr, port):
     S.close()
 
 
+@pytest.mark.parametrize("name", ["cornell", "veach_slight", "cornell_spheres"])
+def test_degenerate_rays_take_the_reference_tree(tr, port, name):
+    """Rays with a zero direction component (1/d = inf: the slab products can be NaN, BoundBox.hpp:57-62) or starting
+    exactly on box planes do not walk the SAH tree but the reference's own tree: same hit, same object, same t bits,
+    same shadow answers as the reference's unordered recursion."""
+    sc, _ = _scene(name)
+    S = port.scene(sc)
+    r = pc._rng(4242)
+    n = 60000
+    V = S.verts.reshape(-1, 3)
+    lo, hi = V.min(0), V.max(0)
+    # origins: random, but a third of the coordinates snapped onto vertex coordinates (= box planes of the tree)
+    o = (lo + (hi - lo) * r.random((n, 3))).astype(np.float32)
+    snap = r.random((n, 3)) < 0.33
+    o = np.where(snap, V[r.integers(0, len(V), (n, 3)), np.arange(3)], o).astype(np.float32)
+    d = pc.unit(r, n)
+    kind = r.integers(0, 4, n)
+    axis = r.integers(0, 3, n)
+    for k in range(3):
+        d[(kind == 0) & (axis == k), k] = 0.0                    # one zero component
+        d[(kind == 1) & (axis != k), k] = 0.0                    # axis-parallel: two zero components
+    d[kind == 2, 0] = np.float32(-0.0)                           # negative zero
+    nz = np.linalg.norm(d, axis=1) > 0
+    o, d = o[nz], d[nz]
+    d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+    hit, t, tri, *_ = S.closest(o, d)
+    target = (o + d * np.float32(200.0) * r.random((len(o), 1)).astype(np.float32)).astype(np.float32)
+    blocked = S.any_hit(o, target)
+    with tr.Context(sc) as ctx:
+        hits = ctx.trace_closest(o, d)
+        got_blocked = ctx.trace_any(o, target)
+    assert count_diff(hits["tri"], tri) == 0
+    assert count_diff(np.where(tri >= 0, hits["t"], 0), np.where(tri >= 0, t, 0)) == 0
+    assert count_diff(got_blocked, blocked) == 0
+    assert 0.2 < (tri >= 0).mean() and 0.02 < blocked.mean() < 0.98
+    S.close()
+
+
 @pytest.mark.parametrize("name", [n for n, _ in pc.material_set()])
 def test_material_functions(tr, name):
     mat = dict(pc.material_set())[name]

@@ -12,7 +12,7 @@ from . import scenes  # noqa: F401
 from .scenes import MAT_DTYPE
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libtutu_hip.so")
+LIB_PATH = os.environ.get("TUTU_HIP_LIB", os.path.join(HERE, "libtutu_hip.so"))  # override: A/B runs of two builds on one box
 
 # every symbol include/tutu_hip.h declares
 ABI_SYMBOLS = [
