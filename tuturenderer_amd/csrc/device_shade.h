@@ -601,6 +601,7 @@ struct TraceParams {
 	int refill_min;  // idle lanes a wave waits for before it fetches new rays (1 = refill at once)
 	int inner_steps;  // node visits between two leaf / finish / refill rounds
 	unsigned long long* util;  // optional [3]: wave-level node steps, leaf steps, outer iterations (TUTU_UTIL_STATS)
+	int any_near_first;  // any-hit: descend into the nearer child first
 };
 
 template <typename S, bool ANY, bool SPH>
@@ -680,7 +681,7 @@ TUTU_DEV void trace_persistent(const S& ss, const TraceParams& tp, int* stack, c
 				else lim = best_tri >= 0 ? best_t * TUTU_PRUNE_SLACK : FLT_MAX;
 				const ChildTest ct = test_children(ss, cur, r, lim);
 				if (ct.hl && ct.hr) {
-					const bool right_first = !ANY && ct.tr < ct.tl;
+					const bool right_first = (!ANY || tp.any_near_first) && ct.tr < ct.tl;
 					stack[sp * 256] = right_first ? ct.left : ct.right;
 					sp++;
 					cur = right_first ? ct.right : ct.left;

@@ -334,6 +334,8 @@ int run_pass(TutuCtx* c, WorkSet& w, hipStream_t s, const TutuCameraFrame* cam, 
 		tp.refill_min = refill_min;
 		static const int inner_steps = getenv("TUTU_INNER_STEPS") ? atoi(getenv("TUTU_INNER_STEPS")) : TUTU_INNER_STEPS;
 		tp.inner_steps = inner_steps;
+		static const int any_nf = getenv("TUTU_ANY_NEAR_FIRST") ? atoi(getenv("TUTU_ANY_NEAR_FIRST")) : 1;
+		tp.any_near_first = any_nf;
 		tp.part = w.part.p;
 		static const bool util_stats = getenv("TUTU_UTIL_STATS") != nullptr;
 		tp.util = util_stats ? w.part.p + 4 * TUTU_PART_BLOCKS : nullptr;
@@ -870,6 +872,7 @@ static int run_trace_kernel(TutuCtx* c, uint32_t n, bool any) {
 	tp.part = nullptr;
 	tp.refill_min = 1;
 	tp.inner_steps = TUTU_INNER_STEPS;
+	tp.any_near_first = 1;
 	tp.util = nullptr;
 	const int grid = persistent_grid(n, c->n_cu, c->trace_blocks_per_cu);
 	if (any) launch_trace<true>(c, s, grid, tp);
