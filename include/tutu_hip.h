@@ -244,6 +244,12 @@ int tutu_hip_eval_sample_light(TutuCtx* ctx, uint32_t n, const float* xi3, int32
 /* scene facts */
 int tutu_hip_scene_info(TutuCtx* ctx, TutuBvhInfo* bvh, uint32_t* n_lights);
 
+/* Tuning / measuring knobs that do not change any result.
+ *   "sets"  number of wavefront passes in flight (1..4, 0 = default 4).  With 1, kernels run one at a time and the
+ *           per-kernel times of TutuStats are exclusive; with more, stages of different passes overlap and every
+ *           launch's duration includes the time it shares the device with others. */
+int tutu_hip_set_option(TutuCtx* ctx, const char* name, int value);
+
 #ifdef __cplusplus
 }
 #endif

@@ -16,9 +16,11 @@ from collections import defaultdict
 
 def stage(name):
     if "k_trace<" in name:
-        return "k_trace_any" if name.split("k_trace<")[1].split(">")[0].replace(" ", "").endswith("true") else "k_trace_closest"
-    if "k_shade<" in name:
-        return "k_shade"
+        params = name.split("k_trace<")[1].split(">")[0].replace(" ", "").split(",")  # <LDS_SCENE, ANY, SPH>
+        return "k_trace_any" if params[1] == "true" else "k_trace_closest"
+    if "k_shade<" in name:  # the per-material-class launches at depth >= 1 (MODE 1..4); depth 0 and connect-only are separate
+        mode = name.split("k_shade<")[1].split(",")[0].strip()
+        return "k_shade" if mode in ("1", "2", "3", "4") else None
     return None
 
 

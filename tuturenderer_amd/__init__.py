@@ -19,7 +19,7 @@ ABI_SYMBOLS = [
     "tutu_camera_frame", "tutu_bvh_build_preorder", "tutu_hip_error_string", "tutu_hip_last_error", "tutu_hip_version",
     "tutu_hip_device_count", "tutu_hip_create", "tutu_hip_destroy", "tutu_hip_render", "tutu_hip_render_device",
     "tutu_hip_trace_closest", "tutu_hip_trace_any", "tutu_hip_trace_samples", "tutu_hip_eval_bxdf", "tutu_hip_eval_pdf",
-    "tutu_hip_eval_sample", "tutu_hip_eval_sample_light", "tutu_hip_scene_info", "tutu_hip_eval_texture",
+    "tutu_hip_eval_sample", "tutu_hip_eval_sample_light", "tutu_hip_scene_info", "tutu_hip_eval_texture", "tutu_hip_set_option",
 ]
 
 
@@ -254,6 +254,9 @@ class Context:
             self.close()
         except Exception:
             pass
+
+    def set_option(self, name, value):
+        _check(self.lib.tutu_hip_set_option(self.h, C.c_char_p(name.encode()), C.c_int(int(value))), "tutu_hip_set_option")
 
     def info(self):
         b = BvhInfo()

@@ -81,6 +81,7 @@ struct TutuCtx {
 	DevBuf<float4> d_nodes, d_tri_isect, d_tri_shade, d_mats, d_lights;
 	bool textured = false;     // the scene has textured objects -> k_shade<.., EXT = true>
 	bool has_spheres = false;  // the scene has sphere leaves    -> k_trace<.., SPH = true>, k_shade<.., EXT = true>
+	int opt_sets = 0;          // tutu_hip_set_option("sets"): passes in flight, 0 = default
 	DevBuf<float4> d_tri_tex, d_texels, d_tex_desc, d_leaf_boxes;
 	DevBuf<uint8_t> d_tri_class;
 	// work buffers: two sets, so that consecutive passes run on two streams and a memory-bound stage of one pass
@@ -456,8 +457,9 @@ int render_impl(TutuCtx* c, const TutuCameraFrame* cam, const TutuRenderParams* 
 	// (measured on the Cornell box, 512 spp: 2 sets x 8 Mi 1518 Msamples/s, 3 x 8 Mi 1619, 4 x 8..12 Mi 1645, flat beyond).
 	const int64_t max_paths = rp->max_paths > 0 ? rp->max_paths : ((int64_t)32 << 20);
 	static const int sets_env = getenv("TUTU_SETS") ? atoi(getenv("TUTU_SETS")) : 4;
-	const int want_sets = std::max(1, std::min(sets_env, TUTU_MAX_SETS));
-	int spp_pass = rp->spp_per_pass > 0 ? rp->spp_per_pass : (int)std::max<int64_t>(1, (max_paths / want_sets) / npix);
+	const int want_sets = std::max(1, std::min(c->opt_sets > 0 ? c->opt_sets : sets_env, TUTU_MAX_SETS));
+	// the pass size does not depend on how many passes are in flight (tutu_hip_set_option "sets" is a measuring aid)
+	int spp_pass = rp->spp_per_pass > 0 ? rp->spp_per_pass : (int)std::max<int64_t>(1, (max_paths / TUTU_MAX_SETS) / npix);
 	spp_pass = std::min(spp_pass, rp->spp);
 	spp_pass = std::min(spp_pass, 65535);  // grid.y limit
 	const int n_passes = (rp->spp + spp_pass - 1) / spp_pass;
@@ -662,6 +664,16 @@ int tutu_hip_destroy(TutuCtx* c) {
 	if (c->stream) (void)hipStreamDestroy(c->stream);
 	delete c;
 	return TUTU_OK;
+}
+
+int tutu_hip_set_option(TutuCtx* c, const char* name, int value) {
+	if (!c || !name) return TUTU_E_INVALID;
+	if (strcmp(name, "sets") == 0) {
+		if (value < 0 || value > TUTU_MAX_SETS) return TUTU_E_INVALID;
+		c->opt_sets = value;
+		return TUTU_OK;
+	}
+	return TUTU_E_INVALID;
 }
 
 int tutu_hip_scene_info(TutuCtx* c, TutuBvhInfo* bvh, uint32_t* n_lights) {
