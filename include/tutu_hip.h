@@ -244,6 +244,15 @@ int tutu_hip_eval_sample_light(TutuCtx* ctx, uint32_t n, const float* xi3, int32
 /* scene facts */
 int tutu_hip_scene_info(TutuCtx* ctx, TutuBvhInfo* bvh, uint32_t* n_lights);
 
+/* Post-processing of a finished linear-radiance frame (width*height*3 floats, row-major) on the device:
+ * Postprocessor.hpp under HDR_BLOOM (global.hpp:32).  stage 0 = Postprocessor::performPostProcess (:29-57: emissive
+ * extraction, Gaussian blur twice, + original, exposure tone map), 1 = getEmmisiveTexture (:128-155),
+ * 2 = getGaussianBlurTexture(KERNELSIZE 10, STDDEV 30) (:62-125), 3 = getHDRtexture (:178-201).  Bit-exact up to exp(). */
+int tutu_hip_postprocess(TutuCtx* ctx, int32_t stage, int32_t width, int32_t height, const float* rgb_in, float* rgb_out);
+/* PPMGenerator::writePixel's channel mapping with GAMMA_COORECTION (PPMGenerator.hpp:825-843):
+ * level = (int)(255 * pow(clamp(0, 1, c), 0.78f)) for each of the n values. */
+int tutu_hip_quantise(TutuCtx* ctx, uint32_t n, const float* values, int32_t* levels);
+
 /* Tuning / measuring knobs that do not change any result.
  *   "sets"  number of wavefront passes in flight (1..4, 0 = default 4).  With 1, kernels run one at a time and the
  *           per-kernel times of TutuStats are exclusive; with more, stages of different passes overlap and every

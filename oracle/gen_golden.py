@@ -81,6 +81,8 @@ def main():
     fn["philox.stream"] = R.rng_stream(12345, 7, pc.KEY0, 2, 64)
     for k, v in pc.run_texture(R, scenes.procedural_maps()["diffuse"][0]).items():
         fn[f"texture.{k}"] = v
+    for k, v in pc.run_postprocess(R).items():
+        fn[f"post.{k}"] = v
     np.savez_compressed(os.path.join(GOLD, "functions.npz"), **fn)
 
     # ---- scene-level vectors + per-sample radiance

@@ -92,6 +92,11 @@ int tor_write_pixel(int n, const float* c, int32_t* out);
 /* Texture::getRGBat (Texture.hpp:18-39) on one texture */
 int tor_texture_lookup(const struct TorTexture* t, int n, const float* u, const float* v, float* rgb);
 
+/* ---- post-processing: Postprocessor.hpp with HDR_BLOOM (global.hpp:32) ----
+ * stage 0 = the whole performPostProcess (bloom then exposure tone map), 1 = getEmmisiveTexture, 2 = getGaussianBlurTexture
+ * (KERNELSIZE 10, STDDEV 30), 3 = getHDRtexture alone.  in / out: width*height*3 floats. */
+int tor_postprocess(int stage, int width, int height, const float* in, float* out);
+
 /* ---- material (one material, n evaluations) ---- */
 int tor_mat_bxdf(int n, const TorMaterial* m, const float* wi, const float* wo, const float* Ng, const float* Ns,
                  float eta_scene, const uint8_t* tir, float* out3);

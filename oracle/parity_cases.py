@@ -311,3 +311,21 @@ def texture_inputs(n=4000, seed=31):
 def run_texture(O, img):
     u, v = texture_inputs()
     return {"in_crc": checksum(u, v, np.ascontiguousarray(img, np.float32)), "rgb": O.texture_lookup(img, u, v)}
+
+
+def postprocess_input(h=40, w=56, seed=41):
+    """an HDR image with a few pixels above the bloom threshold (|c| > 3) and a bright patch"""
+    r = np.random.default_rng(seed)
+    img = (r.random((h, w, 3), dtype=np.float32) ** 4 * np.float32(6)).astype(np.float32)
+    img[10:14, 20:26] = [9, 7, 5]
+    img[0, 0] = [4, 4, 4]
+    img[h - 1, w - 1] = [0.5, 8, 0.25]
+    return img
+
+
+def run_postprocess(O):
+    img = postprocess_input()
+    out = {"in_crc": checksum(img)}
+    for stage, name in ((0, "full"), (1, "emissive"), (2, "blur"), (3, "hdr")):
+        out[name] = O.postprocess(stage, img)
+    return out

@@ -231,6 +231,14 @@ class Oracle:
         self.lib.tor_texture_lookup(C.byref(t), C.c_int(len(u)), _p(u), _p(v), _p(out))
         return out
 
+    def postprocess(self, stage, img):
+        """Postprocessor.hpp: 0 = performPostProcess (HDR_BLOOM), 1 = emissive, 2 = Gaussian blur, 3 = tone map"""
+        img = np.ascontiguousarray(img, dtype=np.float32)
+        out = np.empty_like(img)
+        rc = self.lib.tor_postprocess(C.c_int(stage), C.c_int(img.shape[1]), C.c_int(img.shape[0]), _p(img), _p(out))
+        assert rc == 0, rc
+        return out
+
     def write_pixel(self, c):
         c = _f32(c).ravel()
         out = np.empty(len(c), np.int32)

@@ -13,6 +13,7 @@
 #include "Renderer.hpp" // the reference's umbrella header (pulls PathTracing.hpp, BVH.hpp, Material.hpp, ...)
 #include "OBJ_Loader.h"
 #include "Sphere.hpp"
+#include "Postprocessor.hpp"
 
 #include "oracle_abi.h"
 
@@ -293,6 +294,27 @@ int tor_write_pixel(int n, const float* c, int32_t* out) {
 		color.x = 255 * pow(clamp(0, 1, color.x), GAMMA_VAL);
 		out[i] = (int)color.x;
 	}
+	return 0;
+}
+
+// Postprocessor.hpp, the functions performPostProcess calls under HDR_BLOOM (global.hpp:32)
+int tor_postprocess(int stage, int width, int height, const float* in, float* out) {
+	Texture src;
+	src.width = width;
+	src.height = height;
+	src.rgb.resize((size_t)width * height);
+	for (size_t i = 0; i < src.rgb.size(); i++) src.rgb[i] = V(in + 3 * i);
+	Postprocessor p(&src);
+	Texture res;
+	switch (stage) {
+	case 0: res = p.performPostProcess(); break;
+	case 1: res = p.getEmmisiveTexture(&src); break;
+	case 2: res = p.getGaussianBlurTexture(&src, KERNELSIZE, STDDEV); break;
+	case 3: res = p.getHDRtexture(&src); break;
+	default: return -1;
+	}
+	if ((size_t)res.width * res.height != src.rgb.size()) return -2;
+	for (size_t i = 0; i < res.rgb.size(); i++) S(out + 3 * i, res.rgb[i]);
 	return 0;
 }
 

@@ -1254,6 +1254,122 @@ int tor_texture_lookup(const struct TorTexture* t, int n, const float* u, const 
 	return 0;
 }
 
+// ---- Postprocessor.hpp (HDR_BLOOM, global.hpp:32).  Every read goes through Texture::getRGBat with
+// clamp(0, 0.999, x / w): column 0 / row 0 map to u = 0, which getRGBat turns into 1 -- the texel one row down, or
+// the last texel of the image [sic].
+static Texture post_emissive(const Texture& src) {  // getEmmisiveTexture, Postprocessor.hpp:128-155
+	Texture res;
+	res.width = src.width;
+	res.height = src.height;
+	const int h = res.height, w = res.width;
+	res.rgb.assign((size_t)w * h, V3());
+	for (int y = 0; y < h; y++)
+		for (int x = 0; x < w; x++) {
+			float U = (float)x / w;
+			float V = (float)y / h;
+			V3 col = src.getRGBat(clampf(0, 0.999f, U), clampf(0, 0.999f, V));
+			if (norm(col) > 3.f) {
+				float mx = col.x > col.y ? col.x : col.y;
+				mx = mx > col.z ? mx : col.z;
+				// rescale(input, originMax = mx, 0, targetMax = STRENGTH = 2, 0), global.hpp:66-68
+				V3& color = res.rgb[(size_t)y * w + x];
+				color.x = 0.f + ((2.f - 0.f) * (col.x - 0.f) / (mx - 0.f));
+				color.y = 0.f + ((2.f - 0.f) * (col.y - 0.f) / (mx - 0.f));
+				color.z = 0.f + ((2.f - 0.f) * (col.z - 0.f) / (mx - 0.f));
+			}
+		}
+	return res;
+}
+static inline float post_gaussian(int inputX, float standardDev) {  // Postprocessor.hpp:73-75
+	static float E = 2.7182818f;
+	return (1 / sqrtf(2 * kPi * standardDev)) * powf(E, -(inputX * inputX) / (2 * standardDev * standardDev));
+}
+static Texture post_blur(const Texture& img, int kernelSize, float stddev) {  // getGaussianBlurTexture, :62-125
+	Texture src = img;
+	Texture res;
+	res.width = src.width;
+	res.height = src.height;
+	const int h = res.height, w = res.width;
+	res.rgb.assign((size_t)w * h, V3());
+	for (int y = 0; y < h; y++)
+		for (int x = 0; x < w; x++) {
+			int startY = -kernelSize * 0.5;
+			V3 col;
+			float kernelSum = 0;
+			for (int i = 0; i < kernelSize; i++) {
+				float U = (float)x / w;
+				float V = (float)(y + i + startY) / h;
+				float gauss = post_gaussian((startY + i), stddev);
+				col = col + src.getRGBat(clampf(0, 0.999f, U), clampf(0, 0.999f, V)) * gauss;
+				kernelSum += gauss;
+			}
+			res.rgb[(size_t)y * w + x] = col / kernelSum;
+		}
+	src = res;
+	for (int y = 0; y < h; y++)
+		for (int x = 0; x < w; x++) {
+			int startX = -kernelSize * 0.5;
+			V3 col;
+			float kernelSum = 0;
+			for (int i = 0; i < kernelSize; i++) {
+				float U = (float)(x + i + startX) / w;
+				float V = (float)y / h;
+				float gauss = post_gaussian((startX + i), stddev);
+				col = col + src.getRGBat(clampf(0, 0.999f, U), clampf(0, 0.999f, V)) * gauss;
+				kernelSum += gauss;
+			}
+			res.rgb[(size_t)y * w + x] = col / kernelSum;
+		}
+	return res;
+}
+static Texture post_hdr(const Texture& src) {  // getHDRtexture, :178-201, EXPOSURE 1.5
+	Texture dst;
+	dst.width = src.width;
+	dst.height = src.height;
+	dst.rgb.assign((size_t)dst.width * dst.height, V3());
+	for (int y = 0; y < dst.height; y++)
+		for (int x = 0; x < dst.width; x++) {
+			float U = (float)x / dst.width;
+			float V = (float)y / dst.height;
+			V3 hdr = src.getRGBat(clampf(0, 0.999f, U), clampf(0, 0.999f, V));
+			V3 mapped;
+			mapped.x = 1 - expf(-hdr.x * 1.5f);
+			mapped.y = 1 - expf(-hdr.y * 1.5f);
+			mapped.z = 1 - expf(-hdr.z * 1.5f);
+			dst.rgb[(size_t)y * src.width + x] = mapped;
+		}
+	return dst;
+}
+int tor_postprocess(int stage, int width, int height, const float* in, float* out) {
+	Texture src;
+	src.width = width;
+	src.height = height;
+	src.rgb.resize((size_t)width * height);
+	for (size_t i = 0; i < src.rgb.size(); i++) src.rgb[i] = L(in + 3 * i);
+	Texture res;
+	switch (stage) {
+	case 0: {  // performPostProcess, :29-57: emissive -> blur -> blur (GAUSSIANLOOP 1) -> + original -> tone map
+		Texture e = post_emissive(src);
+		Texture b = post_blur(e, 10, 30.f);
+		b = post_blur(b, 10, 30.f);
+		Texture sum = src;
+		for (size_t i = 0; i < sum.rgb.size(); i++) {
+			sum.rgb[i].x += b.rgb[i].x;
+			sum.rgb[i].y += b.rgb[i].y;
+			sum.rgb[i].z += b.rgb[i].z;
+		}
+		res = post_hdr(sum);
+		break;
+	}
+	case 1: res = post_emissive(src); break;
+	case 2: res = post_blur(src, 10, 30.f); break;
+	case 3: res = post_hdr(src); break;
+	default: return -1;
+	}
+	for (size_t i = 0; i < res.rgb.size(); i++) ST(out + 3 * i, res.rgb[i]);
+	return 0;
+}
+
 // PPMGenerator.hpp:825-843: 255 * pow(clamp(0,1,c), 0.78f) -> (int)
 int tor_write_pixel(int n, const float* c, int32_t* out) {
 	for (int i = 0; i < n; i++) {

@@ -146,6 +146,36 @@ def test_degenerate_rays_take_the_reference_tree(tr, port, name):
     S.close()
 
 
+def test_postprocess_and_quantise(tr, port):
+    """Postprocessor.hpp (HDR_BLOOM) and writePixel's gamma mapping on the device against the reference build's
+    outputs: emissive extraction, Gaussian blur and the add are + - * / sqrt only -> bit-exact; the tone map goes
+    through exp (formed in double, rounded once) and the quantisation through pow -> equal except for isolated
+    last-bit / level differences."""
+    from tuturenderer_amd import scenes
+
+    z = np.load(golden_path("functions.npz"))
+    img = pc.postprocess_input()
+    with tr.Context(scenes.cornell_box(8, 8)) as ctx:
+        assert bit_equal(ctx.postprocess(img, 1), z["post.emissive"])
+        assert bit_equal(ctx.postprocess(img, 2), z["post.blur"])
+        for stage, key in ((3, "post.hdr"), (0, "post.full")):
+            got = ctx.postprocess(img, stage)
+            # 1 - exp(..): one ulp of an exp() near 1 is 6e-8 absolute, many ulps of the small difference
+            assert (got != z[key]).mean() < 2e-3 and np.abs(got - z[key]).max() <= 1.2e-7, key
+        # a full frame: the reference's post-process of a rendered image
+        frame = ctx.render(4, pc.KEY0, 1)
+        c = np.linspace(-0.2, 1.3, 100001, dtype=np.float32)
+        lv = ctx.quantise(c)
+    want = port.write_pixel(c)
+    assert (lv != want).mean() < 1e-4 and np.abs(lv - want).max() <= 1
+    assert lv.min() == 0 and lv.max() == 255
+    with tr.Context(scenes.cornell_box(64, 64)) as ctx:
+        frame = ctx.render(4, pc.KEY0, 1)
+        got = ctx.postprocess(frame, 0)
+    ref = port.postprocess(0, frame)
+    assert (got != ref).mean() < 2e-3 and np.abs(got - ref).max() <= 1.2e-7
+
+
 @pytest.mark.parametrize("name", [n for n, _ in pc.material_set()])
 def test_material_functions(tr, name):
     mat = dict(pc.material_set())[name]

@@ -56,6 +56,12 @@ def test_texture_lookup(port, fn_golden):
     assert_dict_bit_equal(pc.run_texture(port, scenes.procedural_maps()["diffuse"][0]), _sub(fn_golden, "texture."), "texture.")
 
 
+def test_postprocess(port, fn_golden):
+    """Postprocessor.hpp under HDR_BLOOM: emissive extraction, separable Gaussian, add, exposure tone map -- including
+    the u = 0 -> 1 quirk of the getRGBat reads in column 0 / row 0"""
+    assert_dict_bit_equal(pc.run_postprocess(port), _sub(fn_golden, "post."), "post.")
+
+
 @pytest.mark.parametrize("name", [n for n, _ in pc.material_set()])
 def test_material(port, fn_golden, name):
     mat = dict(pc.material_set())[name]

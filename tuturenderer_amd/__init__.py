@@ -19,7 +19,7 @@ ABI_SYMBOLS = [
     "tutu_camera_frame", "tutu_bvh_build_preorder", "tutu_hip_error_string", "tutu_hip_last_error", "tutu_hip_version",
     "tutu_hip_device_count", "tutu_hip_create", "tutu_hip_destroy", "tutu_hip_render", "tutu_hip_render_device",
     "tutu_hip_trace_closest", "tutu_hip_trace_any", "tutu_hip_trace_samples", "tutu_hip_eval_bxdf", "tutu_hip_eval_pdf",
-    "tutu_hip_eval_sample", "tutu_hip_eval_sample_light", "tutu_hip_scene_info", "tutu_hip_eval_texture", "tutu_hip_set_option",
+    "tutu_hip_eval_sample", "tutu_hip_eval_sample_light", "tutu_hip_scene_info", "tutu_hip_eval_texture", "tutu_hip_set_option", "tutu_hip_postprocess", "tutu_hip_quantise",
 ]
 
 
@@ -254,6 +254,20 @@ class Context:
             self.close()
         except Exception:
             pass
+
+    def postprocess(self, img, stage=0):
+        """Postprocessor.hpp on the device: 0 = performPostProcess (HDR_BLOOM), 1 = emissive, 2 = Gaussian blur, 3 = tone map"""
+        img = np.ascontiguousarray(img, dtype=np.float32)
+        out = np.empty_like(img)
+        _check(self.lib.tutu_hip_postprocess(self.h, C.c_int32(stage), C.c_int32(img.shape[1]), C.c_int32(img.shape[0]), _p(img), _p(out)),
+               "tutu_hip_postprocess")
+        return out
+
+    def quantise(self, values):
+        v = _f32(values)
+        out = np.empty(v.shape, np.int32)
+        _check(self.lib.tutu_hip_quantise(self.h, C.c_uint32(v.size), _p(v), _p(out)), "tutu_hip_quantise")
+        return out
 
     def set_option(self, name, value):
         _check(self.lib.tutu_hip_set_option(self.h, C.c_char_p(name.encode()), C.c_int(int(value))), "tutu_hip_set_option")

@@ -13,6 +13,7 @@
 
 #include "../../include/tutu_hip.h"
 #include "device_shade.h"
+#include "device_post.h"
 #include "host_scene.hpp"
 
 using namespace tutu;
@@ -1054,6 +1055,72 @@ int tutu_hip_eval_sample_light(TutuCtx* c, uint32_t n, const float* xi3, int32_t
 	HIP_TRY(hipMemcpy(pos, d_pos, sizeof(float) * 3 * (size_t)n, hipMemcpyDeviceToHost));
 	HIP_TRY(hipMemcpy(nrm, d_nrm, sizeof(float) * 3 * (size_t)n, hipMemcpyDeviceToHost));
 	HIP_TRY(hipMemcpy(pdf, d_pdf, sizeof(float) * (size_t)n, hipMemcpyDeviceToHost));
+	return TUTU_OK;
+}
+
+int tutu_hip_postprocess(TutuCtx* c, int32_t stage, int32_t width, int32_t height, const float* rgb_in, float* rgb_out) {
+	if (!c || !rgb_in || !rgb_out || width <= 0 || height <= 0 || stage < 0 || stage > 3) return TUTU_E_INVALID;
+	if ((int64_t)width * height > (int64_t)1 << 28) return TUTU_E_INVALID;
+	HIP_TRY(hipSetDevice(c->device));
+	const size_t n = (size_t)width * height;
+	Scratch sc;
+	float *d_in, *d_a, *d_b, *d_c;
+	RC(sc.up(rgb_in, 3 * n, &d_in));
+	RC(sc.alloc(3 * n, &d_a));
+	RC(sc.alloc(3 * n, &d_b));
+	RC(sc.alloc(3 * n, &d_c));
+	// the ten Gaussian weights exactly as the reference's lambda forms them (Postprocessor.hpp:73-75, E = 2.7182818f)
+	PostWeights pw;
+	pw.sum = 0.f;
+	{
+		const float E = 2.7182818f, stddev = 30.f, kPi = 3.1415926535897f;
+		for (int k = 0; k < TUTU_POST_KERNEL; k++) {
+			const int inputX = -(TUTU_POST_KERNEL / 2) + k;
+			pw.g[k] = (1 / sqrtf(2 * kPi * stddev)) * powf(E, -(inputX * inputX) / (2 * stddev * stddev));
+			pw.sum += pw.g[k];
+		}
+	}
+	hipStream_t s = c->stream;
+	const dim3 g((unsigned)((n + 255) / 256)), g3((unsigned)((3 * n + 255) / 256)), b(256);
+	auto blur = [&](const float* src, float* tmp, float* dst) {  // getGaussianBlurTexture: vertical, then horizontal
+		k_post_blur<true><<<g, b, 0, s>>>(src, tmp, width, height, pw);
+		k_post_blur<false><<<g, b, 0, s>>>(tmp, dst, width, height, pw);
+	};
+	float* result = d_a;
+	switch (stage) {
+	case 0:  // performPostProcess, Postprocessor.hpp:29-57
+		k_post_emissive<<<g, b, 0, s>>>(d_in, d_a, width, height);
+		blur(d_a, d_b, d_c);
+		blur(d_c, d_b, d_a);  // GAUSSIANLOOP 1
+		k_post_add<<<g3, b, 0, s>>>(d_in, d_a, d_b, (int)(3 * n));
+		k_post_hdr<<<g, b, 0, s>>>(d_b, d_c, width, height);
+		result = d_c;
+		break;
+	case 1: k_post_emissive<<<g, b, 0, s>>>(d_in, d_a, width, height); break;
+	case 2:
+		blur(d_in, d_b, d_a);
+		break;
+	default: k_post_hdr<<<g, b, 0, s>>>(d_in, d_a, width, height); break;
+	}
+	HIP_TRY(hipGetLastError());
+	HIP_TRY(hipStreamSynchronize(s));
+	HIP_TRY(hipMemcpy(rgb_out, result, sizeof(float) * 3 * n, hipMemcpyDeviceToHost));
+	return TUTU_OK;
+}
+
+int tutu_hip_quantise(TutuCtx* c, uint32_t n, const float* values, int32_t* levels) {
+	if (!c || !values || !levels) return TUTU_E_INVALID;
+	if (n == 0) return TUTU_OK;
+	HIP_TRY(hipSetDevice(c->device));
+	Scratch sc;
+	float* d_in;
+	int32_t* d_out;
+	RC(sc.up(values, (size_t)n, &d_in));
+	RC(sc.alloc((size_t)n, &d_out));
+	k_post_quantise<<<dim3((n + 255) / 256), dim3(256), 0, c->stream>>>(d_in, d_out, n);
+	HIP_TRY(hipGetLastError());
+	HIP_TRY(hipStreamSynchronize(c->stream));
+	HIP_TRY(hipMemcpy(levels, d_out, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost));
 	return TUTU_OK;
 }
 

@@ -793,10 +793,29 @@ public:
 	IIntegrator* integrator = nullptr;
 };
 
-// Constructed by every reference main, never run (the performPostProcess() call is commented out there,
-// src/main_cornellBox.cpp:84).  Bloom / tone mapping are a "next" row.
+// Constructed by every reference main; the performPostProcess() call is commented out there
+// (src/main_cornellBox.cpp:84).  Under HDR_BLOOM (global.hpp:32) it is bloom + exposure tone mapping
+// (Postprocessor.hpp:29-57); here the four passes run on the GPU (tutu_hip_postprocess).
 class Postprocessor {
 public:
 	Texture* source;
 	explicit Postprocessor(Texture* src) : source(src) {}
+	Texture performPostProcess() {
+		Texture out;
+		out.width = source->width;
+		out.height = source->height;
+		out.rgb.resize(source->rgb.size());
+		if (out.rgb.empty()) return out;
+		TutuSceneDesc sd;
+		std::memset(&sd, 0, sizeof(sd));  // an empty scene: the context only provides the device and its stream
+		TutuCtx* ctx = nullptr;
+		int rc = tutu_hip_create(&sd, 0, &ctx);
+		if (rc == TUTU_OK) rc = tutu_hip_postprocess(ctx, 0, source->width, source->height, &source->rgb[0].x, &out.rgb[0].x);
+		if (rc != TUTU_OK) {
+			std::cout << "ERROR: post-processing: " << tutu_hip_error_string(rc) << " " << tutu_hip_last_error() << "\n";
+			exit(-1);
+		}
+		tutu_hip_destroy(ctx);
+		return out;
+	}
 };
