@@ -463,7 +463,13 @@ int render_impl(TutuCtx* c, const TutuCameraFrame* cam, const TutuRenderParams* 
 	int spp_pass = rp->spp_per_pass > 0 ? rp->spp_per_pass : (int)std::max<int64_t>(1, (max_paths / TUTU_MAX_SETS) / npix);
 	spp_pass = std::min(spp_pass, rp->spp);
 	spp_pass = std::min(spp_pass, 65535);  // grid.y limit
-	const int n_passes = (rp->spp + spp_pass - 1) / spp_pass;
+	int n_passes = (rp->spp + spp_pass - 1) / spp_pass;
+	if (rp->spp_per_pass <= 0 && n_passes > want_sets && n_passes % want_sets != 0) {
+		// equal passes, a whole number of them per stream: no stream is left alone with a last pass
+		n_passes = (n_passes + want_sets - 1) / want_sets * want_sets;
+		spp_pass = (rp->spp + n_passes - 1) / n_passes;
+		n_passes = (rp->spp + spp_pass - 1) / spp_pass;
+	}
 	static const bool one_set = getenv("TUTU_ONE_SET") != nullptr;  // profiling aid: no overlap, clean per-kernel times
 	const int n_sets = one_set ? 1 : std::min(want_sets, n_passes);
 	const size_t cap = (size_t)npix * (size_t)spp_pass;
