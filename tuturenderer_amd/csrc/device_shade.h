@@ -70,6 +70,9 @@ struct PassParams {
 	const uint32_t* cls_count;  // [8] entries per class list (the lists are packed back to back in `perm`)
 	uint32_t class_mask;        // classes this launch shades
 	int n_mats;
+	int mixed;                     // 1: `perm` is the plain list of continuing slots, classes come from kB (single-class scenes)
+	const uint32_t* mixed_count;   // its length
+	const uint8_t* kB;
 };
 
 // Small read-only tables of the shade stage.  TAB selects where they live:
@@ -242,7 +245,9 @@ TUTU_DEV void texture_modify(const SceneDev& sc, int tri, float b1, float b2, bo
 //   SHADE_GGXR        MICROFACET_R                    SHADE_TERMINAL UNLIT, emissive hit, miss: connect + end
 // Specialisation removes the other materials' code (and registers) from each kernel; results are written to the
 // path's slot as soon as they exist, so few values stay live across the BSDF code.
-enum ShadeMode { SHADE_FIRST = 0, SHADE_LAMBERT = 1, SHADE_MIRROR = 2, SHADE_REFRACT = 3, SHADE_GGXR = 4, SHADE_TERMINAL = 5 };
+enum ShadeMode { SHADE_FIRST = 0, SHADE_LAMBERT = 1, SHADE_MIRROR = 2, SHADE_REFRACT = 3, SHADE_GGXR = 4, SHADE_TERMINAL = 5, SHADE_ANY = 6 };
+//   SHADE_ANY         every class in one launch over the unsorted list of continuing slots (scenes with several
+//                     scattering classes): the material switch is per lane, the records are read in slot order
 
 // EXT: the scene has textured objects (textureModify runs between the refractive test and everything else,
 // PathTracing.hpp:152-158) and/or spheres (hit point and normals from the sphere record, Sphere.hpp:44-53); the
@@ -262,7 +267,11 @@ __global__ void __launch_bounds__(256) k_shade(PassParams pp) {
 	uint32_t base[TUTU_NCLASS];
 	uint32_t pref[TUTU_NCLASS + 1];
 	uint32_t total_chunks = 0;
-	if (!FIRST) {
+	if (!FIRST && pp.mixed) {
+		// one scattering class in the whole scene: no class sort -- the launch walks the plain list of continuing
+		// slots and every lane reads its own class (the connect-only classes are a minority of masked lanes)
+		total_chunks = (*pp.mixed_count + 63u) >> 6;
+	} else if (!FIRST) {
 		pref[0] = 0;
 		uint32_t run = 0;
 #pragma unroll
@@ -280,13 +289,21 @@ __global__ void __launch_bounds__(256) k_shade(PassParams pp) {
 
 	for (uint32_t chunk = FIRST ? 0u : wave_global; FIRST ? (chunk == 0u) : (chunk < total_chunks); chunk += n_waves) {
 		bool act;
-		int chunk_class = 0;  // wave-uniform (class boundaries are padded to a wave)
+		int chunk_class = 0;  // wave-uniform (class boundaries are padded to a wave); per lane when the list is not class-sorted
 		uint32_t idx = 0;   // work item (FIRST only)
 		uint32_t slot = 0;  // the path's slot
 		if (FIRST) {
 			idx = blockIdx.x * blockDim.x + threadIdx.x;
 			act = idx < (uint32_t)pp.npix;
 			slot = pp.smp_list ? idx : blockIdx.y * (uint32_t)pp.npix + idx;
+		} else if (pp.mixed) {
+			const uint32_t j = chunk * 64u + lane;
+			act = j < *pp.mixed_count;
+			if (act) {
+				slot = pp.perm[j];
+				chunk_class = pp.kB[slot] & 7;
+				act = (pp.class_mask >> chunk_class) & 1u;
+			}
 		} else {
 			uint32_t cb = base[0], cn = cnt[0], cp = 0;
 #pragma unroll
@@ -441,7 +458,7 @@ __global__ void __launch_bounds__(256) k_shade(PassParams pp) {
 					Ladd = beta * m.diffuse;
 					added = true;
 				}  // emissive at depth > 0 adds nothing (:164-165); unknown material types end like their `default:` branches
-			} else if ((FIRST || MODE == SHADE_REFRACT) && refractive) {
+			} else if ((FIRST || MODE == SHADE_REFRACT || MODE == SHADE_ANY) && refractive) {
 				// calcForRefractive, PathTracing.hpp:80-134
 				float eta_i = sc.eta, eta_t = m.eta;
 				V3 wi = mk1(0.f);

@@ -83,6 +83,8 @@ struct TutuCtx {
 	bool textured = false;     // the scene has textured objects -> k_shade<.., EXT = true>
 	bool has_spheres = false;  // the scene has sphere leaves    -> k_trace<.., SPH = true>, k_shade<.., EXT = true>
 	int opt_sets = 0;          // tutu_hip_set_option("sets"): passes in flight, 0 = default
+	bool no_class_sort = true; // shade walks the unsorted list of continuing slots (TUTU_CLASS_SORT=1: per-class launches over class-sorted lists)
+	int shade_mode_all = SHADE_ANY;  // the kernel of that launch: the scene's only scattering class, or SHADE_ANY
 	DevBuf<float4> d_tri_tex, d_texels, d_tex_desc, d_leaf_boxes;
 	DevBuf<uint8_t> d_tri_class;
 	// work buffers: two sets, so that consecutive passes run on two streams and a memory-bound stage of one pass
@@ -251,6 +253,7 @@ int launch_shade(TutuCtx* c, hipStream_t s, int mode, dim3 grid, const PassParam
 	case SHADE_MIRROR: return launch_shade_tab<SHADE_MIRROR>(c, s, grid, pp);
 	case SHADE_REFRACT: return launch_shade_tab<SHADE_REFRACT>(c, s, grid, pp);
 	case SHADE_GGXR: return launch_shade_tab<SHADE_GGXR>(c, s, grid, pp);
+	case SHADE_ANY: return launch_shade_tab<SHADE_ANY>(c, s, grid, pp);
 	default: return launch_shade_tab<SHADE_TERMINAL>(c, s, grid, pp);
 	}
 }
@@ -297,6 +300,26 @@ int run_pass(TutuCtx* c, WorkSet& w, hipStream_t s, const TutuCameraFrame* cam, 
 			// that only connect and end (UNLIT, emissive hit, miss) ride along with the first launch
 			uint32_t* pm = w.list_meta.p + (size_t)TUTU_META_STRIDE * (d - 1);
 			pp.cls_count = pm + 16;
+			const bool last = d == TUTU_MAX_DEPTH + 1;
+			if (c->no_class_sort) {
+				// No sort by material: the launch walks the plain (slot-ordered) list of continuing slots of the previous
+				// stage and every lane reads its class from kB.  Records are then read and written in slot order by
+				// ONE launch instead of being split into per-class groups -- the shade stage is bound by its record
+				// traffic, and the sorted groups made that traffic sparser (Cornell: 109 -> 94 ms per frame, and the
+				// class lists' count / scan / scatter launches go away: 26 -> 15 ms).
+				pp.mixed = 1;
+				pp.mixed_count = pm + 0;
+				pp.perm = w.flag_lists.p;
+				pp.kB = w.kB.p;
+				const uint32_t terminal = (1u << TUTU_UNLIT) | (1u << TUTU_CLASS_EMISSIVE) | (1u << TUTU_CLASS_MISS);
+				// the last stage only connects vertex MAX_DEPTH (classes emissive / miss / UNLIT can still add radiance)
+				pp.class_mask = last ? terminal : 0xFFu;
+				const int mode = last ? SHADE_TERMINAL : c->shade_mode_all;
+				rc = launch_shade(c, s, mode, dim3(shade_grid), pp);
+				if (rc != TUTU_OK) return rc;
+				if (last) break;
+				goto shaded;
+			}
 			const uint32_t types = c->type_mask;
 			uint32_t extra = (1u << TUTU_UNLIT) | (1u << TUTU_CLASS_EMISSIVE) | (1u << TUTU_CLASS_MISS);
 			const struct { int mode; uint32_t mask; } groups[4] = {
@@ -306,7 +329,6 @@ int run_pass(TutuCtx* c, WorkSet& w, hipStream_t s, const TutuCameraFrame* cam, 
 			    {SHADE_GGXR, 1u << TUTU_MICROFACET_R}};
 			// the last stage only connects vertex MAX_DEPTH: nothing but a BSDF ray that landed on a light (or the
 			// background behind a refractive vertex) can still add radiance -> classes emissive / miss only
-			const bool last = d == TUTU_MAX_DEPTH + 1;
 			for (int gi = 0; gi < 4 && !last; gi++) {
 				if (!(types & groups[gi].mask)) continue;
 				pp.class_mask = groups[gi].mask | extra;
@@ -320,6 +342,7 @@ int run_pass(TutuCtx* c, WorkSet& w, hipStream_t s, const TutuCameraFrame* cam, 
 				if (rc != TUTU_OK) return rc;
 			}
 		}
+	shaded:
 		if (d == TUTU_MAX_DEPTH + 1) break;  // the last shade only connects; nothing continues
 		rc = build_lists<LIST_FLAGS>(c, w, s, n_pad, meta, w.flag_lists.p, &c->totals.p->closest_rays, &c->totals.p->shadow_rays);
 		if (rc != TUTU_OK) return rc;
@@ -348,8 +371,10 @@ int run_pass(TutuCtx* c, WorkSet& w, hipStream_t s, const TutuCameraFrame* cam, 
 		tp.part = w.part.p + 2 * TUTU_PART_BLOCKS;
 		if (tp.util) tp.util += 4;
 		TIMED(EV_TRACE_ANY, launch_trace<true>(c, s, trace_grid, tp));
-		rc = build_lists<LIST_CLASS>(c, w, s, n_pad, meta + 16, w.perm.p, nullptr, nullptr);
-		if (rc != TUTU_OK) return rc;
+		if (!c->no_class_sort) {
+			rc = build_lists<LIST_CLASS>(c, w, s, n_pad, meta + 16, w.perm.p, nullptr, nullptr);
+			if (rc != TUTU_OK) return rc;
+		}
 	}
 	return TUTU_OK;
 }
@@ -630,6 +655,19 @@ int tutu_hip_create(const TutuSceneDesc* scene, int device, TutuCtx** out) {
 	c->type_mask = 0;
 	for (const GpuMaterial& m : c->hs.mats)
 		if (m.type >= 0 && m.type <= TUTU_UNLIT) c->type_mask |= 1u << m.type;
+	{
+		const uint32_t group_masks[4] = {1u << TUTU_LAMBERTIAN, 1u << TUTU_PERFECT_REFLECTIVE,
+		                                 (1u << TUTU_PERFECT_REFRACTIVE) | (1u << TUTU_MICROFACET_T), 1u << TUTU_MICROFACET_R};
+		const int group_modes[4] = {SHADE_LAMBERT, SHADE_MIRROR, SHADE_REFRACT, SHADE_GGXR};
+		int groups = 0, only = SHADE_TERMINAL;
+		for (int g = 0; g < 4; g++)
+			if (c->type_mask & group_masks[g]) {
+				groups++;
+				only = group_modes[g];
+			}
+		c->no_class_sort = !getenv("TUTU_CLASS_SORT");
+		c->shade_mode_all = groups <= 1 ? only : SHADE_ANY;  // one class: its specialised kernel; several: the generic one
+	}
 	// per-lane traversal stack: at most one push per inner node on a root-to-leaf path.  When nodes + triangles are
 	// small enough, every block also keeps a copy of them in LDS (160 KB per CU).
 	c->stack_entries = (int)c->hs.depth + 1;
