@@ -9,7 +9,9 @@
 //     lists<FLAGS>       stable lists of the slots that continue / that have a shadow request (device_lists.h)
 //     trace_closest      extension rays of the continuing paths; writes the hit and its material class
 //     trace_any          shadow requests; an unblocked one adds its pre-multiplied contribution to the path
-//     lists<CLASS>       continuing slots sorted by material class -> the order shade(d+1) works in
+// shade(d+1) walks the list of continuing slots of iteration d, in slot order.  (TUTU_CLASS_SORT=1 restores the
+// earlier scheme: a second list set sorted by material class and one shade launch per class.  It lost: the shade
+// stage is bound by its record traffic, and per-class groups make that traffic sparser.)
 //
 // HBM layout: a path lives in ONE slot for the whole pass (slot = sample_in_pass * n_items + item, so neighbouring
 // slots are neighbouring pixels); its record is 8 x 16 B in structure-of-arrays form, each field read/written as a
@@ -236,18 +238,18 @@ TUTU_DEV void texture_modify(const SceneDev& sc, int tri, float b1, float b2, bo
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// shade stage, specialised by material class ("sort by material": trace_closest files every continuing path under
-// the class of what it hit, lists<CLASS> sorts them, and each class group gets its own launch of its own kernel).
+// shade stage.  trace_closest files every continuing path under the class of what it hit (kB); MODE selects how much of
+// the material code a launch carries:
 //   SHADE_FIRST       depth 0: paths are created from the per-pixel primary hit (all spp of a pixel share one
 //                     primary ray -- no pixel jitter in the reference, PathTracing.hpp:503-509); any material
 //   SHADE_LAMBERT     LAMBERTIAN                      SHADE_MIRROR   PERFECT_REFLECTIVE
 //   SHADE_REFRACT     PERFECT_REFRACTIVE, MICROFACET_T (calcForRefractive)
 //   SHADE_GGXR        MICROFACET_R                    SHADE_TERMINAL UNLIT, emissive hit, miss: connect + end
-// Specialisation removes the other materials' code (and registers) from each kernel; results are written to the
-// path's slot as soon as they exist, so few values stay live across the BSDF code.
+//   SHADE_ANY         every class, the material switch is per lane (scenes that mix scattering classes)
+// A scene with a single scattering class (the Cornell box: LAMBERTIAN) uses that class's kernel for every stage, which
+// removes the other materials' code (and registers); results are written to the path's slot as soon as they exist, so
+// few values stay live across the BSDF code.
 enum ShadeMode { SHADE_FIRST = 0, SHADE_LAMBERT = 1, SHADE_MIRROR = 2, SHADE_REFRACT = 3, SHADE_GGXR = 4, SHADE_TERMINAL = 5, SHADE_ANY = 6 };
-//   SHADE_ANY         every class in one launch over the unsorted list of continuing slots (scenes with several
-//                     scattering classes): the material switch is per lane, the records are read in slot order
 
 // EXT: the scene has textured objects (textureModify runs between the refractive test and everything else,
 // PathTracing.hpp:152-158) and/or spheres (hit point and normals from the sphere record, Sphere.hpp:44-53); the
