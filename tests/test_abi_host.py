@@ -82,3 +82,33 @@ def test_argument_errors_without_gpu(tr):
 
         with pytest.raises(tr.TutuError):
             tr.Context(scenes.cornell_box(8, 8))
+
+
+def test_committed_bench_line_keeps_the_contract():
+    """the newest bench line under profiles/ (written by bench.py on the GPU box) has every field the driver and the
+    measurement contract read, and its roofline is internally consistent"""
+    import glob
+    import json
+    import os
+
+    from conftest import ROOT
+
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_line.json")))
+    assert files, "no committed bench line"
+    d = json.load(open(files[-1]))
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["unit"] == "Msamples/s" and d["higher_is_better"] is True and d["scaling"] == "strong" and d["data"] == "synthetic"
+    assert d["dtype"] == "f32" and d["vs_baseline"] is None and "workload" in d["config"] and "model" not in d["config"]
+    assert abs(d["value"] - 800 * 800 * 512 / (d["ms_per_step"] * 1e-3) / 1e6) < 1e-6 * d["value"]
+    r = d["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "avg_launch_ms", "algorithmic_bytes_per_launch"):
+        assert k in r, k
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+    assert abs(r["achieved"] - r["algorithmic_bytes_per_launch"] / (r["avg_launch_ms"] * 1e-3) / 1e9) < 1e-6 * r["achieved"]
+    c = d["cpu_baseline"]
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in c, k
+    assert c["kind"] in ("reference", "port") and c["unit"] == "Msamples/s" and c["cores"] >= 1
