@@ -165,8 +165,8 @@ def main():
             "k_trace_any": 48 + n_s * 32 + t_s * 48,            # per shadow ray
             "k_shade": 192.0,                                    # per segment
         }
-        # k_shade here = the per-material-class launches at depth >= 1 (one kernel name per class group; the Cornell
-        # box has one group, LAMBERTIAN: rocprof's `k_shade<1, 2>`); the depth-0 and connect-only launches are separate
+        # k_shade here = the shade launches of the stages at depth 1..6 (one per stage; the Cornell box runs the LAMBERTIAN
+        # instantiation: rocprof's `k_shade<1, 2, false>`); the depth-0 and the connect-only last stage are separate
         units = {"k_trace_closest": ext, "k_trace_any": agg["shadow_rays"], "k_shade": ext}
         ms = {"k_trace_closest": agg["ms_trace_closest"], "k_trace_any": agg["ms_trace_any"], "k_shade": agg["ms_shade_material"]}
         nl = {"k_trace_closest": agg["trace_launches"], "k_trace_any": agg["trace_launches"], "k_shade": agg["shade_material_launches"]}

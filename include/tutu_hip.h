@@ -147,7 +147,7 @@ typedef struct TutuStats {
 	float ms_shade;          /* all shade launches (= ms_shade_first + ms_shade_material + ms_shade_terminal) */
 	float ms_other;          /* primary rays, list building, resolve */
 	float ms_shade_first;    /* depth-0 launches (k_shade<SHADE_FIRST>) */
-	float ms_shade_material; /* per-material-class launches at depth >= 1 */
+	float ms_shade_material; /* the shade launches of depths 1..MAX_DEPTH (one per stage, or one per material class with TUTU_CLASS_SORT) */
 	float ms_shade_terminal; /* launches that only connect (last depth; scenes without scattering materials) */
 	uint32_t shade_material_launches;
 	/* traversal work measured on the device, summed over the call's queue-stage rays (primary rays excluded):
