@@ -16,5 +16,5 @@ grep "^{" $O/bench_under_rocprof.log > $O/bench_line_under_rocprof.json
 (cd /tmp && export TUTU_SETS=1 && rocprofv3 --kernel-trace --stats --output-format csv -d $O/rocprof_exclusive -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $O/bench_exclusive_under_rocprof.log 2>&1); echo "rocprof exclusive rc=$?"
 mkdir -p $R/gpurun_out/pmc_$TAG
 bash profiles/run_pmc.sh $TAG 64 > $O/pmc.log 2>&1; echo "pmc rc=$?"
-timeout -k 10 600 python profiles/bench_scenes.py cornell veach veach_slight bunny broom cornell_textured cornell_spheres > $O/scenes.jsonl 2>&1; echo "scenes rc=$?"
+timeout -k 10 600 python tests/tools/bench_scenes.py cornell veach veach_slight bunny broom cornell_textured cornell_spheres > $O/scenes.jsonl 2>&1; echo "scenes rc=$?"
 tail -1 $O/gpu_tests.log; cut -c1-300 $O/bench_line.json

@@ -10,6 +10,6 @@ for grp in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_
            "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCC_HIT_sum TCC_MISS_sum" "FETCH_SIZE" "WRITE_SIZE" "GRBM_GUI_ACTIVE"; do
   i=$((i+1))
   mkdir -p $R/gpurun_out/pmc_${TAG}
-  rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $R/gpurun_out/pmc_${TAG}/g$i -- python3 $R/profiles/bench_scenes.py $SCENE > $R/gpurun_out/pmc_${TAG}/g$i.log 2>&1 || echo "group $i failed"
+  rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $R/gpurun_out/pmc_${TAG}/g$i -- python3 $R/tests/tools/bench_scenes.py $SCENE > $R/gpurun_out/pmc_${TAG}/g$i.log 2>&1 || echo "group $i failed"
 done
 echo done

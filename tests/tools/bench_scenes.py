@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Throughput + matched-seed parity spot check on every BASELINE config scene (not the contract bench: see bench.py).
-   python profiles/bench_scenes.py [scene ...]   scenes: cornell veach bunny broom cornell_textured"""
+Lives under tests/ because it calls the CPU oracle as a checker (400 samples per scene).
+   python tests/tools/bench_scenes.py [scene ...]   scenes: cornell veach bunny broom cornell_textured"""
 import json
 import os
 import sys
@@ -8,7 +9,7 @@ import time
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import tuturenderer_amd as tr  # noqa: E402
 from oracle.pyoracle import Oracle  # noqa: E402
