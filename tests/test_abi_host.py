@@ -76,6 +76,11 @@ def test_argument_errors_without_gpu(tr):
     h = C.c_void_p()
     assert lib.tutu_hip_create(None, 0, C.byref(h)) == -1
     assert lib.tutu_hip_error_string(-5).decode().startswith("BVH")
+    # the entry points added for textures / spheres / post-processing validate their arguments before any GPU call
+    assert lib.tutu_hip_set_option(None, b"sets", 1) == -1
+    assert lib.tutu_hip_postprocess(None, 0, 4, 4, None, None) == -1
+    assert lib.tutu_hip_quantise(None, 4, None, None) == -1
+    assert lib.tutu_hip_eval_texture(None, 0, 0, 4, None, None, None) == -1
     if n.value == 0:
         # no device: creating a context must fail loudly, never fall back to a CPU path
         from tuturenderer_amd import scenes
