@@ -343,6 +343,23 @@ def test_render_is_independent_of_pass_size_tiling_and_worklist(tr):
         assert not bit_equal(a, d)
 
 
+def test_image_does_not_depend_on_passes_in_flight(tr):
+    """tutu_hip_set_option("sets"): one to four wavefront passes in flight on as many streams -- the resolves are
+    ordered by events, so the frame is bit-identical"""
+    sc, key1 = _scene("cornell_ggxR_glass")
+    with tr.Context(sc) as ctx:
+        ref = ctx.render(24, pc.KEY0, key1, max_paths=4 * 96 * 96 * 3)  # 3 spp per pass, 8 passes
+        for sets in (1, 2, 3, 4):
+            ctx.set_option("sets", sets)
+            img = ctx.render(24, pc.KEY0, key1, max_paths=4 * 96 * 96 * 3)
+            assert bit_equal(img, ref), sets
+            assert ctx.last_stats["passes"] == 8
+        with pytest.raises(tr.TutuError):
+            ctx.set_option("sets", 9)
+        with pytest.raises(tr.TutuError):
+            ctx.set_option("no_such_option", 1)
+
+
 def test_edge_cases(tr):
     from tuturenderer_amd import scenes
 
