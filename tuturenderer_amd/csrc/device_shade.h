@@ -647,6 +647,8 @@ TUTU_DEV void trace_persistent(const S& ss, const TraceParams& tp, int* stack, c
 	uint32_t w_node_steps = 0, w_leaf_steps = 0, w_outer = 0;  // wave-uniform: how often each phase ran (TUTU_UTIL_STATS)
 	// any-hit only
 	float dis = 0.f;
+	float4 Fpre = make_float4(0.f, 0.f, 0.f, 0.f);  // the path's radiance, requested with the shadow request: an unblocked
+	                                                // ray adds to it at the finish without waiting for a load there
 	V3 contrib = mk1(0.f);
 	uint32_t fl = 0;
 	bool blocked = false;
@@ -664,6 +666,7 @@ TUTU_DEV void trace_persistent(const S& ss, const TraceParams& tp, int* stack, c
 					best_t = FLT_MAX; best_u = 0.f; best_v = 0.f; best_tri = -1;
 				} else {
 					const float4 e0 = tp.q.S0[slot], e1 = tp.q.S1[slot], e2 = tp.q.S2[slot];
+					Fpre = tp.q.F[slot];  // nobody else touches this path's record while its shadow ray is in flight
 					const V3 so = mk(e0.x, e0.y, e0.z), lo = mk(e0.w, e1.x, e1.y);
 					contrib = mk(e1.z, e1.w, e2.x);
 					fl = __float_as_uint(e2.y);
@@ -773,7 +776,7 @@ TUTU_DEV void trace_persistent(const S& ss, const TraceParams& tp, int* stack, c
 				if (fl & TUTU_FLAG_KILL) {
 					reinterpret_cast<int*>(&tp.q.C[slot])[3] = TUTU_TRI_KILLED;  // the hit of the (speculative) extension ray is void
 				} else {
-					float4 F = tp.q.F[slot];
+					float4 F = Fpre;
 					F.x = F.x + contrib.x; F.y = F.y + contrib.y; F.z = F.z + contrib.z;
 					tp.q.F[slot] = F;
 				}
