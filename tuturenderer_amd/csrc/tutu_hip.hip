@@ -484,10 +484,10 @@ int render_impl(TutuCtx* c, const TutuCameraFrame* cam, const TutuRenderParams* 
 	// faster box: 4 x 4 Mi 1545, 4 x 8 Mi 1725, 4 x 12 Mi 1753, 4 x 16 Mi 1714; 5, 6 or 8 sets are slower than 4).
 	const int64_t max_paths = rp->max_paths > 0 ? rp->max_paths : ((int64_t)48 << 20);
 	static const int sets_env = getenv("TUTU_SETS") ? atoi(getenv("TUTU_SETS")) : 4;
-	const int size_sets = std::max(1, std::min(sets_env, TUTU_MAX_SETS));
-	const int want_sets = c->opt_sets > 0 ? std::min(c->opt_sets, TUTU_MAX_SETS) : size_sets;
-	// the pass size does not depend on tutu_hip_set_option "sets" (a measuring aid): max_paths / the configured set count
-	int spp_pass = rp->spp_per_pass > 0 ? rp->spp_per_pass : (int)std::max<int64_t>(1, (max_paths / size_sets) / npix);
+	const int want_sets = std::max(1, std::min(c->opt_sets > 0 ? c->opt_sets : sets_env, TUTU_MAX_SETS));
+	// the pass size does not depend on how many passes are in flight (TUTU_SETS / tutu_hip_set_option "sets" are
+	// measuring aids): max_paths is always split into TUTU_MAX_SETS passes' worth of slots
+	int spp_pass = rp->spp_per_pass > 0 ? rp->spp_per_pass : (int)std::max<int64_t>(1, (max_paths / TUTU_MAX_SETS) / npix);
 	spp_pass = std::min(spp_pass, rp->spp);
 	spp_pass = std::min(spp_pass, 65535);  // grid.y limit
 	int n_passes = (rp->spp + spp_pass - 1) / spp_pass;
