@@ -3,7 +3,8 @@
 // launch on one counter word cost more than the shading itself: a single word sustains ~88 atomics/us on MI355X.)
 //
 // A "key" is one byte per path slot:
-//   kA (written by shade):         bit0 = the path continues (extension ray to trace), bit1 = it has a shadow request
+//   kA (written by shade):         bit0 = the path continues (extension ray to trace), bit1 = it has a shadow request,
+//                                  bits 2..4 = the stage (depth) that wrote the byte: a list only takes keys of its own stage
 //   kB (written by trace_closest): material class of the hit (0..5 MaterialType, 6 emissive, 7 miss)
 // Two list sets are built from them, each by three small launches (count per 4096-slot tile, scan of the tile
 // counts, scatter):
@@ -33,7 +34,13 @@ struct ListParams {
 	uint32_t flags_stride;    // FLAGS: list 1 starts at this offset (= capacity)
 	unsigned long long* stat_a;  // totals to bump by list_count[0] (closest rays) -- may be null
 	unsigned long long* stat_b;  // totals to bump by list_count[1] (shadow rays)  -- may be null
+	uint32_t stamp;              // a key byte counts only if its bits 2..4 carry this stage stamp (keys of paths that ended
+	                             // at an earlier stage are stale and nobody clears them)
 };
+
+// the two flag bits of a key byte, or 0 when the byte was written by another stage
+__device__ __forceinline__ uint32_t live_key(uint32_t a, uint32_t stamp) { return ((a >> 2) & 7u) == stamp ? (a & 3u) : 0u; }
+
 
 // membership of a key pair in list c, as packed 16-bit counters: lo = lists 0..3, hi = lists 4..7
 template <int MODE>
@@ -64,7 +71,7 @@ __device__ __forceinline__ void load_and_count(const ListParams& p, uint32_t slo
 #pragma unroll
 		for (int w = 0; w < 4; w++)
 #pragma unroll
-			for (int j = 0; j < 4; j++) key_to_packed<MODE>((wa[w] >> (8 * j)) & 0xFFu, (wb[w] >> (8 * j)) & 0xFFu, lo, hi);
+			for (int j = 0; j < 4; j++) key_to_packed<MODE>(live_key((wa[w] >> (8 * j)) & 0xFFu, p.stamp), (wb[w] >> (8 * j)) & 0xFFu, lo, hi);
 	}
 }
 
@@ -197,7 +204,7 @@ __global__ void __launch_bounds__(256) k_list_scatter(ListParams p) {
 	for (int w = 0; w < 4; w++)
 #pragma unroll
 		for (int j = 0; j < 4; j++) {
-			const uint32_t a = (wa[w] >> (8 * j)) & 0xFFu, b = (wb[w] >> (8 * j)) & 0xFFu;
+			const uint32_t a = live_key((wa[w] >> (8 * j)) & 0xFFu, p.stamp), b = (wb[w] >> (8 * j)) & 0xFFu;
 			const uint32_t slot = slot0 + 4 * w + j;
 			if (MODE == LIST_FLAGS) {
 				if (a & 1u) p.out[pos[0]++] = slot;

@@ -586,7 +586,7 @@ __global__ void __launch_bounds__(256) k_shade(PassParams pp) {
 			F.x = F.x + Ladd.x; F.y = F.y + Ladd.y; F.z = F.z + Ladd.z;
 			pp.q.F[slot] = F;
 		}
-		pp.kA[slot] = (uint8_t)key;
+		pp.kA[slot] = (uint8_t)(key | (((uint32_t)pp.depth & 7u) << 2));  // stage stamp: see device_lists.h
 		if (FIRST) break;
 	}
 }
@@ -675,8 +675,6 @@ TUTU_DEV void trace_persistent(const S& ss, const TraceParams& tp, int* stack, c
 					dis = norm(lo - so);
 					r = make_ray(so, raydir);
 					blocked = false;
-					// the request is consumed: a path that ended at this vertex is never re-shaded, so its flag must not survive
-					tp.kA[slot] = (uint8_t)(tp.kA[slot] & ~TUTU_KEY_SHADOW);
 				}
 				sp = 0;
 				float te;

@@ -209,8 +209,9 @@ int persistent_grid(size_t upper_items, int n_cu, int blocks_per_cu) {
 // count -> scan -> scatter: stable index lists from the per-slot key bytes (device_lists.h)
 template <int MODE>
 int build_lists(TutuCtx* c, WorkSet& w, hipStream_t s, uint32_t n_slots_padded, uint32_t* meta_count, uint32_t* out,
-                unsigned long long* stat_a, unsigned long long* stat_b) {
+                unsigned long long* stat_a, unsigned long long* stat_b, uint32_t stamp) {
 	ListParams lp;
+	lp.stamp = stamp & 7u;
 	lp.kA = w.kA.p;
 	lp.kB = w.kB.p;
 	lp.n_slots = n_slots_padded;
@@ -344,7 +345,7 @@ int run_pass(TutuCtx* c, WorkSet& w, hipStream_t s, const TutuCameraFrame* cam, 
 		}
 	shaded:
 		if (d == TUTU_MAX_DEPTH + 1) break;  // the last shade only connects; nothing continues
-		rc = build_lists<LIST_FLAGS>(c, w, s, n_pad, meta, w.flag_lists.p, &c->totals.p->closest_rays, &c->totals.p->shadow_rays);
+		rc = build_lists<LIST_FLAGS>(c, w, s, n_pad, meta, w.flag_lists.p, &c->totals.p->closest_rays, &c->totals.p->shadow_rays, (uint32_t)d);
 		if (rc != TUTU_OK) return rc;
 		TraceParams tp;
 		tp.sc = c->sc;
@@ -372,7 +373,7 @@ int run_pass(TutuCtx* c, WorkSet& w, hipStream_t s, const TutuCameraFrame* cam, 
 		if (tp.util) tp.util += 4;
 		TIMED(EV_TRACE_ANY, launch_trace<true>(c, s, trace_grid, tp));
 		if (!c->no_class_sort) {
-			rc = build_lists<LIST_CLASS>(c, w, s, n_pad, meta + 16, w.perm.p, nullptr, nullptr);
+			rc = build_lists<LIST_CLASS>(c, w, s, n_pad, meta + 16, w.perm.p, nullptr, nullptr, (uint32_t)d);
 			if (rc != TUTU_OK) return rc;
 		}
 	}
