@@ -1,24 +1,28 @@
 #!/usr/bin/env python3
-"""bench.py -- headline benchmark of the MI355X path-tracing integrator.
+"""bench.py -- benchmark of the MI355X path-tracing integrator on the BASELINE.json configurations.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--config c1|c2|c3|c4|c5]
     (N > 1: launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`)
 
-Workload (BASELINE.json configs[1]): Cornell box 800x800, 512 spp, PathTracing + NEE + MIS, synthetic scene data
-restated from the reference's scene program.  One "step" = one complete render of the frame: every pixel, all 512
-samples, plus (N > 1) the gather of the per-rank pixel sets to rank 0.  Scene, BVH and work buffers are resident in
-HBM before the timed region.  Pixel tiles (32x32, round-robin over ranks) shard the frame; the total work is
-fixed, so the scaling is "strong".
+Workloads (BASELINE.json `configs`, synthetic scene data restated from the reference's scene programs / SURVEY.md 8d):
+    c1  Cornell box 800x800, 16 spp          c2  Cornell box 800x800, 512 spp   (default; the headline metric)
+    c3  bunny stand-in 1024x1024, 256 spp    c4  broom stand-in 1600x900, 1024 spp
+    c5  veach room 800x600, 512 spp, PathTracing integrator
+One "step" = one complete render of the frame: every pixel, all samples, plus (N > 1) the gather of the per-rank
+pixel sets to rank 0.  Scene, BVH and work buffers are resident in HBM before the timed region.  Pixel tiles (32x32,
+round-robin over ranks) shard the frame; the total work is fixed, so the scaling is "strong".
 
 Prints ONE JSON line on rank 0:  metric = Msamples/s (= width*height*spp / wall-seconds), plus
-  roofline     -- the dominant kernel, priced in ALGORITHMIC bytes (per ray = 32 B ray + 16 B hit
-                  + N*32 B nodes entered + T*48 B triangle tests, N and T counted by the traversal kernels)
-                  over its average launch duration measured with HIP events on the library's stream;
+  roofline     -- the dominant kernel of an EXCLUSIVE step (one pass in flight: kernels run one at a time, so a launch's
+                  HIP-event duration is that kernel's own time), priced in ALGORITHMIC bytes; the
+                  figures of the timed region (four passes in flight, launches share the device) are kept under
+                  `overlapped_timed_region`, clearly apart;
   cpu_baseline -- the reference's own integrator (oracle/_ref, kind "reference"; falls back to the CPU restatement,
                   kind "port") timed on this box's host cores on a bounded sample of the same workload.
 """
 import argparse
 import json
+import math
 import os
 import sys
 import time
@@ -29,30 +33,84 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-KEY0, KEY1 = 0x5EED0001, 2  # Philox key: (seed_lo, config id)
+KEY0 = 0x5EED0001  # Philox key word 0; word 1 = config id
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+METRIC = "Msamples/sec (rays traced/sec) + wall-clock to 512spp, Cornell box 800x800"
 
 
-def cpu_baseline(scene, target_seconds=12.0):
-    """Time the reference integrator on the host cores: a first 4-spp frame calibrates, then one frame with as many
+def configs():
+    from tuturenderer_amd import scenes
+
+    return {
+        "c1": dict(key1=1, spp=16, mk=lambda: scenes.cornell_box(800, 800), name="cornell box 800x800, 16 spp, PathTracing+NEE+MIS (BASELINE configs[0])"),
+        "c2": dict(key1=2, spp=512, mk=lambda: scenes.cornell_box(800, 800), name="cornell box 800x800, 512 spp, PathTracing+NEE+MIS (BASELINE configs[1])"),
+        "c3": dict(key1=3, spp=256, mk=lambda: scenes.bunny_box(1024, 1024),
+                   name="bunny stand-in (81 942 triangles, MICROFACET_T blob in the Cornell box; SURVEY.md 8d) 1024x1024, 256 spp (BASELINE configs[2])"),
+        "c4": dict(key1=4, spp=1024, mk=lambda: scenes.broom_room(1600, 900),
+                   name="broom stand-in (48 012 triangles: 4000 thin prisms over a MICROFACET_R floor; SURVEY.md 8d) 1600x900, 1024 spp (BASELINE configs[3])"),
+        "c5": dict(key1=5, spp=512, mk=lambda: scenes.veach_room(800, 600, small_light=False),
+                   name="veach room (2306 triangles as the reference loads them on Linux) 800x600, 512 spp, PathTracing integrator (BASELINE configs[4])"),
+    }
+
+
+def effective_cores():
+    """threads this process can really run at once: CPU affinity, capped by the cgroup CPU quota if there is one"""
+    aff = len(os.sched_getaffinity(0))
+    quota = None
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    quota = float(txt[0]) / float(txt[1])
+            else:
+                q = float(txt[0])
+                if q > 0:
+                    quota = q / float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    eff = aff if quota is None else max(1, min(aff, int(math.ceil(quota))))
+    return {"os_cpu_count": os.cpu_count(), "affinity": aff, "cgroup_quota": quota, "effective": eff}
+
+
+def cpu_baseline(scene, cfg, target_seconds=12.0):
+    """Time the reference integrator on the host cores: a first 1-spp frame calibrates, then one frame with as many
     spp as fit ~target_seconds.  Only this function touches oracle/."""
     from oracle.pyoracle import Oracle, available
 
-    kind = "reference" if available("reference") else "port"
+    # oracle/_ref/libtutu_ref_fast.so: the same harness around the reference's own code, built -O3 for timing
+    # (libtutu_ref.so is -O2 -ffp-contract=off so that it can be compared bit for bit; speed does not need that)
+    kind = "reference_fast" if available("reference_fast") else ("reference" if available("reference") else "port")
     S = Oracle(kind).scene(scene)
-    cores = os.cpu_count() or 1
+    cores = effective_cores()
+    nthreads = cores["effective"]
     W, H = int(scene["width"]), int(scene["height"])
+    key1 = cfg["key1"]
     t0 = time.perf_counter()
-    S.render(4, KEY0, KEY1, nthreads=cores)
+    S.render(1, KEY0, key1, nthreads=nthreads)
     t_cal = time.perf_counter() - t0
-    spp = int(max(4, min(512, round(4 * target_seconds / max(t_cal, 1e-3)))))
+    spp = int(max(1, min(cfg["spp"], round(target_seconds / max(t_cal, 1e-3)))))
     t0 = time.perf_counter()
-    S.render(spp, KEY0, KEY1, nthreads=cores)
+    S.render(spp, KEY0, key1, nthreads=nthreads)
     dt = time.perf_counter() - t0
     S.close()
-    return {"value": W * H * spp / dt / 1e6, "unit": "Msamples/s", "cores": cores, "kind": kind,
-            "sample": f"cornell box {W}x{H}, {spp} spp of 512 (same scene, camera and Philox key), {cores} host threads, "
-                      f"{dt:.1f} s; RNG = Philox stream injected into the reference's getRandomFloat"}
+    return {"value": W * H * spp / dt / 1e6, "unit": "Msamples/s", "cores": nthreads, "kind": "port" if kind == "port" else "reference",
+            "build": {"reference_fast": "g++ -O3 -march=x86-64-v3, the reference's headers compiled where they lie (oracle/Makefile)",
+                      "reference": "g++ -O2 -ffp-contract=off (the bit-exact checker build)", "port": "g++ -O2 -ffp-contract=off"}[kind],
+            "host": cores,
+            "sample": f"{W}x{H}, {spp} spp of {cfg['spp']} (same scene, camera and Philox key), {nthreads} host threads (row split like "
+                      f"PathTracing.hpp:393-429), {dt:.1f} s; RNG = Philox stream injected into the reference's getRandomFloat"}
+
+
+def kernel_table(st, n_primary):
+    """per-kernel units / time / launches of one TutuStats dict"""
+    ext = st["closest_rays"] - n_primary  # extension rays = path vertices shaded at depth >= 1 (primary rays go through k_primary)
+    return {
+        "k_trace_closest": {"units": ext, "ms": st["ms_trace_closest"], "launches": st["trace_launches"]},
+        "k_trace_any": {"units": st["shadow_rays"], "ms": st["ms_trace_any"], "launches": st["trace_launches"]},
+        "k_shade": {"units": ext, "ms": st["ms_shade_material"], "launches": st["shade_material_launches"]},
+    }
 
 
 def main():
@@ -60,22 +118,24 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--spp", type=int, default=512)
-    ap.add_argument("--width", type=int, default=800)
-    ap.add_argument("--height", type=int, default=800)
+    ap.add_argument("--config", default="c2", choices=["c1", "c2", "c3", "c4", "c5"])
+    ap.add_argument("--spp", type=int, default=0, help="override the config's spp (analysis runs; the line says so)")
+    ap.add_argument("--spp-per-pass", type=int, default=0, help="override the pass size (PMC runs at the benchmarked pass size with fewer passes)")
     ap.add_argument("--max-paths", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the exclusive step and the drop-in timing (profiling runs)")
     ap.add_argument("--dump", type=str, default="")
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL, the measured configuration) or gloo (rehearsal of the N>1 path)")
     ap.add_argument("--same-device", action="store_true", help="rehearsal only: every rank uses cuda:0 (needs --backend gloo)")
     ap.add_argument("--emulate-shard", type=int, default=0, help="analysis only: render just shard 0 of an N-way tile split (no collective)")
     args = ap.parse_args()
 
+    # before anything touches the GPU: the host driver only supports dmabuf IPC (RCCL / tensor sharing across processes)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     import torch
     import torch.distributed as dist
 
     import tuturenderer_amd as tr
-    from tuturenderer_amd import scenes
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -89,14 +149,16 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if distributed:
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group("gloo")
 
-    W, H, spp = args.width, args.height, args.spp
-    scene = scenes.cornell_box(W, H)
+    cfg = configs()[args.config]
+    scene = cfg["mk"]()
+    W, H = int(scene["width"]), int(scene["height"])
+    spp = args.spp if args.spp > 0 else cfg["spp"]
+    key1 = cfg["key1"]
     from tuturenderer_amd.dist import TILE, FrameGather
 
     ctx = tr.Context(scene, device=local_rank)
@@ -108,7 +170,7 @@ def main():
     torch.cuda.synchronize()  # the library renders on its own stream: torch's allocation fills must have landed
 
     def step():
-        ctx.render_device(fg.piece.data_ptr(), spp, KEY0, KEY1, pixels=mine, max_paths=args.max_paths)
+        fg.render(ctx, spp, KEY0, key1, pixels=mine, max_paths=args.max_paths, spp_per_pass=args.spp_per_pass)
         if args.emulate_shard <= 1:
             fg.assemble()  # N > 1: the one collective, an RCCL gather of the framebuffer pieces to rank 0
         return ctx.last_stats
@@ -122,12 +184,12 @@ def main():
         step()
     fence()
     t0 = time.perf_counter()
-    agg = {"ms_trace_closest": 0.0, "ms_trace_any": 0.0, "ms_shade": 0.0, "ms_other": 0.0, "trace_launches": 0, "closest_rays": 0,
-           "shadow_rays": 0, "passes": 0, "ms_shade_first": 0.0, "ms_shade_material": 0.0, "ms_shade_terminal": 0.0,
-           "shade_material_launches": 0, "nodes_closest": 0, "leaves_closest": 0, "nodes_any": 0, "leaves_any": 0}
+    agg = None
     for _ in range(args.steps):
         st = step()
-        for k in agg:
+        if agg is None:
+            agg = {k: 0 for k in st}
+        for k in st:
             agg[k] += st[k]
     fence()
     dt = time.perf_counter() - t0
@@ -140,82 +202,125 @@ def main():
     # duration of a launch is the time that kernel needs for its work -- with four passes in flight (the timed
     # configuration) every launch's duration also contains the time it shares the device with three other streams.
     excl = None
-    if world == 1:
+    if world == 1 and not args.no_extras:
         ctx.set_option("sets", 1)
         excl = dict(step())
         torch.cuda.synchronize()
         ctx.set_option("sets", 0)
+    options = ctx.options()
+    info = ctx.info()
 
     if rank == 0:
+        npix = len(mine)
         total_samples = W * H * spp * args.steps
         value = total_samples / dt / 1e6
-        # per-kernel algorithmic bytes per unit (the 288 B of state per segment split by stage)
-        prim = len(mine) * args.steps  # primary rays go through k_primary, not the queue kernel
-        ext = agg["closest_rays"] - prim  # extension rays = path vertices shaded at depth >= 1
-        # per ray 32 B ray + 16 B hit + N*32 B nodes entered + T*48 B leaf tests.  N and T are counted
-        # by the traversal kernels themselves on the tree they actually walk (TutuStats.nodes_* / leaves_*; a node
-        # entered = an inner node visited or a leaf reached), not taken from the CPU restatement's walk of the
-        # reference tree (tuturenderer_amd/scenes/workload_counters.json: N 17.2 / T 2.65 there).
-        n_c = (agg["nodes_closest"] + agg["leaves_closest"]) / max(ext, 1)
-        t_c = agg["leaves_closest"] / max(ext, 1)
+        lds_scene = bool(options.get("lds_scene"))
+        spp_per_pass = int(st["spp_per_pass"])
+        # per ray 32 B ray + 16 B hit + N*32 B nodes entered + T*48 B leaf tests.  N and T are counted by the
+        # traversal kernels themselves on the tree they actually walk (TutuStats.nodes_* / leaves_*; a node entered = an inner
+        # node visited or a leaf reached).  When the scene is staged in LDS (lds_scene) the node / triangle bytes never
+        # touch HBM: `hbm_bytes_per_unit` leaves them out and is what the roofline fraction is computed from.
+        tab = kernel_table(agg, npix * args.steps)
+        n_c = (agg["nodes_closest"] + agg["leaves_closest"]) / max(tab["k_trace_closest"]["units"], 1)
+        t_c = agg["leaves_closest"] / max(tab["k_trace_closest"]["units"], 1)
         n_s = (agg["nodes_any"] + agg["leaves_any"]) / max(agg["shadow_rays"], 1)
         t_s = agg["leaves_any"] / max(agg["shadow_rays"], 1)
-        per_unit = {
-            "k_trace_closest": 32 + 16 + n_c * 32 + t_c * 48,  # per closest-hit ray
-            "k_trace_any": 48 + n_s * 32 + t_s * 48,            # per shadow ray
-            "k_shade": 192.0,                                    # per segment
-        }
-        # k_shade here = the shade launches of the stages at depth 1..6 (one per stage; the Cornell box runs the LAMBERTIAN
-        # instantiation: rocprof's `k_shade<1, 2, false>`); the depth-0 and the connect-only last stage are separate
-        units = {"k_trace_closest": ext, "k_trace_any": agg["shadow_rays"], "k_shade": ext}
-        ms = {"k_trace_closest": agg["ms_trace_closest"], "k_trace_any": agg["ms_trace_any"], "k_shade": agg["ms_shade_material"]}
-        nl = {"k_trace_closest": agg["trace_launches"], "k_trace_any": agg["trace_launches"], "k_shade": agg["shade_material_launches"]}
-        dom = max(ms, key=ms.get)
-        launches = nl[dom]
-        achieved = units[dom] * per_unit[dom] / (ms[dom] * 1e-3) / 1e9  # GB/s
-        traffic = None  # HBM bytes per launch from the committed PMC passes (profiles/make_traffic.py), if any
+        scene_bytes = {"k_trace_closest": n_c * 32 + t_c * 48, "k_trace_any": n_s * 32 + t_s * 48, "k_shade": 0.0}
+        state_bytes = {"k_trace_closest": 32 + 16.0, "k_trace_any": 48.0, "k_shade": 192.0}
+        per_unit = {k: state_bytes[k] + scene_bytes[k] for k in state_bytes}                       # SURVEY's definition
+        hbm_unit = {k: state_bytes[k] + (0.0 if lds_scene else scene_bytes[k]) for k in state_bytes}  # what can reach HBM
+
+        def priced(table, k):
+            e = table[k]
+            ach = e["units"] * hbm_unit[k] / max(e["ms"] * 1e-3, 1e-12) / 1e9
+            return {"avg_launch_ms": e["ms"] / max(e["launches"], 1), "launches": e["launches"], "units_per_launch": e["units"] / max(e["launches"], 1),
+                    "achieved": ach, "frac": ach / HBM_PEAK_GBS}
+
+        src = kernel_table(excl, npix) if excl is not None else tab
+        dom = max(src, key=lambda k: src[k]["ms"])
+        top = priced(src, dom)
+        # measured HBM traffic of that kernel: a committed PMC collection (profiles/make_traffic.py), stored per unit
+        # together with the config and pass size it was collected at; refused when either does not match this run
+        traffic = None
+        traffic_note = "no committed PMC collection for this config / pass size"
+        pipeline_hbm = None
         prof = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(prof):
-            traffic = json.load(open(prof)).get(dom, {}).get("bytes_per_launch")
-        roofline = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                    "algorithmic_bytes_per_launch": units[dom] * per_unit[dom] / max(launches, 1),
-                    "algorithmic_bytes_per_unit": per_unit[dom], "units_per_launch": units[dom] / max(launches, 1),
-                    "avg_launch_ms": ms[dom] / max(launches, 1), "launches": launches,
-                    "kernel_ms_per_step": dict({k: v / args.steps for k, v in ms.items()}, k_shade_depth0=agg["ms_shade_first"] / args.steps,
-                                               k_shade_connect_only=agg["ms_shade_terminal"] / args.steps, other=agg["ms_other"] / args.steps),
-                    "note": "timed region: four wavefront passes in flight on four streams, so a launch's HIP-event duration includes the "
-                            "time it shares the device with other streams' kernels (stage times sum to more than ms_per_step); "
-                            "`exclusive` = the same kernel in one extra step with one pass in flight",
-                    "measured_per_ray": {"N_closest": n_c, "T_closest": t_c, "N_shadow": n_s, "T_shadow": t_s}}
+            tj = json.load(open(prof)).get(args.config)
+            if isinstance(tj, dict) and tj.get("spp_per_pass") == spp_per_pass:
+                tk = tj["kernels"].get(dom)
+                if tk:
+                    traffic = tk["hbm_bytes_per_unit"] * top["units_per_launch"]
+                    traffic_note = (f"{tk['hbm_bytes_per_unit']:.1f} B/unit x units_per_launch; from the committed PMC collection {tj.get('tag')} "
+                                    f"(FETCH_SIZE x2 + WRITE_SIZE, same config, spp_per_pass {tj['spp_per_pass']}), not measured in this run")
+                if tj.get("hbm_bytes_per_sample"):
+                    pipeline_hbm = {"hbm_bytes_per_sample": tj["hbm_bytes_per_sample"],
+                                    "frac": value * 1e6 * tj["hbm_bytes_per_sample"] / (HBM_PEAK_GBS * 1e9),
+                                    "note": "measured HBM bytes per sample (all kernels, committed PMC collection) x this run's samples/s / 8 TB/s"}
+        roofline = {"bound": "hbm", "kernel": dom, "achieved": top["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": top["frac"],
+                    "traffic": traffic, "traffic_note": traffic_note,
+                    "avg_launch_ms": top["avg_launch_ms"], "launches": top["launches"], "units_per_launch": top["units_per_launch"],
+                    "algorithmic_bytes_per_unit": per_unit[dom], "hbm_bytes_per_unit": hbm_unit[dom],
+                    "algorithmic_bytes_per_launch": hbm_unit[dom] * top["units_per_launch"],
+                    "measured_on": "one extra step with ONE pass in flight (kernels run one at a time)" if excl is not None else
+                                   "the timed region (N > 1 or --no-extras: launches of several passes overlap, durations include shared time)",
+                    "lds_scene": lds_scene,
+                    "measured_per_ray": {"N_closest": n_c, "T_closest": t_c, "N_shadow": n_s, "T_shadow": t_s},
+                    "per_kernel": {k: dict(priced(src, k), algorithmic_bytes_per_unit=per_unit[k], hbm_bytes_per_unit=hbm_unit[k]) for k in src}}
         if excl is not None:
-            e_ms = {"k_trace_closest": excl["ms_trace_closest"], "k_trace_any": excl["ms_trace_any"], "k_shade": excl["ms_shade_material"]}
-            e_nl = {"k_trace_closest": excl["trace_launches"], "k_trace_any": excl["trace_launches"], "k_shade": excl["shade_material_launches"]}
-            e_units = {"k_trace_closest": excl["closest_rays"] - len(mine), "k_trace_any": excl["shadow_rays"], "k_shade": excl["closest_rays"] - len(mine)}
-            e_ach = e_units[dom] * per_unit[dom] / (e_ms[dom] * 1e-3) / 1e9
-            roofline["exclusive"] = {"avg_launch_ms": e_ms[dom] / max(e_nl[dom], 1), "launches": e_nl[dom], "achieved": e_ach,
-                                     "frac": e_ach / HBM_PEAK_GBS, "ms_per_step": excl["ms_total"],
-                                     "kernel_ms_per_step": dict(e_ms, k_shade_depth0=excl["ms_shade_first"],
-                                                                k_shade_connect_only=excl["ms_shade_terminal"], other=excl["ms_other"])}
-        # whole-pipeline algorithmic bytes per sample with the measured N and T
-        seg_per_sample = ext / max(W * H * spp * args.steps, 1)
-        sh_per_sample = agg["shadow_rays"] / max(W * H * spp * args.steps, 1)
-        b_sample = seg_per_sample * (per_unit["k_trace_closest"] + per_unit["k_shade"]) + sh_per_sample * per_unit["k_trace_any"]
-        roofline["pipeline_B_sample"] = b_sample
-        roofline["pipeline_frac"] = value * 1e6 * b_sample / (HBM_PEAK_GBS * 1e9)
+            roofline["exclusive_step_ms"] = excl["ms_total"]
+            roofline["exclusive_kernel_ms_per_step"] = {"k_trace_closest": excl["ms_trace_closest"], "k_trace_any": excl["ms_trace_any"],
+                                                        "k_shade": excl["ms_shade_material"], "k_shade_depth0": excl["ms_shade_first"],
+                                                        "k_shade_connect_only": excl["ms_shade_terminal"], "other": excl["ms_other"]}
+            roofline["overlapped_timed_region"] = {
+                "note": "four wavefront passes in flight on four streams: a launch's HIP-event duration includes the time it shares the device "
+                        "with other streams' kernels, so these are NOT kernel durations (they sum to more than ms_per_step)",
+                "per_kernel_ms_per_step": {k: tab[k]["ms"] / args.steps for k in tab}}
+        rendered = max(npix * spp * args.steps, 1)
+        seg_per_sample = tab["k_shade"]["units"] / rendered
+        sh_per_sample = agg["shadow_rays"] / rendered
+        roofline["pipeline"] = {
+            "segments_per_sample": seg_per_sample, "shadow_rays_per_sample": sh_per_sample,
+            "algorithmic_bytes_per_sample": seg_per_sample * (per_unit["k_trace_closest"] + per_unit["k_shade"]) + sh_per_sample * per_unit["k_trace_any"],
+            "of_which_lds_served": (seg_per_sample * scene_bytes["k_trace_closest"] + sh_per_sample * scene_bytes["k_trace_any"]) if lds_scene else 0.0,
+            "measured_hbm": pipeline_hbm}
         line = {
-            "metric": "Msamples/sec (rays traced/sec) + wall-clock to 512spp, Cornell box 800x800",
+            "metric": METRIC if args.config == "c2" else "Msamples/sec (rays traced/sec)",
             "value": value, "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"cornell box {W}x{H}, {spp} spp, PathTracing+NEE+MIS (BASELINE configs[1])",
-                       "pixel_tiles": f"{TILE}x{TILE} round-robin over {world} rank(s)", "philox_key": [KEY0, KEY1],
-                       "wall_clock_to_512spp_s": dt / args.steps if spp == 512 else None,
-                       "rays_per_s": (agg["closest_rays"] + agg["shadow_rays"]) * world / dt if world == 1 else None},
+            "config": {"workload": cfg["name"] + ("" if spp == cfg["spp"] else f" -- RUN AT {spp} spp"), "id": args.config,
+                       "triangles": info["n_tris"], "bvh_depth": info["depth"], "lights": info["n_lights"],
+                       "pixel_tiles": f"{TILE}x{TILE} round-robin over {world} rank(s)", "philox_key": [KEY0, key1],
+                       "spp_per_pass": spp_per_pass, "passes_per_step": agg["passes"] // max(args.steps, 1),
+                       "wall_clock_to_512spp_s": dt / args.steps if (spp == 512 and args.config == "c2") else None,
+                       "rays_per_s": (agg["closest_rays"] + agg["shadow_rays"]) / dt if world == 1 else None,
+                       "timed": "tutu_hip_render_device: scene, BVH and work buffers resident in HBM, frame left in HBM (bench contract); "
+                                "see `drop_in` for the SURVEY 8d bracket (create + H2D + render + D2H + destroy)",
+                       "knobs": options, "env": {k: v for k, v in os.environ.items() if k.startswith("TUTU_")}},
             "roofline": roofline,
         }
+        if world == 1 and not args.no_extras:
+            # what a caller of the drop-in seam pays (src/main_cornellBox.cpp:75-79 brackets render()):
+            # context creation (BVH build + scene H2D), work-buffer allocation, render, frame D2H, destroy
+            t0 = time.perf_counter()
+            c2 = tr.Context(scene, device=local_rank)
+            t_c2 = time.perf_counter() - t0
+            t0 = time.perf_counter()
+            c2.render(spp, KEY0, key1, full_frame=False)
+            t_r1 = time.perf_counter() - t0
+            t0 = time.perf_counter()
+            c2.render(spp, KEY0, key1, full_frame=False)
+            t_r2 = time.perf_counter() - t0
+            t0 = time.perf_counter()
+            c2.close()
+            t_d = time.perf_counter() - t0
+            line["drop_in"] = {"create_s": t_c2, "first_render_s": t_r1, "second_render_s": t_r2, "destroy_s": t_d,
+                               "Msamples_per_s_cold": W * H * spp / (t_c2 + t_r1 + t_d) / 1e6, "Msamples_per_s_warm_host_frame": W * H * spp / t_r2 / 1e6,
+                               "note": "tutu_hip_create + tutu_hip_render (host frame: PCIe D2H included) + tutu_hip_destroy; the first render also "
+                                       "allocates the work buffers (hipMalloc); `second` = a persistent context's steady state"}
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(scene)
+            line["cpu_baseline"] = cpu_baseline(scene, cfg)
         else:
             line["cpu_baseline"] = None
         if args.dump:

@@ -153,6 +153,8 @@ typedef struct TutuStats {
 	/* traversal work measured on the device, summed over the call's queue-stage rays (primary rays excluded):
 	 * nodes entered and leaf (triangle / sphere) tests, for closest-hit and any-hit rays */
 	uint64_t nodes_closest, leaves_closest, nodes_any, leaves_any;
+	uint32_t spp_per_pass; /* samples per pixel of a full wavefront pass of this call (the last pass may be shorter) */
+	uint32_t n_sets;       /* passes that were in flight at once */
 } TutuStats;
 
 typedef struct TutuHit {
@@ -254,10 +256,19 @@ int tutu_hip_postprocess(TutuCtx* ctx, int32_t stage, int32_t width, int32_t hei
 int tutu_hip_quantise(TutuCtx* ctx, uint32_t n, const float* values, int32_t* levels);
 
 /* Tuning / measuring knobs that do not change any result.
- *   "sets"  number of wavefront passes in flight (1..4, 0 = default 4).  With 1, kernels run one at a time and the
+ *   "sets"  number of wavefront passes in flight (1..4, 0 = default).  With 1, kernels run one at a time and the
  *           per-kernel times of TutuStats are exclusive; with more, stages of different passes overlap and every
- *           launch's duration includes the time it shares the device with others. */
+ *           launch's duration includes the time it shares the device with others.
+ * The remaining knobs take their start values from TUTU_* environment variables ONCE, at tutu_hip_create, where a
+ * value outside its range fails the create with TUTU_E_INVALID (it never reaches a kernel):
+ *   "sets_default" TUTU_SETS [1,4] | "one_set" TUTU_ONE_SET {0,1} | "shade_bpc" TUTU_SHADE_BPC [1,16] |
+ *   "trace_bpc" TUTU_TRACE_BPC [0,8] (0 = from the LDS footprint) | "refill_min" TUTU_REFILL_MIN [1,64] |
+ *   "inner_steps" TUTU_INNER_STEPS [1,64] | "any_near_first" TUTU_ANY_NEAR_FIRST {0,1} |
+ *   "util_stats" TUTU_UTIL_STATS {0,1} | "class_sort" TUTU_CLASS_SORT {0,1} (create-time only).
+ * tutu_hip_get_option reports the effective value of any of them, plus the read-only facts "sah_tree", "lds_scene"
+ * and "shade_tab" -- a benchmark line should echo them (bench.py does). */
 int tutu_hip_set_option(TutuCtx* ctx, const char* name, int value);
+int tutu_hip_get_option(TutuCtx* ctx, const char* name, int* value);
 
 #ifdef __cplusplus
 }

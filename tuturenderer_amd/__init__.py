@@ -19,7 +19,7 @@ ABI_SYMBOLS = [
     "tutu_camera_frame", "tutu_bvh_build_preorder", "tutu_hip_error_string", "tutu_hip_last_error", "tutu_hip_version",
     "tutu_hip_device_count", "tutu_hip_create", "tutu_hip_destroy", "tutu_hip_render", "tutu_hip_render_device",
     "tutu_hip_trace_closest", "tutu_hip_trace_any", "tutu_hip_trace_samples", "tutu_hip_eval_bxdf", "tutu_hip_eval_pdf",
-    "tutu_hip_eval_sample", "tutu_hip_eval_sample_light", "tutu_hip_scene_info", "tutu_hip_eval_texture", "tutu_hip_set_option", "tutu_hip_postprocess", "tutu_hip_quantise",
+    "tutu_hip_eval_sample", "tutu_hip_eval_sample_light", "tutu_hip_scene_info", "tutu_hip_eval_texture", "tutu_hip_set_option", "tutu_hip_get_option", "tutu_hip_postprocess", "tutu_hip_quantise",
 ]
 
 
@@ -118,7 +118,8 @@ class Stats(C.Structure):
                 ("passes", C.c_uint32), ("trace_launches", C.c_uint32), ("ms_total", C.c_float), ("ms_trace_closest", C.c_float),
                 ("ms_trace_any", C.c_float), ("ms_shade", C.c_float), ("ms_other", C.c_float), ("ms_shade_first", C.c_float),
                 ("ms_shade_material", C.c_float), ("ms_shade_terminal", C.c_float), ("shade_material_launches", C.c_uint32),
-                ("nodes_closest", C.c_uint64), ("leaves_closest", C.c_uint64), ("nodes_any", C.c_uint64), ("leaves_any", C.c_uint64)]
+                ("nodes_closest", C.c_uint64), ("leaves_closest", C.c_uint64), ("nodes_any", C.c_uint64), ("leaves_any", C.c_uint64),
+                ("spp_per_pass", C.c_uint32), ("n_sets", C.c_uint32)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
@@ -271,6 +272,18 @@ class Context:
 
     def set_option(self, name, value):
         _check(self.lib.tutu_hip_set_option(self.h, C.c_char_p(name.encode()), C.c_int(int(value))), "tutu_hip_set_option")
+
+    OPTION_NAMES = ("sets", "sets_default", "one_set", "shade_bpc", "trace_bpc", "refill_min", "inner_steps", "any_near_first",
+                    "util_stats", "class_sort", "sah_tree", "lds_scene", "shade_tab")
+
+    def get_option(self, name):
+        v = C.c_int(0)
+        _check(self.lib.tutu_hip_get_option(self.h, C.c_char_p(name.encode()), C.byref(v)), "tutu_hip_get_option")
+        return v.value
+
+    def options(self):
+        """effective value of every knob (what a benchmark line should echo)"""
+        return {k: self.get_option(k) for k in self.OPTION_NAMES}
 
     def info(self):
         b = BvhInfo()

@@ -6,17 +6,23 @@
 // One iteration d of the loop (host enqueues, no host sync inside a pass):
 //     shade(d)           connect vertex d-1 to the hit found for its BSDF ray (MIS-weighted emission or Russian
 //                        roulette), then shade vertex d: light sample -> shadow request, BSDF sample -> next ray
-//     lists<FLAGS>       stable lists of the slots that continue / that have a shadow request (device_lists.h)
+//     lists              stable lists of the records that continue / that hold a shadow request (device_lists.h)
 //     trace_closest      extension rays of the continuing paths; writes the hit and its material class
-//     trace_any          shadow requests; an unblocked one adds its pre-multiplied contribution to the path
-// shade(d+1) walks the list of continuing slots of iteration d, in slot order.  (TUTU_CLASS_SORT=1 restores the
-// earlier scheme: a second list set sorted by material class and one shade launch per class.  It lost: the shade
-// stage is bound by its record traffic, and per-class groups make that traffic sparser.)
+//     trace_any          shadow requests; writes a one-byte verdict (the contribution is added by shade(d+1))
 //
-// HBM layout: a path lives in ONE slot for the whole pass (slot = sample_in_pass * n_items + item, so neighbouring
-// slots are neighbouring pixels); its record is 8 x 16 B in structure-of-arrays form, each field read/written as a
-// full dwordx4 per lane.  Nothing is moved: stages reach their work through the stable index lists, which keeps
-// lanes of a wave on neighbouring pixels and needs no atomics.
+// HBM layout -- COMPACTING records.  What bounds a wavefront stage on MI355X is not bytes but PARTIAL LINES: a 16-B
+// store into a line whose neighbours are not stored costs a read-modify-write in the memory system (measured,
+// profiles/membench: the same 208 B per record move at 4.9 TB/s when every line is written whole and at 1.0-2.4 TB/s
+// when 25-75 % of the slots are holes; sparse READS cost little).  So a path does NOT keep its slot: shade(d) reads
+// its records from set (d-1)&1 through the list of continuing records and writes the survivors of every 64-record
+// chunk, compacted by a ballot rank, to the FRONT of that chunk's 64 slots of set d&1.  Every store instruction of
+// the stage then writes one contiguous run of 16-B fields; the only partial lines are the one at the end of each
+// chunk.  The outputs of a lane are staged in LDS ([field][lane], 16 B each) as soon as they exist -- few values stay
+// live across the BSDF code -- and copied out at the end of the chunk, when the ranks are known.
+// A record is 8-10 fields of 16 B in structure-of-arrays form (below); the radiance gathered so far travels with the
+// path (L) together with its HOME slot (sample_in_pass * n_items + item), and is written to F[home] exactly once, by
+// whoever sees the path end: shade, or trace_any when the path's last act was a shadow request.
+// Hits are written per LIST POSITION (dense), not per slot: shade(d+1) walks the same list trace_closest(d) walked.
 #pragma once
 #include "device_lists.h"
 #include "device_trace.h"
@@ -31,24 +37,33 @@ namespace tutu {
 #define TUTU_FLAG_PREV_MIRROR_PM1 2u  // vertex d-1 PERFECT_REFLECTIVE with mat_pdf == 1 (PathTracing.hpp:252-253)
 #define TUTU_FLAG_KILL 4u             // NEE hit the `r2*pdf < MIN_DIVISOR` early return (PathTracing.hpp:215)
 
-#define TUTU_KEY_NEXT 1u    // kA bit0: the path continues
-#define TUTU_KEY_SHADOW 2u  // kA bit1: the slot holds a shadow request
+// key byte of a record (bits 0,1: device_lists.h)
+#define TUTU_KEY_KILL 4u    // shadow request: an UNBLOCKED ray ends the whole path (PathTracing.hpp:215)
+#define TUTU_KEY_FINAL 8u   // shadow request of a path that does not continue: trace_any writes F[home]
+#define TUTU_KEY_ALT 16u    // shadow origin in S2 (it differs from the extension ray's origin in A)
+// verdict byte of a shadow request, written by trace_any, read by the next shade stage
+#define TUTU_V_BLOCKED 0u
+#define TUTU_V_ADD 1u       // unblocked: add P
+#define TUTU_V_KILLED 2u    // unblocked KILL request: the path ends, its speculative extension hit is void
 
-struct Queue {  // structure-of-arrays path records, one per slot
-	float4* A;  // ray origin xyz | pixel index (RNG counter word 0)
-	float4* B;  // ray direction xyz (NOT normalised for mirror/refraction, as in the reference) | smp<<8 | vertex flags<<6 | draw
-	float4* C;  // hit: t, b1, b2 | triangle (leaf order, -1 miss, -2 killed by its shadow ray)   -- written by the trace stages
-	float4* D;  // beta xyz | mat_pdf of the BSDF sample at the previous vertex
-	float4* E;  // tp xyz: the reference's Russian-roulette variable (NOT the throughput); only live from depth 4 on
-	float4* F;  // L xyz: radiance gathered so far (touched only when something is added); final when the path has ended
-	float4* G;  // position of the previous vertex xyz (read only when a BSDF ray lands on a light)
-	float4* H;  // f_r at the previous vertex xyz | |Ng.wi| there
-	float4* S0;  // shadow request: origin xyz | target x
-	float4* S1;  //                 target yz | contribution xy
-	float4* S2;  //                 contribution z | flags | unused
+struct Records {  // one of the two record sets of a work set (structure of arrays, 16 B per field and slot)
+	float4* A;   // ray origin xyz (also the shadow ray's origin unless TUTU_KEY_ALT) | pixel index (RNG counter word 0)
+	float4* B;   // ray direction xyz (NOT normalised for mirror/refraction, as in the reference) | smp<<8 | vertex flags<<6 | draw
+	float4* D;   // beta xyz | mat_pdf of the BSDF sample at this vertex
+	float4* E;   // tp xyz: the reference's Russian-roulette variable (NOT the throughput); only live from depth 4 on
+	float4* G;   // position of this vertex xyz (read only when the BSDF ray lands on a light)
+	float4* H;   // f_r at this vertex xyz | |Ng.wi|
+	float4* L;   // radiance gathered so far xyz | home slot
+	float4* S;   // shadow request: target xyz | -
+	float4* P;   //                 pre-multiplied contribution xyz | -
+	float4* S2;  //                 origin xyz when TUTU_KEY_ALT | -
+	uint8_t* key;  // per slot: TUTU_KEY_*
+	uint8_t* V;    // per slot: TUTU_V_*
 };
 
-#define TUTU_TRI_KILLED (-2)
+// LDS staging area of one wave: [field][lane] float4
+enum StageField { SF_A = 0, SF_B, SF_D, SF_H, SF_L, SF_G, SF_S, SF_P, SF_E, SF_S2, SF_COUNT };
+#define TUTU_STAGE_BYTES_PER_BLOCK (4 * SF_COUNT * 64 * 16)  // 4 waves
 
 struct Totals {  // accumulated over a render call
 	unsigned long long closest_rays, shadow_rays, segments, pad;
@@ -61,31 +76,33 @@ struct PassParams {
 	int depth;
 	int npix;   // work items
 	int s0;     // first sample index of this pass
-	uint32_t n_slots;
 	const float4* prim_dir;  // per item: primary direction xyz | pixel index
 	const float4* prim_hit;  // per item: t, b1, b2 | tri
 	const uint32_t* smp_list;  // optional: per item sample index (tutu_hip_trace_samples); then one sample per item
 	float eye[3];
-	Queue q;
-	uint8_t* kA;              // out: continuation / shadow flags per slot
-	const uint32_t* perm;     // class-sorted continuing slots (packed lists)
-	const uint32_t* cls_count;  // [8] entries per class list (the lists are packed back to back in `perm`)
-	uint32_t class_mask;        // classes this launch shades
+	Records in, out;         // depth > 0: the set shade(depth-1) wrote; the set this stage writes
+	const uint32_t* list;    // continuing records of `in`, in slot order (the list trace_closest(depth-1) walked)
+	const uint32_t* n_in;    // its length
+	const float4* hitC;      // per list position: t, b1, b2 | triangle (leaf order, -1 miss)
+	const uint8_t* hitK;     // per list position: material class of the hit
+	float4* F;               // per home slot: the finished sample's radiance
 	int n_mats;
-	int mixed;                     // 1: `perm` is the plain list of continuing slots, classes come from kB (single-class scenes)
-	const uint32_t* mixed_count;   // its length
-	const uint8_t* kB;
 };
 
 // Small read-only tables of the shade stage.  TAB selects where they live:
 //   0  all in HBM (L2-cached gathers)
 //   1  materials + lights staged in LDS by every block
 //   2  materials + lights + per-triangle shading records staged in LDS (small scenes, e.g. the Cornell box: 2.5 KB)
-// Staging removes two to three dependent memory round trips from every vertex.
+// Staging removes two to three dependent memory round trips from every vertex.  The per-triangle records are staged
+// as structure of arrays ([4][n_tris] x 16 B): lanes that hit different triangles then read different banks (as
+// array of 64-B structures 61 % of the LDS cycles of this kernel were bank conflicts), lanes on one triangle broadcast.
 struct ShadeTabs {
 	const float4* mats;    // 4 x float4 per material
 	const float4* lights;  // 6 x float4 per light
-	const float4* tris;    // 4 x float4 per triangle (GpuTriShade)
+	const float4* tris;    // 4 x float4 per triangle (GpuTriShade): part k of triangle i at tris[i * tri_si + k * tri_sk]
+	int tri_si, tri_sk;
+	float4* stage;         // LDS behind the tables: the block's staging area (4 waves x SF_COUNT x 64 x 16 B)
+	TUTU_DEV float4 tri(int i, int k) const { return tris[i * tri_si + k * tri_sk]; }
 };
 
 template <int TAB>
@@ -94,6 +111,9 @@ TUTU_DEV ShadeTabs stage_shade_tabs(const SceneDev& sc, float4* lds, int n_mats)
 	t.mats = sc.mats;
 	t.lights = sc.lights;
 	t.tris = sc.tri_shade;
+	t.tri_si = 4;
+	t.tri_sk = 1;
+	t.stage = lds;
 	if (TAB >= 1) {
 		float4* lm = lds;
 		float4* ll = lm + 4 * n_mats;
@@ -102,9 +122,13 @@ TUTU_DEV ShadeTabs stage_shade_tabs(const SceneDev& sc, float4* lds, int n_mats)
 		for (int i = threadIdx.x; i < 6 * sc.n_lights; i += blockDim.x) ll[i] = sc.lights[i];
 		t.mats = lm;
 		t.lights = ll;
+		t.stage = lt;
 		if (TAB >= 2) {
-			for (int i = threadIdx.x; i < 4 * sc.n_tris; i += blockDim.x) lt[i] = sc.tri_shade[i];
+			for (int i = threadIdx.x; i < 4 * sc.n_tris; i += blockDim.x) lt[(i & 3) * sc.n_tris + (i >> 2)] = sc.tri_shade[i];
 			t.tris = lt;
+			t.tri_si = 1;
+			t.tri_sk = sc.n_tris;
+			t.stage = lt + 4 * sc.n_tris;
 		}
 		__syncthreads();
 	}
@@ -254,340 +278,361 @@ enum ShadeMode { SHADE_FIRST = 0, SHADE_LAMBERT = 1, SHADE_MIRROR = 2, SHADE_REF
 // EXT: the scene has textured objects (textureModify runs between the refractive test and everything else,
 // PathTracing.hpp:152-158) and/or spheres (hit point and normals from the sphere record, Sphere.hpp:44-53); the
 // plain instantiations do not contain that code at all.
+//
+// Work decomposition: SHADE_FIRST: grid (ceil(npix/256), samples), one chunk per wave, chunk id = linear wave id;
+// else persistent waves striding over the 64-entry chunks of the list.  Chunk c writes its survivors to slots
+// [64 c, 64 c + survivors) of the output set, and key / verdict bytes for all 64 slots of its region.
 template <int MODE, int TAB, bool EXT>
 __global__ void __launch_bounds__(256) k_shade(PassParams pp) {
 	constexpr bool FIRST = MODE == SHADE_FIRST;
 	const SceneDev& sc = pp.sc;
 	extern __shared__ float4 shade_lds[];
 	const ShadeTabs tb = stage_shade_tabs<TAB>(sc, shade_lds, pp.n_mats);
+	float4* const stg = tb.stage + (threadIdx.x >> 6) * (SF_COUNT * 64);  // this wave's staging area, [field][lane]
 	const int lane = __lane_id();
+	const unsigned long long lt_mask = (1ull << lane) - 1ull;
 	const int depth = pp.depth;
+	const bool keep_tp = depth >= TUTU_MIN_DEPTH + 1;  // wave-uniform: tp is live from depth 4 on
 
-	// work decomposition: FIRST: grid (ceil(npix/256), samples), slot = sample*npix + item ; else: persistent,
-	// wave-sized chunks over this launch's classes of the class-sorted list, class boundaries padded to a wave
-	uint32_t cnt[TUTU_NCLASS];
-	uint32_t base[TUTU_NCLASS];
-	uint32_t pref[TUTU_NCLASS + 1];
-	uint32_t total_chunks = 0;
-	if (!FIRST && pp.mixed) {
-		// one scattering class in the whole scene: no class sort -- the launch walks the plain list of continuing
-		// slots and every lane reads its own class (the connect-only classes are a minority of masked lanes)
-		total_chunks = (*pp.mixed_count + 63u) >> 6;
-	} else if (!FIRST) {
-		pref[0] = 0;
-		uint32_t run = 0;
-#pragma unroll
-		for (int c = 0; c < TUTU_NCLASS; c++) {
-			const uint32_t n_c = pp.cls_count[c];
-			cnt[c] = ((pp.class_mask >> c) & 1u) ? n_c : 0u;
-			base[c] = run;
-			run += n_c;
-			pref[c + 1] = pref[c] + ((cnt[c] + 63u) >> 6);
-		}
-		total_chunks = pref[TUTU_NCLASS];
+	uint32_t n_in = 0, chunk, total_chunks, chunk_step;
+	if (FIRST) {
+		chunk = ((blockIdx.y * gridDim.x + blockIdx.x) * blockDim.x + threadIdx.x) >> 6;
+		total_chunks = chunk + 1;
+		chunk_step = 1;
+	} else {
+		n_in = *pp.n_in;
+		chunk = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+		total_chunks = (n_in + 63u) >> 6;
+		chunk_step = (gridDim.x * blockDim.x) >> 6;
 	}
-	const uint32_t wave_global = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-	const uint32_t n_waves = (gridDim.x * blockDim.x) >> 6;
 
-	for (uint32_t chunk = FIRST ? 0u : wave_global; FIRST ? (chunk == 0u) : (chunk < total_chunks); chunk += n_waves) {
+	for (; chunk < total_chunks; chunk += chunk_step) {
 		bool act;
-		int chunk_class = 0;  // wave-uniform (class boundaries are padded to a wave); per lane when the list is not class-sorted
-		uint32_t idx = 0;   // work item (FIRST only)
-		uint32_t slot = 0;  // the path's slot
+		int chunk_class = 0;  // class of the hit (per lane)
+		uint32_t idx = 0;     // work item (FIRST only)
+		uint32_t j = 0;       // list position
+		uint32_t slot_in = 0;
 		if (FIRST) {
 			idx = blockIdx.x * blockDim.x + threadIdx.x;
 			act = idx < (uint32_t)pp.npix;
-			slot = pp.smp_list ? idx : blockIdx.y * (uint32_t)pp.npix + idx;
-		} else if (pp.mixed) {
-			const uint32_t j = chunk * 64u + lane;
-			act = j < *pp.mixed_count;
+		} else {
+			j = chunk * 64u + lane;
+			act = j < n_in;
 			if (act) {
-				slot = pp.perm[j];
-				chunk_class = pp.kB[slot] & 7;
-				act = (pp.class_mask >> chunk_class) & 1u;
+				slot_in = pp.list[j];
+				chunk_class = pp.hitK[j] & 7;
 			}
-		} else {
-			uint32_t cb = base[0], cn = cnt[0], cp = 0;
-#pragma unroll
-			for (int k = 1; k < TUTU_NCLASS; k++)
-				if (chunk >= pref[k]) {
-					cb = base[k];
-					cn = cnt[k];
-					cp = pref[k];
-					chunk_class = k;
-				}
-			const uint32_t j = (chunk - cp) * 64u + lane;
-			act = j < cn;
-			if (act) slot = pp.perm[cb + j];
 		}
-		if (!act) {
-			if (FIRST) break;
-			continue;
-		}
-
-		// ---- load the path (only the fields this depth needs)
-		V3 o, d, beta = mk1(1.f), tp = mk1(1.f), fprev = mk1(0.f);
-		V3 Ladd = mk1(0.f);  // radiance this stage adds to the path
-		bool added = false;
-		float t, b1, b2, pm = 0.f, cosprev = 0.f;
-		int tri;
-		uint32_t pix, smp, draw = 0, flags = 0;
-		if (FIRST) {
-			const float4 pd = pp.prim_dir[idx];
-			const float4 ph = pp.prim_hit[idx];
-			o = mk(pp.eye[0], pp.eye[1], pp.eye[2]);
-			d = mk(pd.x, pd.y, pd.z);
-			pix = __float_as_uint(pd.w);
-			t = ph.x; b1 = ph.y; b2 = ph.z; tri = __float_as_int(ph.w);
-			smp = pp.smp_list ? pp.smp_list[idx] : (uint32_t)pp.s0 + blockIdx.y;
-		} else {
-			const float4 A = pp.q.A[slot], B = pp.q.B[slot], C = pp.q.C[slot], D = pp.q.D[slot], H = pp.q.H[slot];
-			o = mk(A.x, A.y, A.z); pix = __float_as_uint(A.w);
-			d = mk(B.x, B.y, B.z);
-			const uint32_t sd = __float_as_uint(B.w);
-			smp = sd >> 8; draw = sd & 0x3Fu; flags = (sd >> 6) & 3u;
-			t = C.x; b1 = C.y; b2 = C.z; tri = __float_as_int(C.w);
-			if (tri == TUTU_TRI_KILLED) flags |= TUTU_FLAG_KILL;
-			beta = mk(D.x, D.y, D.z); pm = D.w;
-			if ((depth - 1) > TUTU_MIN_DEPTH) {  // tp is reset to 1 for shallower vertices (PathTracing.hpp:265)
-				const float4 E = pp.q.E[slot];
-				tp = mk(E.x, E.y, E.z);
-			}
-			fprev = mk(H.x, H.y, H.z); cosprev = H.w;
-		}
-
-		Rng rng;
-		rng.init(pix, smp, draw, pp.key0, pp.key1);
-		const bool hit = tri >= 0;  // (a killed path keeps go = false below)
-		bool go = true;  // proceed to shading of the vertex at `depth`
-
-		// hit-point data (Triangle.hpp:50-57)
-		V3 pos = mk1(0.f), Ns = mk1(0.f), Ng = mk1(0.f);
-		int mat_id = 0;
-		float hit_light_pdf = 0.f;
-		bool is_sphere = false;
-		if (hit) {
-			const float4 s0 = tb.tris[4 * tri + 0];
-			const float4 s1 = tb.tris[4 * tri + 1];
-			const float4 s2 = tb.tris[4 * tri + 2];
-			const float4 s3 = tb.tris[4 * tri + 3];
-			const V3 n0 = mk(s0.x, s0.y, s0.z), n1 = mk(s0.w, s1.x, s1.y), n2 = mk(s1.z, s1.w, s2.x);
-			Ng = mk(s2.y, s2.z, s2.w);
-			mat_id = __float_as_int(s3.x);
-			hit_light_pdf = s3.z;
-			pos = o + t * d;
-			if (EXT && (__float_as_int(s3.w) & TUTU_CLS_SPHERE)) {  // n0 = centre
-				is_sphere = true;
-				Ng = normalized(pos - n0);
-				Ns = Ng;
+		uint32_t key = 0;       // TUTU_KEY_* of the record this lane leaves behind (0: the path ended here)
+		bool alt_origin = false;
+		if (act) {
+			// ---- load the path (only the fields this depth needs)
+			V3 o, d, beta = mk1(1.f), tp = mk1(1.f), fprev = mk1(0.f);
+			V3 Lsum = mk1(0.f);   // radiance gathered so far
+			V3 Ladd = mk1(0.f);   // radiance this stage adds to the path
+			bool added = false;
+			float t, b1, b2, pm = 0.f, cosprev = 0.f;
+			int tri;
+			uint32_t pix, smp, draw = 0, flags = 0, home;
+			if (FIRST) {
+				const float4 pd = pp.prim_dir[idx];
+				const float4 ph = pp.prim_hit[idx];
+				o = mk(pp.eye[0], pp.eye[1], pp.eye[2]);
+				d = mk(pd.x, pd.y, pd.z);
+				pix = __float_as_uint(pd.w);
+				t = ph.x; b1 = ph.y; b2 = ph.z; tri = __float_as_int(ph.w);
+				smp = pp.smp_list ? pp.smp_list[idx] : (uint32_t)pp.s0 + blockIdx.y;
+				home = pp.smp_list ? idx : blockIdx.y * (uint32_t)pp.npix + idx;
 			} else {
-				Ns = normalized((n0 * (1 - b1 - b2)) + n1 * b1 + n2 * b2);
-			}
-		}
-
-		// ---- connect: finish vertex depth-1 now that the hit of its BSDF ray is known (PathTracing.hpp:234-278)
-		if (FIRST) {
-			if (!hit) {  // :150
-				Ladd = beta * mk(sc.bkg[0], sc.bkg[1], sc.bkg[2]);
-				added = true;
-				go = false;
-			}
-		} else if (flags & TUTU_FLAG_KILL) {
-			go = false;
-		} else if (flags & TUTU_FLAG_PREV_REFRACTIVE) {
-			if (!hit) {  // :150 reached through calcForRefractive's recursive call
-				Ladd = beta * mk(sc.bkg[0], sc.bkg[1], sc.bkg[2]);
-				added = true;
-				go = false;
-			}
-		} else if (!hit) {  // :234 -- background is NOT added for secondary misses
-			go = false;
-		} else {
-			bool indirect = true;
-			if (hit_light_pdf) {  // getLightPdf > 0 (:239-240); non-zero test, as there
-				const V3 light_N = normalized(Ns);
-				const float cos_theta_prime = dot(light_N, -d);
-				if (!(cos_theta_prime <= 0)) {  // else: back of a light, falls into the indirect branch (:243-244)
-					indirect = false;
-					const float4 G = pp.q.G[slot];
-					const float r2 = norm2(pos - mk(G.x, G.y, G.z));
-					const float l_pdf_transformed = hit_light_pdf * r2 / cos_theta_prime;
-					float mis_weight_m = getMisWeight(pm, l_pdf_transformed);
-					if (flags & TUTU_FLAG_PREV_MIRROR_PM1) mis_weight_m = 1.f;
-					const float4 em = tb.mats[4 * mat_id + 1];
-					if (!(pm < TUTU_MIN_DIVISOR)) {
-						Ladd = beta * (mis_weight_m * mk(em.x, em.y, em.z) * fprev * cosprev / pm);
-						added = true;
-					}
-					go = false;
+				const float4 A = pp.in.A[slot_in], B = pp.in.B[slot_in], C = pp.hitC[j], D = pp.in.D[slot_in], H = pp.in.H[slot_in];
+				const float4 Lr = pp.in.L[slot_in];
+				const uint32_t verdict = pp.in.V[slot_in];
+				o = mk(A.x, A.y, A.z); pix = __float_as_uint(A.w);
+				d = mk(B.x, B.y, B.z);
+				const uint32_t sd = __float_as_uint(B.w);
+				smp = sd >> 8; draw = sd & 0x3Fu; flags = (sd >> 6) & 3u;
+				t = C.x; b1 = C.y; b2 = C.z; tri = __float_as_int(C.w);
+				beta = mk(D.x, D.y, D.z); pm = D.w;
+				if ((depth - 1) > TUTU_MIN_DEPTH) {  // tp is reset to 1 for shallower vertices (PathTracing.hpp:265)
+					const float4 E = pp.in.E[slot_in];
+					tp = mk(E.x, E.y, E.z);
+				}
+				fprev = mk(H.x, H.y, H.z); cosprev = H.w;
+				Lsum = mk(Lr.x, Lr.y, Lr.z); home = __float_as_uint(Lr.w);
+				// the shadow request of the previous vertex: trace_any left its verdict, the contribution is added here
+				if (verdict == TUTU_V_ADD) {
+					const float4 P = pp.in.P[slot_in];
+					Lsum = mk(Lsum.x + P.x, Lsum.y + P.y, Lsum.z + P.z);
+				} else if (verdict == TUTU_V_KILLED) {
+					flags |= TUTU_FLAG_KILL;
 				}
 			}
-			if (indirect) {  // :264-277
-				tp = (depth - 1) > TUTU_MIN_DEPTH ? tp : mk1(1.f);
-				const float rr_prob = std_max(tp.x, std_max(tp.y, tp.z));
-				if (rng.next() > rr_prob) {
-					go = false;
+
+			Rng rng;
+			rng.init(pix, smp, draw, pp.key0, pp.key1);
+			const bool hit = tri >= 0;
+			bool go = true;  // proceed to shading of the vertex at `depth`
+
+			// hit-point data (Triangle.hpp:50-57)
+			V3 pos = mk1(0.f), Ns = mk1(0.f), Ng = mk1(0.f);
+			int mat_id = 0;
+			float hit_light_pdf = 0.f;
+			bool is_sphere = false;
+			if (hit) {
+				const float4 s0 = tb.tri(tri, 0);
+				const float4 s1 = tb.tri(tri, 1);
+				const float4 s2 = tb.tri(tri, 2);
+				const float4 s3 = tb.tri(tri, 3);
+				const V3 n0 = mk(s0.x, s0.y, s0.z), n1 = mk(s0.w, s1.x, s1.y), n2 = mk(s1.z, s1.w, s2.x);
+				Ng = mk(s2.y, s2.z, s2.w);
+				mat_id = __float_as_int(s3.x);
+				hit_light_pdf = s3.z;
+				pos = o + t * d;
+				if (EXT && (__float_as_int(s3.w) & TUTU_CLS_SPHERE)) {  // n0 = centre
+					is_sphere = true;
+					Ng = normalized(pos - n0);
+					Ns = Ng;
 				} else {
-					const V3 coe = fprev * cosprev / (pm * rr_prob);
-					if (pm * rr_prob < TUTU_MIN_DIVISOR) {
+					Ns = normalized((n0 * (1 - b1 - b2)) + n1 * b1 + n2 * b2);
+				}
+			}
+
+			// ---- connect: finish vertex depth-1 now that the hit of its BSDF ray is known (PathTracing.hpp:234-278)
+			if (FIRST) {
+				if (!hit) {  // :150
+					Ladd = beta * mk(sc.bkg[0], sc.bkg[1], sc.bkg[2]);
+					added = true;
+					go = false;
+				}
+			} else if (flags & TUTU_FLAG_KILL) {
+				go = false;
+			} else if (flags & TUTU_FLAG_PREV_REFRACTIVE) {
+				if (!hit) {  // :150 reached through calcForRefractive's recursive call
+					Ladd = beta * mk(sc.bkg[0], sc.bkg[1], sc.bkg[2]);
+					added = true;
+					go = false;
+				}
+			} else if (!hit) {  // :234 -- background is NOT added for secondary misses
+				go = false;
+			} else {
+				bool indirect = true;
+				if (hit_light_pdf) {  // getLightPdf > 0 (:239-240); non-zero test, as there
+					const V3 light_N = normalized(Ns);
+					const float cos_theta_prime = dot(light_N, -d);
+					if (!(cos_theta_prime <= 0)) {  // else: back of a light, falls into the indirect branch (:243-244)
+						indirect = false;
+						const float4 G = pp.in.G[slot_in];
+						const float r2 = norm2(pos - mk(G.x, G.y, G.z));
+						const float l_pdf_transformed = hit_light_pdf * r2 / cos_theta_prime;
+						float mis_weight_m = getMisWeight(pm, l_pdf_transformed);
+						if (flags & TUTU_FLAG_PREV_MIRROR_PM1) mis_weight_m = 1.f;
+						const float4 em = tb.mats[4 * mat_id + 1];
+						if (!(pm < TUTU_MIN_DIVISOR)) {
+							Ladd = beta * (mis_weight_m * mk(em.x, em.y, em.z) * fprev * cosprev / pm);
+							added = true;
+						}
+						go = false;
+					}
+				}
+				if (indirect) {  // :264-277
+					tp = (depth - 1) > TUTU_MIN_DEPTH ? tp : mk1(1.f);
+					const float rr_prob = std_max(tp.x, std_max(tp.y, tp.z));
+					if (rng.next() > rr_prob) {
 						go = false;
 					} else {
-						tp = tp * coe;
-						beta = beta * coe;
+						const V3 coe = fprev * cosprev / (pm * rr_prob);
+						if (pm * rr_prob < TUTU_MIN_DIVISOR) {
+							go = false;
+						} else {
+							tp = tp * coe;
+							beta = beta * coe;
+						}
 					}
 				}
 			}
-		}
-		if (go && depth > TUTU_MAX_DEPTH) go = false;  // :140 / :82
+			if (go && depth > TUTU_MAX_DEPTH) go = false;  // :140 / :82
 
-		// ---- shade the vertex at `depth`; every result goes to the slot as soon as it exists
-		uint32_t key = 0;
-		if (go) {
-			Mat m = load_mat(tb, mat_id);  // per-hit copy, like Intersection::mtlcolor
-			// classes 5..7 (UNLIT, emissive hit, miss) only connect and end; they ride along with the first material
-			// launch of the depth.  The chunk's class is wave-uniform.
-			const bool terminal = !FIRST && chunk_class >= TUTU_UNLIT;
-			if (!terminal) {
-				if (MODE == SHADE_LAMBERT) m.type = TUTU_LAMBERTIAN;  // class-sorted: known at compile time
-				if (MODE == SHADE_MIRROR) m.type = TUTU_PERFECT_REFLECTIVE;
-				if (MODE == SHADE_GGXR) m.type = TUTU_MICROFACET_R;
-			}
-			const V3 wo = -d;
-			const bool refractive = m.type == TUTU_PERFECT_REFRACTIVE || m.type == TUTU_MICROFACET_T;
-			if (EXT && sc.has_tex && !refractive) texture_modify(sc, tri, b1, b2, is_sphere, Ng, m, Ns);  // :157-158
-			if (terminal) {
-				if (m.type == TUTU_UNLIT) {  // :161
+			// ---- shade the vertex at `depth`; every result goes to the staging area as soon as it exists
+			if (go) {
+				Mat m = load_mat(tb, mat_id);  // per-hit copy, like Intersection::mtlcolor
+				// classes 5..7 (UNLIT, emissive hit, miss) only connect and end
+				const bool terminal = !FIRST && chunk_class >= TUTU_UNLIT;
+				if (!terminal) {
+					if (MODE == SHADE_LAMBERT) m.type = TUTU_LAMBERTIAN;  // single-class scene: known at compile time
+					if (MODE == SHADE_MIRROR) m.type = TUTU_PERFECT_REFLECTIVE;
+					if (MODE == SHADE_GGXR) m.type = TUTU_MICROFACET_R;
+				}
+				const V3 wo = -d;
+				const bool refractive = m.type == TUTU_PERFECT_REFRACTIVE || m.type == TUTU_MICROFACET_T;
+				if (EXT && sc.has_tex && !refractive) texture_modify(sc, tri, b1, b2, is_sphere, Ng, m, Ns);  // :157-158
+				if (terminal) {
+					if (m.type == TUTU_UNLIT) {  // :161
+						Ladd = beta * m.diffuse;
+						added = true;
+					}  // emissive at depth > 0 adds nothing (:164-165); unknown material types end like their `default:` branches
+				} else if ((FIRST || MODE == SHADE_REFRACT || MODE == SHADE_ANY) && refractive) {
+					// calcForRefractive, PathTracing.hpp:80-134
+					float eta_i = sc.eta, eta_t = m.eta;
+					V3 wi = mk1(0.f);
+					bool ok, TIR;
+					sampleDirection(m, wo, Ns, wi, eta_i, rng, ok, TIR);
+					wi = normalized(wi);
+					float p = mat_pdf(m, wi, wo, Ns, eta_i, eta_t);
+					if (TIR) {
+						wi = normalized(getReflectionDir(wo, Ns));
+						p = 1;
+						if (m.type == TUTU_MICROFACET_T) {
+							V3 interNs = Ns;
+							if (dot(wo, Ng) < 0) {
+								float tmp = eta_i; eta_i = eta_t; eta_t = tmp;
+								interNs = -interNs;
+							}
+							const V3 h = normalized(wo + wi);
+							const float cosTheta = fabsf(dot(interNs, h));
+							wi = normalized(getReflectionDir(wo, h));
+							p = 1 * D_ndf(h, interNs, m.roughness) * cosTheta / (4.f * dot(wo, h));
+						}
+					}
+					const V3 f_r = BxDF(m, wi, wo, Ng, Ns, eta_i, TIR);
+					V3 rayOrig = pos;
+					float cosv = 0;
+					if (dot(wi, Ns) > 0) {
+						rayOrig = rayOrig + Ns * TUTU_EPSILON;
+						cosv = fabsf(dot(Ng, wi));
+					} else {
+						rayOrig = rayOrig - Ns * TUTU_EPSILON;
+						cosv = fabsf(dot(-Ng, wi));
+					}
+					// :128-133 -- the reference traces the continuation and then drops it when pdf < MIN_DIVISOR
+					if (!(p < TUTU_MIN_DIVISOR || depth + 1 > TUTU_MAX_DEPTH)) {
+						beta = ((beta * cosv) * f_r) / p;
+						stg[SF_A * 64 + lane] = make_float4(rayOrig.x, rayOrig.y, rayOrig.z, __uint_as_float(pix));
+						stg[SF_B * 64 + lane] = make_float4(wi.x, wi.y, wi.z, __uint_as_float((smp << 8) | (TUTU_FLAG_PREV_REFRACTIVE << 6) | (rng.draw & 0x3Fu)));
+						stg[SF_D * 64 + lane] = make_float4(beta.x, beta.y, beta.z, 0.f);
+						if (keep_tp) stg[SF_E * 64 + lane] = make_float4(1.f, 1.f, 1.f, 0.f);  // tp = 1
+						key = TUTU_KEY_NEXT;
+					}
+				} else if (FIRST && m.type == TUTU_UNLIT) {  // :161
 					Ladd = beta * m.diffuse;
 					added = true;
-				}  // emissive at depth > 0 adds nothing (:164-165); unknown material types end like their `default:` branches
-			} else if ((FIRST || MODE == SHADE_REFRACT || MODE == SHADE_ANY) && refractive) {
-				// calcForRefractive, PathTracing.hpp:80-134
-				float eta_i = sc.eta, eta_t = m.eta;
-				V3 wi = mk1(0.f);
-				bool ok, TIR;
-				sampleDirection(m, wo, Ns, wi, eta_i, rng, ok, TIR);
-				wi = normalized(wi);
-				float p = mat_pdf(m, wi, wo, Ns, eta_i, eta_t);
-				if (TIR) {
-					wi = normalized(getReflectionDir(wo, Ns));
-					p = 1;
-					if (m.type == TUTU_MICROFACET_T) {
-						V3 interNs = Ns;
-						if (dot(wo, Ng) < 0) {
-							float tmp = eta_i; eta_i = eta_t; eta_t = tmp;
-							interNs = -interNs;
-						}
-						const V3 h = normalized(wo + wi);
-						const float cosTheta = fabsf(dot(interNs, h));
-						wi = normalized(getReflectionDir(wo, h));
-						p = 1 * D_ndf(h, interNs, m.roughness) * cosTheta / (4.f * dot(wo, h));
+				} else if (FIRST && m.has_emission) {  // :164-170
+					if (depth == 0) {
+						Ladd = beta * m.emission;
+						added = true;
 					}
-				}
-				const V3 f_r = BxDF(m, wi, wo, Ng, Ns, eta_i, TIR);
-				V3 rayOrig = pos;
-				float cosv = 0;
-				if (dot(wi, Ns) > 0) {
-					rayOrig = rayOrig + Ns * TUTU_EPSILON;
-					cosv = fabsf(dot(Ng, wi));
-				} else {
-					rayOrig = rayOrig - Ns * TUTU_EPSILON;
-					cosv = fabsf(dot(-Ng, wi));
-				}
-				// :128-133 -- the reference traces the continuation and then drops it when pdf < MIN_DIVISOR
-				if (!(p < TUTU_MIN_DIVISOR || depth + 1 > TUTU_MAX_DEPTH)) {
-					beta = ((beta * cosv) * f_r) / p;
-					pp.q.A[slot] = make_float4(rayOrig.x, rayOrig.y, rayOrig.z, __uint_as_float(pix));
-					pp.q.B[slot] = make_float4(wi.x, wi.y, wi.z, __uint_as_float((smp << 8) | (TUTU_FLAG_PREV_REFRACTIVE << 6) | (rng.draw & 0x3Fu)));
-					pp.q.D[slot] = make_float4(beta.x, beta.y, beta.z, 0.f);
-					if (depth >= TUTU_MIN_DEPTH + 1) pp.q.E[slot] = make_float4(1.f, 1.f, 1.f, 0.f);  // tp = 1
-					key = TUTU_KEY_NEXT;
-				}
-			} else if (FIRST && m.type == TUTU_UNLIT) {  // :161
-				Ladd = beta * m.diffuse;
-				added = true;
-			} else if (FIRST && m.has_emission) {  // :164-170
-				if (depth == 0) {
-					Ladd = beta * m.emission;
-					added = true;
-				}
-			} else if (MODE != SHADE_TERMINAL && MODE != SHADE_REFRACT) {
-				// ---- light sampling, :180-219
-				bool kill_req = false;
-				if (sc.n_lights > 0) {
-					const LightSample ls = sample_light(tb, sc.n_lights, rng);
-					V3 wi = ls.pos - pos;
-					const float r2 = norm2(wi);
-					wi = normalized(wi);
-					if (!(dot(wi, ls.N) > 0)) {
-						const float mpdf = mat_pdf(m, wi, wo, Ns, sc.eta, m.eta);
-						const V3 light_N = normalized(ls.N);
-						const float cos_theta_prime = dot(light_N, -wi);
-						if (!(cos_theta_prime <= 0)) {
-							const float cos_theta = fabsf(dot(Ng, wi));
-							const float pdfl = ls.pdf;
-							const float light_pdf = pdfl * r2 / cos_theta_prime;
-							const float mis_weight_l = getMisWeight(light_pdf, mpdf);
-							const V3 f_r = BxDF(m, wi, wo, Ng, Ns, sc.eta, false);
-							const bool rayInside = dot(Ns, wo) < 0;
-							V3 shadowRayOrig = pos;
-							if (rayInside) shadowRayOrig = shadowRayOrig - Ns * TUTU_EPSILON;
-							else shadowRayOrig = shadowRayOrig + Ns * TUTU_EPSILON;
-							const V3 lightPos = ls.pos + ls.N * TUTU_EPSILON;
-							V3 sh_c = mk1(0.f);
-							uint32_t sh_flags = 0;
-							if (r2 * pdfl < TUTU_MIN_DIVISOR) {
-								sh_flags = TUTU_FLAG_KILL;  // :215: an UNBLOCKED shadow ray ends the whole path here
-								kill_req = true;
-							} else {
-								sh_c = beta * (mis_weight_l * ls.emission * f_r * cos_theta * cos_theta_prime / (r2 * pdfl));
-							}
-							// A contribution that is exactly zero (surface facing away from the light: f_r = 0) cannot change
-							// the radiance whatever the shadow ray finds: the reference traces that ray for nothing, we do not.
-							// (NaN != 0, so a NaN contribution is still traced and still poisons the sample as it must.)
-							if (kill_req || sh_c.x != 0.f || sh_c.y != 0.f || sh_c.z != 0.f) {
-								pp.q.S0[slot] = make_float4(shadowRayOrig.x, shadowRayOrig.y, shadowRayOrig.z, lightPos.x);
-								pp.q.S1[slot] = make_float4(lightPos.y, lightPos.z, sh_c.x, sh_c.y);
-								pp.q.S2[slot] = make_float4(sh_c.z, __uint_as_float(sh_flags), 0.f, 0.f);
-								key |= TUTU_KEY_SHADOW;
+				} else if (MODE != SHADE_TERMINAL && MODE != SHADE_REFRACT) {
+					// ---- light sampling, :180-219
+					bool kill_req = false;
+					bool shadow_inside = false;  // which side of the surface the shadow ray starts on (:187-190)
+					if (sc.n_lights > 0) {
+						const LightSample ls = sample_light(tb, sc.n_lights, rng);
+						V3 wi = ls.pos - pos;
+						const float r2 = norm2(wi);
+						wi = normalized(wi);
+						if (!(dot(wi, ls.N) > 0)) {
+							const float mpdf = mat_pdf(m, wi, wo, Ns, sc.eta, m.eta);
+							const V3 light_N = normalized(ls.N);
+							const float cos_theta_prime = dot(light_N, -wi);
+							if (!(cos_theta_prime <= 0)) {
+								const float cos_theta = fabsf(dot(Ng, wi));
+								const float pdfl = ls.pdf;
+								const float light_pdf = pdfl * r2 / cos_theta_prime;
+								const float mis_weight_l = getMisWeight(light_pdf, mpdf);
+								const V3 f_r = BxDF(m, wi, wo, Ng, Ns, sc.eta, false);
+								shadow_inside = dot(Ns, wo) < 0;
+								const V3 lightPos = ls.pos + ls.N * TUTU_EPSILON;
+								V3 sh_c = mk1(0.f);
+								if (r2 * pdfl < TUTU_MIN_DIVISOR) {
+									kill_req = true;  // :215: an UNBLOCKED shadow ray ends the whole path here
+								} else {
+									sh_c = beta * (mis_weight_l * ls.emission * f_r * cos_theta * cos_theta_prime / (r2 * pdfl));
+								}
+								// A contribution that is exactly zero (surface facing away from the light: f_r = 0) cannot change
+								// the radiance whatever the shadow ray finds: the reference traces that ray for nothing, we do not.
+								// (NaN != 0, so a NaN contribution is still traced and still poisons the sample as it must.)
+								if (kill_req || sh_c.x != 0.f || sh_c.y != 0.f || sh_c.z != 0.f) {
+									stg[SF_S * 64 + lane] = make_float4(lightPos.x, lightPos.y, lightPos.z, 0.f);
+									stg[SF_P * 64 + lane] = make_float4(sh_c.x, sh_c.y, sh_c.z, 0.f);
+									key |= TUTU_KEY_SHADOW | (kill_req ? TUTU_KEY_KILL : 0u);
+								}
 							}
 						}
 					}
-				}
-				// ---- BSDF sampling, :222-233
-				V3 wi = mk1(0.f);
-				bool ok, special;
-				sampleDirection(m, wo, Ns, wi, sc.eta, rng, ok, special);
-				if (ok) {  // else :225-226
-					const float n_pm = mat_pdf(m, wi, wo, Ns, sc.eta, m.eta);
-					V3 rayOrig = pos;
-					if (dot(wi, Ns) < 0) rayOrig = rayOrig - Ns * TUTU_EPSILON;
-					else rayOrig = rayOrig + Ns * TUTU_EPSILON;
-					const V3 n_f = BxDF(m, wi, wo, Ng, Ns, sc.eta, false);
-					const float n_cos = fabsf(dot(Ng, wi));
-					const uint32_t n_flags = (m.type == TUTU_PERFECT_REFLECTIVE && n_pm == 1.f) ? TUTU_FLAG_PREV_MIRROR_PM1 : 0u;
-					pp.q.A[slot] = make_float4(rayOrig.x, rayOrig.y, rayOrig.z, __uint_as_float(pix));
-					pp.q.B[slot] = make_float4(wi.x, wi.y, wi.z, __uint_as_float((smp << 8) | (n_flags << 6) | (rng.draw & 0x3Fu)));
-					pp.q.D[slot] = make_float4(beta.x, beta.y, beta.z, n_pm);
-					if (depth >= TUTU_MIN_DEPTH + 1) pp.q.E[slot] = make_float4(tp.x, tp.y, tp.z, 0.f);
-					pp.q.G[slot] = make_float4(pos.x, pos.y, pos.z, 0.f);
-					pp.q.H[slot] = make_float4(n_f.x, n_f.y, n_f.z, n_cos);
-					key |= TUTU_KEY_NEXT;
-				} else if (kill_req) {
-					key &= ~TUTU_KEY_SHADOW;  // the path ends here anyway: nothing left for the shadow ray to kill
+					// ---- BSDF sampling, :222-233
+					V3 wi = mk1(0.f);
+					bool ok, special;
+					sampleDirection(m, wo, Ns, wi, sc.eta, rng, ok, special);
+					if (ok) {  // else :225-226
+						const float n_pm = mat_pdf(m, wi, wo, Ns, sc.eta, m.eta);
+						const bool ray_inside = dot(wi, Ns) < 0;
+						V3 rayOrig = pos;
+						if (ray_inside) rayOrig = rayOrig - Ns * TUTU_EPSILON;
+						else rayOrig = rayOrig + Ns * TUTU_EPSILON;
+						const V3 n_f = BxDF(m, wi, wo, Ng, Ns, sc.eta, false);
+						const float n_cos = fabsf(dot(Ng, wi));
+						const uint32_t n_flags = (m.type == TUTU_PERFECT_REFLECTIVE && n_pm == 1.f) ? TUTU_FLAG_PREV_MIRROR_PM1 : 0u;
+						stg[SF_A * 64 + lane] = make_float4(rayOrig.x, rayOrig.y, rayOrig.z, __uint_as_float(pix));
+						stg[SF_B * 64 + lane] = make_float4(wi.x, wi.y, wi.z, __uint_as_float((smp << 8) | (n_flags << 6) | (rng.draw & 0x3Fu)));
+						stg[SF_D * 64 + lane] = make_float4(beta.x, beta.y, beta.z, n_pm);
+						if (keep_tp) stg[SF_E * 64 + lane] = make_float4(tp.x, tp.y, tp.z, 0.f);
+						stg[SF_G * 64 + lane] = make_float4(pos.x, pos.y, pos.z, 0.f);
+						stg[SF_H * 64 + lane] = make_float4(n_f.x, n_f.y, n_f.z, n_cos);
+						// the shadow ray starts at `pos -/+ Ns*EPSILON` as well (:187-190): the same bits as rayOrig when both
+						// rays leave on the same side (always, for a Lambertian vertex); else it gets a field of its own
+						if ((key & TUTU_KEY_SHADOW) && shadow_inside != ray_inside) {
+							const V3 so = shadow_inside ? pos - Ns * TUTU_EPSILON : pos + Ns * TUTU_EPSILON;
+							stg[SF_S2 * 64 + lane] = make_float4(so.x, so.y, so.z, 0.f);
+							key |= TUTU_KEY_ALT;
+							alt_origin = true;
+						}
+						key |= TUTU_KEY_NEXT;
+					} else if (kill_req) {
+						key = 0;  // the path ends here anyway: nothing left for the shadow ray to kill
+					} else if (key & TUTU_KEY_SHADOW) {
+						// the path's last act is this shadow request: its origin goes where the extension ray's would
+						const V3 so = shadow_inside ? pos - Ns * TUTU_EPSILON : pos + Ns * TUTU_EPSILON;
+						stg[SF_A * 64 + lane] = make_float4(so.x, so.y, so.z, __uint_as_float(pix));
+						key |= TUTU_KEY_FINAL;
+					}
 				}
 			}
+			// radiance: a path has at most one term per stage besides its shadow request (background, UNLIT, emission
+			// or MIS-weighted emission).  A path that ends here without a pending shadow request is finished.
+			if (added) Lsum = mk(Lsum.x + Ladd.x, Lsum.y + Ladd.y, Lsum.z + Ladd.z);
+			if (key == 0) pp.F[home] = make_float4(Lsum.x, Lsum.y, Lsum.z, 0.f);
+			else stg[SF_L * 64 + lane] = make_float4(Lsum.x, Lsum.y, Lsum.z, __uint_as_float(home));
 		}
-		// radiance: depth 0 initialises the accumulator; later stages touch it only when they add something.
-		// (a path always has at most one such term per stage: background, UNLIT, emission or MIS-weighted emission)
-		if (FIRST) {
-			pp.q.F[slot] = make_float4(Ladd.x, Ladd.y, Ladd.z, 0.f);  // 0 + term
-		} else if (added) {
-			float4 F = pp.q.F[slot];
-			F.x = F.x + Ladd.x; F.y = F.y + Ladd.y; F.z = F.z + Ladd.z;
-			pp.q.F[slot] = F;
+
+		// ---- compact the chunk's survivors to the front of its 64 output slots.  All 64 lanes take part.
+		const bool surv = key != 0;
+		const unsigned long long m_surv = __ballot(surv);
+		const uint32_t n_surv = (uint32_t)__popcll(m_surv);
+		const uint32_t rank = surv ? (uint32_t)__popcll(m_surv & lt_mask) : n_surv + (uint32_t)__popcll(~m_surv & lt_mask);
+		const bool any_alt = __ballot(alt_origin) != 0ull;
+		// lane r receives the lane index and the key of the survivor of rank r (ended / idle lanes send key 0 behind them)
+		const int src = __builtin_amdgcn_ds_permute((int)(rank << 2), lane);
+		const uint32_t key_r = (uint32_t)__builtin_amdgcn_ds_permute((int)(rank << 2), (int)key);
+		__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // the other lanes' staged fields are read below
+		__builtin_amdgcn_wave_barrier();
+		const uint32_t out0 = chunk * 64u;
+		if ((uint32_t)lane < n_surv) {
+			const uint32_t so = out0 + lane;
+			pp.out.A[so] = stg[SF_A * 64 + src];
+			pp.out.L[so] = stg[SF_L * 64 + src];
+			if (MODE != SHADE_TERMINAL) {
+				pp.out.B[so] = stg[SF_B * 64 + src];
+				pp.out.D[so] = stg[SF_D * 64 + src];
+				pp.out.H[so] = stg[SF_H * 64 + src];
+				pp.out.G[so] = stg[SF_G * 64 + src];
+				if (keep_tp) pp.out.E[so] = stg[SF_E * 64 + src];
+			}
+			pp.out.S[so] = stg[SF_S * 64 + src];
+			pp.out.P[so] = stg[SF_P * 64 + src];
+			if (any_alt) pp.out.S2[so] = stg[SF_S2 * 64 + src];
 		}
-		pp.kA[slot] = (uint8_t)(key | (((uint32_t)pp.depth & 7u) << 2));  // stage stamp: see device_lists.h
-		if (FIRST) break;
+		pp.out.key[out0 + lane] = (uint8_t)key_r;
+		pp.out.V[out0 + lane] = (uint8_t)TUTU_V_BLOCKED;
+		__builtin_amdgcn_wave_barrier();  // the next chunk's staging writes stay behind these reads
 	}
 }
 
@@ -607,11 +652,12 @@ __global__ void __launch_bounds__(256) k_shade(PassParams pp) {
 
 struct TraceParams {
 	SceneDev sc;
-	Queue q;
+	Records rec;            // the record set the shade stage of this depth wrote
 	const uint32_t* list;   // slots to trace
 	const uint32_t* n_ptr;  // device count
-	uint8_t* kA;            // any-hit: the consumed request's flag is cleared
-	uint8_t* kB;            // closest-hit: material class of the hit
+	float4* hitC;           // closest-hit: t, b1, b2 | triangle, per LIST POSITION
+	uint8_t* hitK;          // closest-hit: material class of the hit, per list position
+	float4* F;              // any-hit: final radiance per home slot (TUTU_KEY_FINAL requests)
 	const uint8_t* tri_class;  // per triangle (leaf order): class of its material
 	int stack_entries;
 	// work counters, per block: [block][0] nodes entered, [1] leaf tests (SURVEY.md 8(d)'s N and T, measured on the tree
@@ -638,7 +684,7 @@ TUTU_DEV void trace_persistent(const S& ss, const TraceParams& tp, int* stack, c
 	int cur = TUTU_TRAV_IDLE;
 	int pend = TUTU_TRAV_IDLE;  // parked leaf (TUTU_TRAV_IDLE = none)
 	int sp = 0;
-	uint32_t slot = 0;
+	uint32_t slot = 0;  // closest-hit: the ray's list position (where its hit goes); any-hit: the request's record slot
 	RayPre r = make_ray(mk1(0.f), mk1(1.f));
 	float best_t = FLT_MAX, best_u = 0.f, best_v = 0.f;
 	int best_tri = -1;
@@ -647,10 +693,9 @@ TUTU_DEV void trace_persistent(const S& ss, const TraceParams& tp, int* stack, c
 	uint32_t w_node_steps = 0, w_leaf_steps = 0, w_outer = 0;  // wave-uniform: how often each phase ran (TUTU_UTIL_STATS)
 	// any-hit only
 	float dis = 0.f;
-	float4 Fpre = make_float4(0.f, 0.f, 0.f, 0.f);  // the path's radiance, requested with the shadow request: an unblocked
-	                                                // ray adds to it at the finish without waiting for a load there
-	V3 contrib = mk1(0.f);
-	uint32_t fl = 0;
+	float4 Lpre = make_float4(0.f, 0.f, 0.f, 0.f);  // TUTU_KEY_FINAL requests: the path's radiance | home slot and the
+	V3 contrib = mk1(0.f);                          // contribution, requested with the ray so that the finish does not wait
+	uint32_t fl = 0;                                // key byte of the request
 	bool blocked = false;
 
 	for (;;) {
@@ -661,15 +706,20 @@ TUTU_DEV void trace_persistent(const S& ss, const TraceParams& tp, int* stack, c
 			if (cur == TUTU_TRAV_IDLE && i < end) {
 				slot = tp.list[i];
 				if (!ANY) {
-					const float4 A = tp.q.A[slot], B = tp.q.B[slot];
+					const float4 A = tp.rec.A[slot], B = tp.rec.B[slot];
+					slot = i;
 					r = make_ray(mk(A.x, A.y, A.z), mk(B.x, B.y, B.z));
 					best_t = FLT_MAX; best_u = 0.f; best_v = 0.f; best_tri = -1;
 				} else {
-					const float4 e0 = tp.q.S0[slot], e1 = tp.q.S1[slot], e2 = tp.q.S2[slot];
-					Fpre = tp.q.F[slot];  // nobody else touches this path's record while its shadow ray is in flight
-					const V3 so = mk(e0.x, e0.y, e0.z), lo = mk(e0.w, e1.x, e1.y);
-					contrib = mk(e1.z, e1.w, e2.x);
-					fl = __float_as_uint(e2.y);
+					fl = tp.rec.key[slot];
+					const float4 e0 = (fl & TUTU_KEY_ALT) ? tp.rec.S2[slot] : tp.rec.A[slot];
+					const float4 e1 = tp.rec.S[slot];
+					if (fl & TUTU_KEY_FINAL) {  // nobody else touches this path's record any more
+						Lpre = tp.rec.L[slot];
+						const float4 e2 = tp.rec.P[slot];
+						contrib = mk(e2.x, e2.y, e2.z);
+					}
+					const V3 so = mk(e0.x, e0.y, e0.z), lo = mk(e1.x, e1.y, e1.z);
 					// isShadowRayBlocked, IIntegrator.hpp:135-137
 					const V3 raydir = normalized(lo - so);
 					dis = norm(lo - so);
@@ -768,16 +818,17 @@ TUTU_DEV void trace_persistent(const S& ss, const TraceParams& tp, int* stack, c
 		// ---- finish
 		if (cur == TUTU_TRAV_DONE && pend == TUTU_TRAV_IDLE) {
 			if (!ANY) {
-				tp.q.C[slot] = make_float4(best_t, best_u, best_v, __int_as_float(best_tri));
-				tp.kB[slot] = best_tri >= 0 ? tri_class[best_tri] : (uint8_t)TUTU_CLASS_MISS;
-			} else if (!blocked) {
-				if (fl & TUTU_FLAG_KILL) {
-					reinterpret_cast<int*>(&tp.q.C[slot])[3] = TUTU_TRI_KILLED;  // the hit of the (speculative) extension ray is void
-				} else {
-					float4 F = Fpre;
+				tp.hitC[slot] = make_float4(best_t, best_u, best_v, __int_as_float(best_tri));
+				tp.hitK[slot] = best_tri >= 0 ? tri_class[best_tri] : (uint8_t)TUTU_CLASS_MISS;
+			} else if (fl & TUTU_KEY_FINAL) {  // the path ended with this request: its sample is finished
+				float4 F = make_float4(Lpre.x, Lpre.y, Lpre.z, 0.f);
+				if (!blocked) {
 					F.x = F.x + contrib.x; F.y = F.y + contrib.y; F.z = F.z + contrib.z;
-					tp.q.F[slot] = F;
 				}
+				tp.F[__float_as_uint(Lpre.w)] = F;
+			} else if (!blocked) {
+				// KILL: the hit of the (speculative) extension ray is void; else shade(depth + 1) adds the contribution
+				tp.rec.V[slot] = (uint8_t)((fl & TUTU_KEY_KILL) ? TUTU_V_KILLED : TUTU_V_ADD);
 			}
 			cur = TUTU_TRAV_IDLE;
 		}

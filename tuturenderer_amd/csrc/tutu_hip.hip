@@ -83,20 +83,35 @@ struct TutuCtx {
 	bool textured = false;     // the scene has textured objects -> k_shade<.., EXT = true>
 	bool has_spheres = false;  // the scene has sphere leaves    -> k_trace<.., SPH = true>, k_shade<.., EXT = true>
 	int opt_sets = 0;          // tutu_hip_set_option("sets"): passes in flight, 0 = default
-	bool no_class_sort = true; // shade walks the unsorted list of continuing slots (TUTU_CLASS_SORT=1: per-class launches over class-sorted lists)
+	// Tuning / measuring knobs.  Read ONCE, at tutu_hip_create, from the TUTU_* environment variables, range-checked
+	// there (a value outside its range fails the create with TUTU_E_INVALID instead of reaching a kernel: inner_steps = 0
+	// would keep every traversal wave spinning, a zero block count would launch an empty grid); later changes go
+	// through tutu_hip_set_option, same checks; tutu_hip_get_option reports the effective values (bench.py echoes them).
+	struct Knobs {
+		int sets = 4;             // TUTU_SETS           passes in flight                         [1, 4]
+		int one_set = 0;          // TUTU_ONE_SET        profiling aid: one work set              {0, 1}
+		int shade_bpc = 8;        // TUTU_SHADE_BPC      shade blocks per CU (persistent grid)    [1, 16]
+		int trace_bpc = 0;        // TUTU_TRACE_BPC      traversal blocks per CU, 0 = by LDS use  [0, 8]
+		int refill_min = 16;      // TUTU_REFILL_MIN     idle lanes before a wave refills         [1, 64]
+		int inner_steps = TUTU_INNER_STEPS;  // TUTU_INNER_STEPS node visits per round            [1, 64]
+		int any_near_first = 1;   // TUTU_ANY_NEAR_FIRST any-hit: nearer child first              {0, 1}
+		int util_stats = 0;       // TUTU_UTIL_STATS     phase counters of the traversal kernels  {0, 1}
+	} knobs;
 	int shade_mode_all = SHADE_ANY;  // the kernel of that launch: the scene's only scattering class, or SHADE_ANY
 	DevBuf<float4> d_tri_tex, d_texels, d_tex_desc, d_leaf_boxes;
 	DevBuf<uint8_t> d_tri_class;
-	// work buffers: two sets, so that consecutive passes run on two streams and a memory-bound stage of one pass
-	// overlaps a compute-bound stage of the other
+	// work buffers: up to four sets, so that consecutive passes run on their own streams and a memory-bound stage of
+	// one pass overlaps a compute-bound stage of another
 	struct WorkSet {
-		size_t cap = 0;           // path slots (multiple of TUTU_LIST_TILE)
-		DevBuf<float4> qbuf[11];  // A..H, S0..S2
-		DevBuf<uint8_t> kA, kB;
-		DevBuf<uint32_t> flag_lists;  // [2][cap]: extension-ray slots, shadow-request slots
-		DevBuf<uint32_t> perm;        // [cap]: continuing slots sorted by class
+		size_t cap = 0;            // record slots (multiple of TUTU_LIST_TILE)
+		DevBuf<float4> rec[2][10]; // the two record sets (device_shade.h: Records), fields A B D E G H L S P S2
+		DevBuf<uint8_t> key[2], verdict[2];
+		DevBuf<float4> hitC;       // per list position: the hit of the extension ray
+		DevBuf<uint8_t> hitK;      // per list position: its material class
+		DevBuf<float4> F;          // per home slot: finished radiance
+		DevBuf<uint32_t> lists;    // [2][cap]: continuing records, records with a shadow request
 		DevBuf<uint32_t> tile_counts, tile_offsets;
-		DevBuf<uint32_t> list_meta;   // per depth: flag-list counts [8] | class-list counts [8]
+		DevBuf<uint32_t> list_meta;   // per depth: list counts [2]
 		DevBuf<unsigned long long> part;  // [2 kinds][TUTU_PART_BLOCKS][2] traversal work counters
 		hipEvent_t ev_resolved = nullptr;
 	} ws[TUTU_MAX_SETS];
@@ -111,32 +126,88 @@ struct TutuCtx {
 	size_t ev_used = 0;
 };
 
+
+namespace {
+
+struct KnobDesc {
+	const char* name;  // option name of tutu_hip_set_option / tutu_hip_get_option
+	const char* env;   // environment variable read at create time
+	int TutuCtx::Knobs::*field;
+	int lo, hi;
+};
+const KnobDesc kKnobs[] = {
+    {"sets_default", "TUTU_SETS", &TutuCtx::Knobs::sets, 1, TUTU_MAX_SETS},
+    {"one_set", "TUTU_ONE_SET", &TutuCtx::Knobs::one_set, 0, 1},
+    {"shade_bpc", "TUTU_SHADE_BPC", &TutuCtx::Knobs::shade_bpc, 1, 16},
+    {"trace_bpc", "TUTU_TRACE_BPC", &TutuCtx::Knobs::trace_bpc, 0, 8},
+    {"refill_min", "TUTU_REFILL_MIN", &TutuCtx::Knobs::refill_min, 1, 64},
+    {"inner_steps", "TUTU_INNER_STEPS", &TutuCtx::Knobs::inner_steps, 1, 64},
+    {"any_near_first", "TUTU_ANY_NEAR_FIRST", &TutuCtx::Knobs::any_near_first, 0, 1},
+    {"util_stats", "TUTU_UTIL_STATS", &TutuCtx::Knobs::util_stats, 0, 1},
+};
+
+// strict integer parse: the whole string must be a number inside [lo, hi]
+bool parse_knob(const char* text, int lo, int hi, int* out) {
+	if (!text || !*text) return false;
+	char* end = nullptr;
+	const long v = strtol(text, &end, 10);
+	if (*end != '\0' || v < lo || v > hi) return false;
+	*out = (int)v;
+	return true;
+}
+
+int read_env_knobs(TutuCtx* c) {
+	for (const KnobDesc& k : kKnobs) {
+		const char* e = getenv(k.env);
+		if (!e) continue;
+		int v = 0;
+		// historical spelling: TUTU_ONE_SET / TUTU_UTIL_STATS / TUTU_CLASS_SORT were "set to anything"
+		if (k.lo == 0 && k.hi == 1 && !parse_knob(e, 0, 1, &v) && *e && (k.field == &TutuCtx::Knobs::one_set || k.field == &TutuCtx::Knobs::util_stats)) v = 1;
+		else if (!parse_knob(e, k.lo, k.hi, &v)) {
+			char buf[256];
+			snprintf(buf, sizeof(buf), "%s=%s: expected an integer in [%d, %d]", k.env, e, k.lo, k.hi);
+			g_last_error = buf;
+			return TUTU_E_INVALID;
+		}
+		c->knobs.*(k.field) = v;
+	}
+	return TUTU_OK;
+}
+
+}  // namespace
+
 namespace {
 
 typedef TutuCtx::WorkSet WorkSet;
 
-Queue queue_of(WorkSet& w) {
-	Queue q;
-	q.A = w.qbuf[0].p; q.B = w.qbuf[1].p; q.C = w.qbuf[2].p; q.D = w.qbuf[3].p;
-	q.E = w.qbuf[4].p; q.F = w.qbuf[5].p; q.G = w.qbuf[6].p; q.H = w.qbuf[7].p;
-	q.S0 = w.qbuf[8].p; q.S1 = w.qbuf[9].p; q.S2 = w.qbuf[10].p;
-	return q;
+Records records_of(WorkSet& w, int which) {
+	Records r;
+	DevBuf<float4>* f = w.rec[which];
+	r.A = f[0].p; r.B = f[1].p; r.D = f[2].p; r.E = f[3].p; r.G = f[4].p;
+	r.H = f[5].p; r.L = f[6].p; r.S = f[7].p; r.P = f[8].p; r.S2 = f[9].p;
+	r.key = w.key[which].p;
+	r.V = w.verdict[which].p;
+	return r;
 }
 
-#define TUTU_META_STRIDE 32  // uint32 per depth in list_meta
+#define TUTU_META_STRIDE 8  // uint32 per depth in list_meta
 
 int ensure_set(WorkSet& w, size_t want_slots) {
 	int rc;
 	const size_t cap = (want_slots + TUTU_LIST_TILE - 1) / TUTU_LIST_TILE * TUTU_LIST_TILE;
 	if (cap > w.cap) {
-		for (int f = 0; f < 11; f++)
-			if ((rc = w.qbuf[f].ensure(cap)) != TUTU_OK) return rc;
-		if ((rc = w.kA.ensure(cap)) != TUTU_OK) return rc;
-		if ((rc = w.kB.ensure(cap)) != TUTU_OK) return rc;
-		if ((rc = w.flag_lists.ensure(2 * cap)) != TUTU_OK) return rc;
-		if ((rc = w.perm.ensure(cap)) != TUTU_OK) return rc;
-		if ((rc = w.tile_counts.ensure(8 * (cap / TUTU_LIST_TILE))) != TUTU_OK) return rc;
-		if ((rc = w.tile_offsets.ensure(8 * (cap / TUTU_LIST_TILE))) != TUTU_OK) return rc;
+		for (int k = 0; k < 2; k++) {
+			for (int f = 0; f < 10; f++)
+				if ((rc = w.rec[k][f].ensure(cap)) != TUTU_OK) return rc;
+			if ((rc = w.key[k].ensure(cap)) != TUTU_OK) return rc;
+			if ((rc = w.verdict[k].ensure(cap)) != TUTU_OK) return rc;
+		}
+		if ((rc = w.hitC.ensure(cap)) != TUTU_OK) return rc;
+		if ((rc = w.hitK.ensure(cap)) != TUTU_OK) return rc;
+		if ((rc = w.F.ensure(cap)) != TUTU_OK) return rc;
+		if ((rc = w.lists.ensure(2 * cap)) != TUTU_OK) return rc;
+		if ((rc = w.tile_counts.ensure(2 * (cap / TUTU_LIST_TILE))) != TUTU_OK) return rc;
+		if ((rc = w.tile_offsets.ensure(2 * (cap / TUTU_LIST_TILE))) != TUTU_OK) return rc;
 		w.cap = cap;
 	}
 	if ((rc = w.list_meta.ensure(TUTU_META_STRIDE * (TUTU_MAX_DEPTH + 3))) != TUTU_OK) return rc;
@@ -206,26 +277,25 @@ int persistent_grid(size_t upper_items, int n_cu, int blocks_per_cu) {
 	return (int)std::min(blocks, maxb);
 }
 
-// count -> scan -> scatter: stable index lists from the per-slot key bytes (device_lists.h)
-template <int MODE>
-int build_lists(TutuCtx* c, WorkSet& w, hipStream_t s, uint32_t n_slots_padded, uint32_t* meta_count, uint32_t* out,
-                unsigned long long* stat_a, unsigned long long* stat_b, uint32_t stamp) {
+// count -> scan -> scatter: stable index lists from the key bytes of a record set (device_lists.h)
+int build_lists(TutuCtx* c, WorkSet& w, hipStream_t s, const uint8_t* key, uint32_t n_slots_padded, const uint32_t* n_prev, uint32_t range_const,
+                uint32_t* meta_count, unsigned long long* stat_a, unsigned long long* stat_b) {
 	ListParams lp;
-	lp.stamp = stamp & 7u;
-	lp.kA = w.kA.p;
-	lp.kB = w.kB.p;
+	lp.key = key;
 	lp.n_slots = n_slots_padded;
 	lp.n_tiles = n_slots_padded / TUTU_LIST_TILE;
+	lp.n_prev = n_prev;
+	lp.range_const = range_const;
 	lp.tile_counts = w.tile_counts.p;
 	lp.tile_offsets = w.tile_offsets.p;
 	lp.list_count = meta_count;
-	lp.out = out;
-	lp.flags_stride = (uint32_t)w.cap;
+	lp.out = w.lists.p;
+	lp.stride = (uint32_t)w.cap;
 	lp.stat_a = stat_a;
 	lp.stat_b = stat_b;
-	TIMED(EV_OTHER, k_list_count<MODE><<<dim3(lp.n_tiles), dim3(256), 0, s>>>(lp));
-	TIMED(EV_OTHER, k_list_scan<MODE><<<dim3(MODE == LIST_FLAGS ? 2 : TUTU_NCLASS), dim3(1024), 0, s>>>(lp));
-	TIMED(EV_OTHER, k_list_scatter<MODE><<<dim3(lp.n_tiles), dim3(256), 0, s>>>(lp));
+	TIMED(EV_OTHER, k_list_count<<<dim3(lp.n_tiles), dim3(256), 0, s>>>(lp));
+	TIMED(EV_OTHER, k_list_scan<<<dim3(2), dim3(1024), 0, s>>>(lp));
+	TIMED(EV_OTHER, k_list_scatter<<<dim3(lp.n_tiles), dim3(256), 0, s>>>(lp));
 	return TUTU_OK;
 }
 
@@ -236,14 +306,14 @@ int launch_shade_tab(TutuCtx* c, hipStream_t s, dim3 grid, const PassParams& pp)
 		switch (c->shade_tab) {
 		case 2: TIMED(ev, k_shade<MODE, 2, true><<<grid, dim3(256), c->shade_lds_bytes, s>>>(pp)); break;
 		case 1: TIMED(ev, k_shade<MODE, 1, true><<<grid, dim3(256), c->shade_lds_bytes, s>>>(pp)); break;
-		default: TIMED(ev, k_shade<MODE, 0, true><<<grid, dim3(256), 0, s>>>(pp)); break;
+		default: TIMED(ev, k_shade<MODE, 0, true><<<grid, dim3(256), c->shade_lds_bytes, s>>>(pp)); break;
 		}
 		return TUTU_OK;
 	}
 	switch (c->shade_tab) {
 	case 2: TIMED(ev, k_shade<MODE, 2, false><<<grid, dim3(256), c->shade_lds_bytes, s>>>(pp)); break;
 	case 1: TIMED(ev, k_shade<MODE, 1, false><<<grid, dim3(256), c->shade_lds_bytes, s>>>(pp)); break;
-	default: TIMED(ev, k_shade<MODE, 0, false><<<grid, dim3(256), 0, s>>>(pp)); break;
+	default: TIMED(ev, k_shade<MODE, 0, false><<<grid, dim3(256), c->shade_lds_bytes, s>>>(pp)); break;
 	}
 	return TUTU_OK;
 }
@@ -260,12 +330,14 @@ int launch_shade(TutuCtx* c, hipStream_t s, int mode, dim3 grid, const PassParam
 }
 
 // One wavefront pass over `npix` work items x `nsamp` samples (or, with smp_list, one sample per item).
+// Stage d: shade(d) reads record set (d-1)&1 through stage d-1's list of continuing records and writes set d&1,
+// compacted per 64-record chunk; lists; trace_closest; trace_any.  The slots in use shrink with every stage.
 int run_pass(TutuCtx* c, WorkSet& w, hipStream_t s, const TutuCameraFrame* cam, uint32_t key0, uint32_t key1, int npix, int s0, int nsamp,
              const uint32_t* d_smp_list, uint32_t* n_trace_launches) {
-	const size_t npaths = (size_t)npix * (size_t)nsamp;
-	const uint32_t n_pad = (uint32_t)((npaths + TUTU_LIST_TILE - 1) / TUTU_LIST_TILE * TUTU_LIST_TILE);
-	// padding keys must read "nothing here"
-	if (n_pad > npaths) HIP_TRY(hipMemsetAsync(w.kA.p + npaths, 0, n_pad - npaths, s));
+	const uint32_t blocks_x = (uint32_t)((npix + 255) / 256);
+	const size_t region0 = (size_t)blocks_x * 256u * (size_t)nsamp;  // slots stage 0 may write: one 64-slot chunk per wave
+	const uint32_t n_pad = (uint32_t)((region0 + TUTU_LIST_TILE - 1) / TUTU_LIST_TILE * TUTU_LIST_TILE);
+	if (n_pad > w.cap) return TUTU_E_INVALID;
 
 	PassParams pp;
 	memset(&pp, 0, sizeof(pp));
@@ -274,108 +346,62 @@ int run_pass(TutuCtx* c, WorkSet& w, hipStream_t s, const TutuCameraFrame* cam, 
 	pp.key1 = key1;
 	pp.npix = npix;
 	pp.s0 = s0;
-	pp.n_slots = (uint32_t)npaths;
 	pp.prim_dir = c->prim_dir.p;
 	pp.prim_hit = c->prim_hit.p;
 	pp.smp_list = d_smp_list;
 	memcpy(pp.eye, cam->eye, sizeof(pp.eye));
-	pp.q = queue_of(w);
-	pp.kA = w.kA.p;
-	pp.perm = w.perm.p;
-
-	static const int shade_bpc = getenv("TUTU_SHADE_BPC") ? atoi(getenv("TUTU_SHADE_BPC")) : 8;
-	static const int trace_bpc_env = getenv("TUTU_TRACE_BPC") ? atoi(getenv("TUTU_TRACE_BPC")) : 0;
-	const int shade_grid = persistent_grid(npaths, c->n_cu, shade_bpc);  // persistent blocks: the table staging is paid once per block
-	const int trace_grid = persistent_grid(npaths, c->n_cu, trace_bpc_env > 0 ? std::min(trace_bpc_env, c->trace_blocks_per_cu) : c->trace_blocks_per_cu);
-	int rc = TUTU_OK;
+	pp.hitC = w.hitC.p;
+	pp.hitK = w.hitK.p;
+	pp.F = w.F.p;
+	pp.list = w.lists.p;
 	pp.n_mats = (int)c->hs.mats.size();
+
+	const size_t npaths = (size_t)npix * (size_t)nsamp;
+	const int shade_grid = persistent_grid(npaths, c->n_cu, c->knobs.shade_bpc);  // persistent blocks: the table staging is paid once per block
+	const int trace_grid = persistent_grid(npaths, c->n_cu, c->knobs.trace_bpc > 0 ? std::min(c->knobs.trace_bpc, c->trace_blocks_per_cu) : c->trace_blocks_per_cu);
+	int rc = TUTU_OK;
 	for (int d = 0; d <= TUTU_MAX_DEPTH + 1; d++) {
 		pp.depth = d;
-		uint32_t* meta = w.list_meta.p + (size_t)TUTU_META_STRIDE * d;  // [0..8) flag counts, [8..16) flag bases, [16..24) class counts, [24..32) class bases
+		uint32_t* meta = w.list_meta.p + (size_t)TUTU_META_STRIDE * d;  // [0] continuing records, [1] shadow requests of this stage
+		const uint32_t* prev_count = d > 0 ? w.list_meta.p + (size_t)TUTU_META_STRIDE * (d - 1) : nullptr;
+		pp.out = records_of(w, d & 1);
+		pp.in = records_of(w, (d & 1) ^ 1);
+		pp.n_in = prev_count;
+		const bool last = d == TUTU_MAX_DEPTH + 1;
 		if (d == 0) {
-			dim3 g((unsigned)((npix + 255) / 256), (unsigned)nsamp, 1);
+			dim3 g(blocks_x, (unsigned)nsamp, 1);
 			rc = launch_shade(c, s, SHADE_FIRST, g, pp);
-			if (rc != TUTU_OK) return rc;
 		} else {
-			// one launch per material class group that exists in the scene (sort-by-material pipeline); the classes
-			// that only connect and end (UNLIT, emissive hit, miss) ride along with the first launch
-			uint32_t* pm = w.list_meta.p + (size_t)TUTU_META_STRIDE * (d - 1);
-			pp.cls_count = pm + 16;
-			const bool last = d == TUTU_MAX_DEPTH + 1;
-			if (c->no_class_sort) {
-				// No sort by material: the launch walks the plain (slot-ordered) list of continuing slots of the previous
-				// stage and every lane reads its class from kB.  Records are then read and written in slot order by
-				// ONE launch instead of being split into per-class groups -- the shade stage is bound by its record
-				// traffic, and the sorted groups made that traffic sparser (Cornell: 109 -> 94 ms per frame, and the
-				// class lists' count / scan / scatter launches go away: 26 -> 15 ms).
-				pp.mixed = 1;
-				pp.mixed_count = pm + 0;
-				pp.perm = w.flag_lists.p;
-				pp.kB = w.kB.p;
-				const uint32_t terminal = (1u << TUTU_UNLIT) | (1u << TUTU_CLASS_EMISSIVE) | (1u << TUTU_CLASS_MISS);
-				// the last stage only connects vertex MAX_DEPTH (classes emissive / miss / UNLIT can still add radiance)
-				pp.class_mask = last ? terminal : 0xFFu;
-				const int mode = last ? SHADE_TERMINAL : c->shade_mode_all;
-				rc = launch_shade(c, s, mode, dim3(shade_grid), pp);
-				if (rc != TUTU_OK) return rc;
-				if (last) break;
-				goto shaded;
-			}
-			const uint32_t types = c->type_mask;
-			uint32_t extra = (1u << TUTU_UNLIT) | (1u << TUTU_CLASS_EMISSIVE) | (1u << TUTU_CLASS_MISS);
-			const struct { int mode; uint32_t mask; } groups[4] = {
-			    {SHADE_LAMBERT, 1u << TUTU_LAMBERTIAN},
-			    {SHADE_MIRROR, 1u << TUTU_PERFECT_REFLECTIVE},
-			    {SHADE_REFRACT, (1u << TUTU_PERFECT_REFRACTIVE) | (1u << TUTU_MICROFACET_T)},
-			    {SHADE_GGXR, 1u << TUTU_MICROFACET_R}};
-			// the last stage only connects vertex MAX_DEPTH: nothing but a BSDF ray that landed on a light (or the
-			// background behind a refractive vertex) can still add radiance -> classes emissive / miss only
-			for (int gi = 0; gi < 4 && !last; gi++) {
-				if (!(types & groups[gi].mask)) continue;
-				pp.class_mask = groups[gi].mask | extra;
-				extra = 0;
-				rc = launch_shade(c, s, groups[gi].mode, dim3(shade_grid), pp);
-				if (rc != TUTU_OK) return rc;
-			}
-			if (extra) {  // a scene without any scattering material
-				pp.class_mask = extra;
-				rc = launch_shade(c, s, SHADE_TERMINAL, dim3(shade_grid), pp);
-				if (rc != TUTU_OK) return rc;
-			}
+			// No sort by material: one launch walks the slot-ordered list of continuing records and every lane reads the
+			// class of its hit.  The last stage only connects vertex MAX_DEPTH and finishes the samples.
+			rc = launch_shade(c, s, last ? SHADE_TERMINAL : c->shade_mode_all, dim3(shade_grid), pp);
 		}
-	shaded:
-		if (d == TUTU_MAX_DEPTH + 1) break;  // the last shade only connects; nothing continues
-		rc = build_lists<LIST_FLAGS>(c, w, s, n_pad, meta, w.flag_lists.p, &c->totals.p->closest_rays, &c->totals.p->shadow_rays, (uint32_t)d);
+		if (rc != TUTU_OK) return rc;
+		if (last) break;  // nothing continues
+		rc = build_lists(c, w, s, pp.out.key, n_pad, prev_count, (uint32_t)region0, meta, &c->totals.p->closest_rays, &c->totals.p->shadow_rays);
 		if (rc != TUTU_OK) return rc;
 		TraceParams tp;
 		tp.sc = c->sc;
-		tp.q = pp.q;
-		tp.list = w.flag_lists.p;
+		tp.rec = pp.out;
+		tp.list = w.lists.p;
 		tp.n_ptr = meta + 0;
-		tp.kA = w.kA.p;
-		tp.kB = w.kB.p;
+		tp.hitC = w.hitC.p;
+		tp.hitK = w.hitK.p;
+		tp.F = w.F.p;
 		tp.tri_class = c->d_tri_class.p;
 		tp.stack_entries = c->stack_entries;
-		static const int refill_min = getenv("TUTU_REFILL_MIN") ? atoi(getenv("TUTU_REFILL_MIN")) : 16;
-		tp.refill_min = refill_min;
-		static const int inner_steps = getenv("TUTU_INNER_STEPS") ? atoi(getenv("TUTU_INNER_STEPS")) : TUTU_INNER_STEPS;
-		tp.inner_steps = inner_steps;
-		static const int any_nf = getenv("TUTU_ANY_NEAR_FIRST") ? atoi(getenv("TUTU_ANY_NEAR_FIRST")) : 1;
-		tp.any_near_first = any_nf;
+		tp.refill_min = c->knobs.refill_min;
+		tp.inner_steps = c->knobs.inner_steps;
+		tp.any_near_first = c->knobs.any_near_first;
 		tp.part = w.part.p;
-		static const bool util_stats = getenv("TUTU_UTIL_STATS") != nullptr;
-		tp.util = util_stats ? w.part.p + 4 * TUTU_PART_BLOCKS : nullptr;
+		tp.util = c->knobs.util_stats ? w.part.p + 4 * TUTU_PART_BLOCKS : nullptr;
 		TIMED(EV_TRACE_CLOSEST, launch_trace<false>(c, s, trace_grid, tp));
 		(*n_trace_launches)++;
-		tp.list = w.flag_lists.p + w.cap;
+		tp.list = w.lists.p + w.cap;
 		tp.n_ptr = meta + 1;
 		tp.part = w.part.p + 2 * TUTU_PART_BLOCKS;
 		if (tp.util) tp.util += 4;
 		TIMED(EV_TRACE_ANY, launch_trace<true>(c, s, trace_grid, tp));
-		if (!c->no_class_sort) {
-			rc = build_lists<LIST_CLASS>(c, w, s, n_pad, meta + 16, w.perm.p, nullptr, nullptr, (uint32_t)d);
-			if (rc != TUTU_OK) return rc;
-		}
 	}
 	return TUTU_OK;
 }
@@ -430,7 +456,7 @@ int collect_stats(TutuCtx* c, hipStream_t s, TutuStats* st, uint64_t samples, ui
 			}
 			for (int j = 0; j < 8; j++) util[j] += h[4 * TUTU_PART_BLOCKS + j];
 		}
-		if (getenv("TUTU_UTIL_STATS"))
+		if (c->knobs.util_stats)
 			fprintf(stderr, "[tutu util] closest: lanes/node-step %.1f lanes/leaf-step %.1f node-steps/outer %.2f leaf-steps/outer %.2f | any: %.1f %.1f %.2f %.2f\n",
 			        util[0] ? (double)st->nodes_closest / util[0] : 0.0, util[1] ? (double)st->leaves_closest / util[1] : 0.0,
 			        util[2] ? (double)util[0] / util[2] : 0.0, util[2] ? (double)util[1] / util[2] : 0.0,
@@ -484,8 +510,7 @@ int render_impl(TutuCtx* c, const TutuCameraFrame* cam, const TutuRenderParams* 
 	// (measured on the Cornell box, 512 spp: 2 sets x 8 Mi 1518 Msamples/s, 3 x 8 Mi 1619, 4 x 8 Mi 1645; later, on a
 	// faster box: 4 x 4 Mi 1545, 4 x 8 Mi 1725, 4 x 12 Mi 1753, 4 x 16 Mi 1714; 5, 6 or 8 sets are slower than 4).
 	const int64_t max_paths = rp->max_paths > 0 ? rp->max_paths : ((int64_t)48 << 20);
-	static const int sets_env = getenv("TUTU_SETS") ? atoi(getenv("TUTU_SETS")) : 4;
-	const int want_sets = std::max(1, std::min(c->opt_sets > 0 ? c->opt_sets : sets_env, TUTU_MAX_SETS));
+	const int want_sets = std::max(1, std::min(c->opt_sets > 0 ? c->opt_sets : c->knobs.sets, TUTU_MAX_SETS));
 	// the pass size does not depend on how many passes are in flight (TUTU_SETS / tutu_hip_set_option "sets" are
 	// measuring aids): max_paths is always split into TUTU_MAX_SETS passes' worth of slots
 	int spp_pass = rp->spp_per_pass > 0 ? rp->spp_per_pass : (int)std::max<int64_t>(1, (max_paths / TUTU_MAX_SETS) / npix);
@@ -498,9 +523,8 @@ int render_impl(TutuCtx* c, const TutuCameraFrame* cam, const TutuRenderParams* 
 		spp_pass = (rp->spp + n_passes - 1) / n_passes;
 		n_passes = (rp->spp + spp_pass - 1) / spp_pass;
 	}
-	static const bool one_set = getenv("TUTU_ONE_SET") != nullptr;  // profiling aid: no overlap, clean per-kernel times
-	const int n_sets = one_set ? 1 : std::min(want_sets, n_passes);
-	const size_t cap = (size_t)npix * (size_t)spp_pass;
+	const int n_sets = c->knobs.one_set ? 1 : std::min(want_sets, n_passes);  // one_set: profiling aid, no overlap, clean per-kernel times
+	const size_t cap = (size_t)((npix + 255) / 256 * 256) * (size_t)spp_pass;  // stage 0 fills one 64-slot chunk per wave
 	int rc = ensure_work(c, cap, (size_t)npix, n_sets);
 	if (rc != TUTU_OK) return rc;
 	const int32_t* d_pixels = nullptr;
@@ -533,7 +557,7 @@ int render_impl(TutuCtx* c, const TutuCameraFrame* cam, const TutuRenderParams* 
 		if (i > 0 && n_sets > 1) HIP_TRY(hipStreamWaitEvent(sk, c->ws[(k + n_sets - 1) % n_sets].ev_resolved, 0));
 		{
 			hipStream_t s = sk;  // TIMED records on `s`
-			TIMED(EV_OTHER, k_resolve<<<dim3((npix + 255) / 256), dim3(256), 0, s>>>(w.qbuf[5].p, c->accum.p, npix, ns));
+			TIMED(EV_OTHER, k_resolve<<<dim3((npix + 255) / 256), dim3(256), 0, s>>>(w.F.p, c->accum.p, npix, ns));
 		}
 		if (n_sets > 1) HIP_TRY(hipEventRecord(w.ev_resolved, sk));
 		passes++;
@@ -544,7 +568,12 @@ int render_impl(TutuCtx* c, const TutuCameraFrame* cam, const TutuRenderParams* 
 	}
 	const float spp_inv = 1.f / rp->spp;  // SPP_inv, global.hpp:20
 	TIMED(EV_OTHER, k_finalize<<<dim3((npix + 255) / 256), dim3(256), 0, s>>>(c->accum.p, d_out, npix, spp_inv));
-	return collect_stats(c, s, st, (uint64_t)npix * (uint64_t)rp->spp, passes, trace_launches);
+	rc = collect_stats(c, s, st, (uint64_t)npix * (uint64_t)rp->spp, passes, trace_launches);
+	if (rc == TUTU_OK && st) {
+		st->spp_per_pass = (uint32_t)spp_pass;
+		st->n_sets = (uint32_t)n_sets;
+	}
+	return rc;
 }
 
 template <typename T>
@@ -582,7 +611,8 @@ int tutu_hip_create(const TutuSceneDesc* scene, int device, TutuCtx** out) {
 	if (rc != TUTU_OK) return rc;
 	if (device < 0 || device >= ndev) return TUTU_E_NO_DEVICE;
 	TutuCtx* c = new TutuCtx();
-	rc = build_host_scene(scene, c->hs);
+	rc = read_env_knobs(c);
+	if (rc == TUTU_OK) rc = build_host_scene(scene, c->hs);
 	if (rc != TUTU_OK) {
 		delete c;
 		return rc;
@@ -654,6 +684,7 @@ int tutu_hip_create(const TutuSceneDesc* scene, int device, TutuCtx** out) {
 			c->shade_lds_bytes = 0;
 		}
 		if (c->shade_lds_bytes == 0 && c->shade_tab != 0) c->shade_tab = 0;
+		c->shade_lds_bytes += TUTU_STAGE_BYTES_PER_BLOCK;  // behind the tables: the block's output staging area
 	}
 	c->type_mask = 0;
 	for (const GpuMaterial& m : c->hs.mats)
@@ -668,7 +699,6 @@ int tutu_hip_create(const TutuSceneDesc* scene, int device, TutuCtx** out) {
 				groups++;
 				only = group_modes[g];
 			}
-		c->no_class_sort = !getenv("TUTU_CLASS_SORT");
 		c->shade_mode_all = groups <= 1 ? only : SHADE_ANY;  // one class: its specialised kernel; several: the generic one
 	}
 	// per-lane traversal stack: at most one push per inner node on a root-to-leaf path.  When nodes + triangles are
@@ -698,8 +728,12 @@ int tutu_hip_destroy(TutuCtx* c) {
 		if (c->extra_streams[k]) (void)hipStreamSynchronize(c->extra_streams[k]);
 	for (int k = 0; k < TUTU_MAX_SETS; k++) {
 		TutuCtx::WorkSet& w = c->ws[k];
-		for (int f = 0; f < 11; f++) w.qbuf[f].release();
-		w.kA.release(); w.kB.release(); w.flag_lists.release(); w.perm.release(); w.tile_counts.release(); w.tile_offsets.release();
+		for (int k2 = 0; k2 < 2; k2++) {
+			for (int f = 0; f < 10; f++) w.rec[k2][f].release();
+			w.key[k2].release();
+			w.verdict[k2].release();
+		}
+		w.hitC.release(); w.hitK.release(); w.F.release(); w.lists.release(); w.tile_counts.release(); w.tile_offsets.release();
 		w.list_meta.release(); w.part.release();
 		if (w.ev_resolved) (void)hipEventDestroy(w.ev_resolved);
 	}
@@ -721,6 +755,38 @@ int tutu_hip_set_option(TutuCtx* c, const char* name, int value) {
 		c->opt_sets = value;
 		return TUTU_OK;
 	}
+	for (const KnobDesc& k : kKnobs)
+		if (strcmp(name, k.name) == 0) {
+			if (value < k.lo || value > k.hi) return TUTU_E_INVALID;
+			c->knobs.*(k.field) = value;
+			return TUTU_OK;
+		}
+	return TUTU_E_INVALID;
+}
+
+int tutu_hip_get_option(TutuCtx* c, const char* name, int* value) {
+	if (!c || !name || !value) return TUTU_E_INVALID;
+	if (strcmp(name, "sets") == 0) {
+		*value = c->opt_sets > 0 ? c->opt_sets : c->knobs.sets;
+		return TUTU_OK;
+	}
+	if (strcmp(name, "sah_tree") == 0) {
+		*value = c->hs.has_fast_tree ? 1 : 0;
+		return TUTU_OK;
+	}
+	if (strcmp(name, "lds_scene") == 0) {
+		*value = c->lds_scene ? 1 : 0;
+		return TUTU_OK;
+	}
+	if (strcmp(name, "shade_tab") == 0) {
+		*value = c->shade_tab;
+		return TUTU_OK;
+	}
+	for (const KnobDesc& k : kKnobs)
+		if (strcmp(name, k.name) == 0) {
+			*value = c->knobs.*(k.field);
+			return TUTU_OK;
+		}
 	return TUTU_E_INVALID;
 }
 
@@ -764,10 +830,10 @@ int tutu_hip_trace_samples(TutuCtx* c, const TutuCameraFrame* cam, uint32_t n, c
 	if (!c || !cam || !pix || !smp || !L3) return TUTU_E_INVALID;
 	if (n == 0) return TUTU_OK;
 	for (uint32_t i = 0; i < n; i++)
-		if (pix[i] >= (uint32_t)(cam->width * cam->height)) return TUTU_E_INVALID;
+		if (pix[i] >= (uint32_t)(cam->width * cam->height) || smp[i] >= (1u << 24)) return TUTU_E_INVALID;  // sample index: 24 bits of the record (as spp in render_impl)
 	HIP_TRY(hipSetDevice(c->device));
 	hipStream_t s = c->stream;
-	int rc = ensure_work(c, n, n, 1);
+	int rc = ensure_work(c, ((size_t)n + 255) / 256 * 256, n, 1);
 	if (rc != TUTU_OK) return rc;
 	if ((rc = c->u32a.ensure(n)) != TUTU_OK) return rc;
 	if ((rc = c->u32b.ensure(n)) != TUTU_OK) return rc;
@@ -781,7 +847,7 @@ int tutu_hip_trace_samples(TutuCtx* c, const TutuCameraFrame* cam, uint32_t n, c
 	if ((rc = launch_primary(c, s, cam, (int)n, nullptr, c->u32a.p, 0, 0, 1)) != TUTU_OK) return rc;
 	uint32_t tl = 0;
 	if ((rc = run_pass(c, c->ws[0], s, cam, key0, key1, (int)n, 0, 1, c->u32b.p, &tl)) != TUTU_OK) return rc;
-	hipLaunchKernelGGL(k_copy_L, dim3((n + 255) / 256), dim3(256), 0, s, c->ws[0].qbuf[5].p, c->out_stage.p, (int)n);
+	hipLaunchKernelGGL(k_copy_L, dim3((n + 255) / 256), dim3(256), 0, s, c->ws[0].F.p, c->out_stage.p, (int)n);
 	HIP_TRY(hipGetLastError());
 	HIP_TRY(hipStreamSynchronize(s));
 	c->ev_used = 0;
@@ -917,16 +983,17 @@ static int run_trace_kernel(TutuCtx* c, uint32_t n, bool any) {
 	TutuCtx::WorkSet& w = c->ws[0];
 	std::vector<uint32_t> iota(n);
 	for (uint32_t i = 0; i < n; i++) iota[i] = i;
-	uint32_t* list = any ? w.flag_lists.p + w.cap : w.flag_lists.p;
+	uint32_t* list = any ? w.lists.p + w.cap : w.lists.p;
 	HIP_TRY(hipMemcpyAsync(list, iota.data(), sizeof(uint32_t) * n, hipMemcpyHostToDevice, s));
 	HIP_TRY(hipMemcpyAsync(w.list_meta.p + (any ? 1 : 0), &n, sizeof(uint32_t), hipMemcpyHostToDevice, s));
 	TraceParams tp;
 	tp.sc = c->sc;
-	tp.q = queue_of(w);
+	tp.rec = records_of(w, 0);
 	tp.list = list;
 	tp.n_ptr = w.list_meta.p + (any ? 1 : 0);
-	tp.kA = w.kA.p;
-	tp.kB = w.kB.p;
+	tp.hitC = w.hitC.p;
+	tp.hitK = w.hitK.p;
+	tp.F = w.F.p;
 	tp.tri_class = c->d_tri_class.p;
 	tp.stack_entries = c->stack_entries;
 	tp.part = nullptr;
@@ -953,11 +1020,12 @@ int tutu_hip_trace_closest(TutuCtx* c, uint32_t n, const float* orig, const floa
 		A[i] = make_float4(orig[3 * (size_t)i], orig[3 * (size_t)i + 1], orig[3 * (size_t)i + 2], 0.f);
 		B[i] = make_float4(dir[3 * (size_t)i], dir[3 * (size_t)i + 1], dir[3 * (size_t)i + 2], 0.f);
 	}
-	HIP_TRY(hipMemcpyAsync(c->ws[0].qbuf[0].p, A.data(), sizeof(float4) * n, hipMemcpyHostToDevice, c->stream));
-	HIP_TRY(hipMemcpyAsync(c->ws[0].qbuf[1].p, B.data(), sizeof(float4) * n, hipMemcpyHostToDevice, c->stream));
+	const Records r = records_of(c->ws[0], 0);
+	HIP_TRY(hipMemcpyAsync(r.A, A.data(), sizeof(float4) * n, hipMemcpyHostToDevice, c->stream));
+	HIP_TRY(hipMemcpyAsync(r.B, B.data(), sizeof(float4) * n, hipMemcpyHostToDevice, c->stream));
 	rc = run_trace_kernel(c, n, false);
 	if (rc != TUTU_OK) return rc;
-	HIP_TRY(hipMemcpy(A.data(), c->ws[0].qbuf[2].p, sizeof(float4) * n, hipMemcpyDeviceToHost));
+	HIP_TRY(hipMemcpy(A.data(), c->ws[0].hitC.p, sizeof(float4) * n, hipMemcpyDeviceToHost));
 	for (uint32_t i = 0; i < n; i++) {
 		int tri;
 		memcpy(&tri, &A[i].w, 4);
@@ -975,25 +1043,24 @@ int tutu_hip_trace_any(TutuCtx* c, uint32_t n, const float* orig, const float* t
 	HIP_TRY(hipSetDevice(c->device));
 	int rc = ensure_work(c, n, 1, 1);
 	if (rc != TUTU_OK) return rc;
-	// a shadow request with contribution (1,0,0): unblocked rays add it to the (zeroed) radiance field
-	std::vector<float4> S0(n), S1(n), S2(n);
+	// plain shadow requests (no KILL, not FINAL): an unblocked ray leaves the verdict TUTU_V_ADD
+	std::vector<float4> A(n), S(n);
 	for (uint32_t i = 0; i < n; i++) {
 		const float* o = orig + 3 * (size_t)i;
 		const float* t = target + 3 * (size_t)i;
-		S0[i] = make_float4(o[0], o[1], o[2], t[0]);
-		S1[i] = make_float4(t[1], t[2], 1.f, 0.f);
-		S2[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+		A[i] = make_float4(o[0], o[1], o[2], 0.f);
+		S[i] = make_float4(t[0], t[1], t[2], 0.f);
 	}
 	hipStream_t s = c->stream;
-	HIP_TRY(hipMemcpyAsync(c->ws[0].qbuf[8].p, S0.data(), sizeof(float4) * n, hipMemcpyHostToDevice, s));
-	HIP_TRY(hipMemcpyAsync(c->ws[0].qbuf[9].p, S1.data(), sizeof(float4) * n, hipMemcpyHostToDevice, s));
-	HIP_TRY(hipMemcpyAsync(c->ws[0].qbuf[10].p, S2.data(), sizeof(float4) * n, hipMemcpyHostToDevice, s));
-	HIP_TRY(hipMemsetAsync(c->ws[0].qbuf[5].p, 0, sizeof(float4) * n, s));
-	HIP_TRY(hipMemsetAsync(c->ws[0].kA.p, 0, n, s));
+	const Records r = records_of(c->ws[0], 0);
+	HIP_TRY(hipMemcpyAsync(r.A, A.data(), sizeof(float4) * n, hipMemcpyHostToDevice, s));
+	HIP_TRY(hipMemcpyAsync(r.S, S.data(), sizeof(float4) * n, hipMemcpyHostToDevice, s));
+	HIP_TRY(hipMemsetAsync(r.key, (int)TUTU_KEY_SHADOW, n, s));
+	HIP_TRY(hipMemsetAsync(r.V, (int)TUTU_V_BLOCKED, n, s));
 	rc = run_trace_kernel(c, n, true);
 	if (rc != TUTU_OK) return rc;
-	HIP_TRY(hipMemcpy(S0.data(), c->ws[0].qbuf[5].p, sizeof(float4) * n, hipMemcpyDeviceToHost));
-	for (uint32_t i = 0; i < n; i++) blocked[i] = S0[i].x == 0.f ? 1 : 0;
+	HIP_TRY(hipMemcpy(blocked, r.V, n, hipMemcpyDeviceToHost));
+	for (uint32_t i = 0; i < n; i++) blocked[i] = blocked[i] == TUTU_V_BLOCKED ? 1 : 0;
 	return TUTU_OK;
 }
 

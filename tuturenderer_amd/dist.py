@@ -47,9 +47,26 @@ class FrameGather:
         self.frame = torch.zeros((H * W, 3), dtype=torch.float32, device=device) if rank == 0 else None
         self.gather_list = [torch.zeros_like(self.piece) for _ in range(world)] if (world > 1 and rank == 0) else None
         self.index = [torch.from_numpy(l.astype(np.int64)).to(device) for l in self.lists] if rank == 0 else None
+        # Ordering contract with tutu_hip_render_device: the library writes `piece` from ITS stream and
+        # returns when that write is complete; what it cannot see is torch-stream work that still READS `piece` (the
+        # gather / index_copy below are enqueued asynchronously).  `consumed` marks the end of that work; the next
+        # render waits for it on the host before the library touches `piece` again.
+        self.consumed = torch.cuda.Event() if device.type == "cuda" else None
+
+    def render(self, ctx, spp, key0, key1, pixels=None, **kw):
+        """ctx.render_device into this rank's piece, ordered after the previous frame's consumers of `piece`"""
+        if self.consumed is not None:
+            self.consumed.synchronize()
+        return ctx.render_device(self.piece.data_ptr(), spp, key0, key1, pixels=self.mine if pixels is None else pixels, **kw)
 
     def assemble(self):
         """the collective (world > 1) + scatter of the pieces into the frame on rank 0"""
+        frame = self._assemble()
+        if self.consumed is not None:
+            self.consumed.record()
+        return frame
+
+    def _assemble(self):
         if self.world > 1:
             import torch.distributed as dist
 
