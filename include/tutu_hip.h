@@ -243,6 +243,25 @@ int tutu_hip_eval_texture(TutuCtx* ctx, int32_t list, int32_t index, uint32_t n,
 int tutu_hip_eval_sample_light(TutuCtx* ctx, uint32_t n, const float* xi3, int32_t* tri, float* pos, float* nrm,
                                float* pdf);
 
+/* Device evaluation of the remaining hot-path functions on arrays, for function-level parity (SURVEY.md 8a rows a10, a11,
+ * a16, a17).  in[k] = the k-th input array, n rows; widths (floats per row) in -> out:
+ *   BBOX            BoundBox::IntersectRay (BoundBox.hpp:55-92)        pmin3 pmax3 o3 d3 -> hit (0/1)
+ *   TRI             Triangle::intersect (Triangle.hpp:23-74)           verts9 normals9 o3 d3 -> hit, t, pos3, Ns3, Ng3 (zeros on a miss)
+ *   NORMALIZED      Vector3f::normalized (Vector.hpp:213-220)          v3 -> 3
+ *   FRESNEL         global.hpp:242-261                                 I3 N3 eta_i eta_t -> 1
+ *   FRESNEL_SCHLICK global.hpp:236-239                                 cos F0_3 -> 3
+ *   REFLECT / REFRACT  getReflectionDir / getRefractionDir (:264-301)  I3 N3 [eta_i eta_t] -> 3
+ *   D / G           D_ndf (:311-324) / G_smf (:334-346)                h3 n3 rough -> 1 / wi3 wo3 n3 rough h3 -> 1
+ *   MIS             getMisWeight (:374-380)                            a b -> 1
+ *   LOCAL2WORLD     SphereLocal2world (:387-410)                       N3 dir3 -> 3
+ *   RNG             the xi stream that replaces getRandomFloat         (pix, smp, key0, key1, first draw) as uint32 -> 8 xi
+ *   PHILOX          Philox4x32-10 block                                (ctr0, ctr1, ctr2, key0, key1) as uint32 -> 4 words as uint32 */
+enum TutuFn {
+	TUTU_FN_BBOX = 0, TUTU_FN_TRI, TUTU_FN_NORMALIZED, TUTU_FN_FRESNEL, TUTU_FN_FRESNEL_SCHLICK, TUTU_FN_REFLECT, TUTU_FN_REFRACT,
+	TUTU_FN_D, TUTU_FN_G, TUTU_FN_MIS, TUTU_FN_LOCAL2WORLD, TUTU_FN_RNG, TUTU_FN_PHILOX, TUTU_FN_COUNT
+};
+int tutu_hip_eval_fn(TutuCtx* ctx, int32_t fn, uint32_t n, const float* const* in, float* out);
+
 /* scene facts */
 int tutu_hip_scene_info(TutuCtx* ctx, TutuBvhInfo* bvh, uint32_t* n_lights);
 
@@ -264,7 +283,7 @@ int tutu_hip_quantise(TutuCtx* ctx, uint32_t n, const float* values, int32_t* le
  *   "sets_default" TUTU_SETS [1,4] | "one_set" TUTU_ONE_SET {0,1} | "shade_bpc" TUTU_SHADE_BPC [1,16] |
  *   "trace_bpc" TUTU_TRACE_BPC [0,8] (0 = from the LDS footprint) | "refill_min" TUTU_REFILL_MIN [1,64] |
  *   "inner_steps" TUTU_INNER_STEPS [1,64] | "any_near_first" TUTU_ANY_NEAR_FIRST {0,1} |
- *   "util_stats" TUTU_UTIL_STATS {0,1} | "class_sort" TUTU_CLASS_SORT {0,1} (create-time only).
+ *   "util_stats" TUTU_UTIL_STATS {0,1}.
  * tutu_hip_get_option reports the effective value of any of them, plus the read-only facts "sah_tree", "lds_scene"
  * and "shade_tab" -- a benchmark line should echo them (bench.py does). */
 int tutu_hip_set_option(TutuCtx* ctx, const char* name, int value);

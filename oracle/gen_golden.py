@@ -106,5 +106,44 @@ def main():
         S.close()
 
 
-if __name__ == "__main__":
+if __name__ == "__main__" and len(sys.argv) == 1:
     main()
+
+
+# ---- BASELINE configs 3 and 4: the synthetic bunny / broom stand-ins.  The scenes are procedural
+# (tuturenderer_amd/scenes.py regenerates them from fixed seeds), so only sample ids and the REFERENCE BUILD's answers are
+# stored: per-sample radiance from its own traceRay, and its closest hits for the samples' primary rays.
+def standin_scenes():
+    return {
+        "bunny": (lambda: scenes.bunny_box(256, 256), 3),
+        "broom": (lambda: scenes.broom_room(320, 180), 4),
+    }
+
+
+def standin_sample_ids(sc, n=4000, seed=5):
+    rng = np.random.default_rng(seed)
+    pix = rng.integers(0, sc["width"] * sc["height"], n).astype(np.uint32)
+    smp = rng.integers(0, 64, n).astype(np.uint32)
+    return pix, smp
+
+
+def main_standins():
+    R = Oracle("reference")
+    for name, (mk, key1) in standin_scenes().items():
+        sc = mk()
+        S = R.scene(sc)
+        pix, smp = standin_sample_ids(sc)
+        L, nd, nc = S.trace_samples(pix, smp, pc.KEY0, key1, stats=True)
+        d = S.raydir((pix % sc["width"]).astype(np.int32), (pix // sc["width"]).astype(np.int32))
+        o = np.repeat(S.camera()[5][None], len(pix), 0)
+        hit, t, tri, *_ = S.closest(o, d)
+        out = {"samples.L": L, "samples.ndraws": nd, "samples.nclosest": nc, "samples.in_crc": pc.checksum(pix, smp),
+               "primary.hit": hit, "primary.t": np.where(hit.astype(bool), t, 0).astype(np.float32), "primary.tri": tri,
+               "scene.crc": pc.checksum(np.ascontiguousarray(sc["verts"], np.float32), np.ascontiguousarray(sc["normals"], np.float32))}
+        np.savez_compressed(os.path.join(GOLD, f"scene_{name}.npz"), **out)
+        print(name, "tris", len(sc["verts"]), "mean L", float(np.nanmean(L)), "closest/sample", float(nc.mean()))
+        S.close()
+
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "standins":
+    main_standins()

@@ -421,33 +421,224 @@ def test_full_size_properties(tr):
     assert np.allclose(c[lit], np.array(scenes.CB_EMISSION, np.float32))
 
 
-@pytest.mark.parametrize("name,n", [("bunny", 600), ("broom", 300)])
-def test_stand_in_scenes_per_sample_parity(tr, port, name, n):
+@pytest.mark.parametrize("name", ["bunny", "broom"])
+def test_stand_in_scenes_per_sample_parity(tr, name):
     """BASELINE configs 3 and 4 (synthetic stand-ins, 82 k / 48 k triangles, BVH depth 17 / 16, rough glass /
-    rough metal): these go through the HBM-resident traversal path.  Matched-seed radiance of random samples
-    against the CPU restatement."""
-    from tuturenderer_amd import scenes
+    rough metal): these go through the HBM-resident traversal path.  Matched-seed radiance of 4000 random samples and
+    the closest hits of their primary rays against what the REFERENCE BUILD answered (tests/golden/scene_bunny.npz,
+    scene_broom.npz, written by `oracle/gen_golden.py standins`), at the bar of the other scenes."""
+    from oracle.gen_golden import standin_sample_ids, standin_scenes
 
-    sc = scenes.bunny_box(256, 256) if name == "bunny" else scenes.broom_room(320, 180)
-    key1 = 3 if name == "bunny" else 4
-    rng = np.random.default_rng(5)
-    pix = rng.integers(0, sc["width"] * sc["height"], n).astype(np.uint32)
-    smp = rng.integers(0, 64, n).astype(np.uint32)
+    mk, key1 = standin_scenes()[name]
+    sc = mk()
+    z = np.load(golden_path(f"scene_{name}.npz"))
+    assert pc.checksum(np.ascontiguousarray(sc["verts"], np.float32), np.ascontiguousarray(sc["normals"], np.float32)) == z["scene.crc"], \
+        "the procedural scene is not the one the golden vectors were made for"
+    pix, smp = standin_sample_ids(sc)
+    assert pc.checksum(pix, smp) == z["samples.in_crc"]
     with tr.Context(sc) as ctx:
         info = ctx.info()
         L = ctx.trace_samples(pix, smp, pc.KEY0, key1)
-        # kernel-level: the same primary rays through the closest-hit entry point, bit-exact against the oracle
-        S = port.scene(sc)
-        d = S.raydir((pix % sc["width"]).astype(np.int32), (pix // sc["width"]).astype(np.int32))
-        o = np.repeat(S.camera()[5][None], n, 0)
-        hits = ctx.trace_closest(o, d)
-    hit, t, tri, *_ = S.closest(o, d)
-    assert count_diff(hits["tri"], tri) == 0 and count_diff(np.where(tri >= 0, hits["t"], 0), np.where(tri >= 0, t, 0)) == 0
-    want = S.trace_samples(pix, smp, pc.KEY0, key1)
-    S.close()
-    err = np.abs(L - want).max(1)
-    scale = np.maximum(np.abs(want).max(1), 1e-3)
-    bad = ~((err <= 1e-4 * scale + 1e-6) | (np.isnan(L).any(1) & np.isnan(want).any(1)))
-    print(f"{name}: {info} diverged {int(bad.sum())}/{n}")
+        cam = tr.camera_frame_array(sc)
+        x, y = (pix % sc["width"]).astype(np.float32), (pix // sc["width"]).astype(np.float32)
+        p = cam[0] + x[:, None] * cam[1] + y[:, None] * cam[2] + cam[4] + cam[4]  # PathTracing.hpp:503 [sic]
+        d = p - cam[5]
+        d = (d * (np.float32(1) / np.sqrt((d * d).sum(1, dtype=np.float32), dtype=np.float32))[:, None]).astype(np.float32)
+        hits = ctx.trace_closest(np.repeat(cam[5][None], len(pix), 0), d)
+    # kernel level: same object, same t bits as the reference's getIntersection (the ray directions above may differ from the
+    # reference's by an ulp in the normalisation, so a handful of edge rays are allowed to land on a neighbour)
+    tri_bad = (hits["tri"] != z["primary.tri"]).mean()
+    t_bad = (np.where(hits["tri"] >= 0, hits["t"], 0).astype(np.float32) != z["primary.t"]).mean()
+    want = z["samples.L"]
+    nan_g, nan_w = np.isnan(L).any(1), np.isnan(want).any(1)
+    fin = ~(nan_g | nan_w)
+    err = np.abs(L[fin] - want[fin]).max(1)
+    scale = np.maximum(np.abs(want[fin]).max(1), 1e-3)
+    bad = 1.0 - (err <= 1e-4 * scale + 1e-6).mean()
+    print(f"{name}: {info} diverged samples {bad:.4f}, primary tri mismatches {tri_bad:.5f}, t mismatches {t_bad:.5f}")
     assert info["depth"] >= 15
-    assert bad.mean() < 0.02
+    assert (nan_g != nan_w).mean() < 1e-3
+    assert tri_bad < 2e-3 and t_bad < 1e-2
+    assert bad < 5e-3, bad
+    assert abs(L[fin].mean() - want[fin].mean()) < 2e-2 * max(want[fin].mean(), 1e-3)
+
+
+# ------------------------------------------------------------------------------------------------------------
+# function-level parity of the rows that were green only by implication: a10 slab test, a11 triangle test, a16 math
+# helpers, a17 RNG -- the DEVICE functions, through tutu_hip_eval_fn, against the reference build's golden vectors
+@pytest.fixture(scope="module")
+def fn_ctx(tr):
+    from tuturenderer_amd import scenes
+
+    with tr.Context(scenes.cornell_box(8, 8)) as ctx:
+        yield ctx
+
+
+def test_device_slab_test_bit_exact(fn_ctx):
+    """BoundBox::IntersectRay on the device: 20 000 boxes / rays incl. flat boxes, zero and negative-zero direction
+    components, origins on slab planes (NaN products fall through the ?: selects exactly as in the reference)"""
+    z = np.load(golden_path("functions.npz"))
+    pmin, pmax, o, d = pc.bbox_inputs()
+    assert pc.checksum(pmin, pmax, o, d) == z["bbox.in_crc"]
+    got = fn_ctx.eval_fn("bbox", pmin, pmax, o, d)[:, 0]
+    assert count_diff(got.astype(np.uint8), z["bbox.hit"]) == 0
+    assert 0.05 < got.mean() < 0.9
+
+
+def test_device_triangle_test(fn_ctx):
+    """Triangle::intersect on the device (host-hoisted E1, E2, normal): hit decisions and t bit-exact; pos, Ns, Ng bit-exact
+    on the hits (+ - * / sqrt only)"""
+    z = np.load(golden_path("functions.npz"))
+    verts, normals, o, d = pc.tri_inputs()
+    assert pc.checksum(verts, normals, o, d) == z["tri.in_crc"]
+    got = fn_ctx.eval_fn("tri", verts, normals, o, d)
+    assert count_diff(got[:, 0].astype(np.uint8), z["tri.hit"]) == 0
+    assert bit_equal(got[:, 1], z["tri.t"])
+    assert bit_equal(got[:, 2:5], z["tri.pos"]) and bit_equal(got[:, 5:8], z["tri.Ns"]) and bit_equal(got[:, 8:11], z["tri.Ng"])
+    assert 0.05 < z["tri.hit"].mean() < 0.95
+
+
+def test_device_math_helpers(fn_ctx, port):
+    """global.hpp helpers on the device against the reference build: exact for + - * / sqrt chains, <= 16 ulp or 1e-6 + 2e-5
+    relative through acosf / tanf / x^5"""
+    z = np.load(golden_path("functions.npz"))
+    a, b, c, scale, eta_i, eta_t, rough, x, y = pc.math_inputs()
+    assert pc.checksum(a, b, c, scale, eta_i, eta_t, rough, x, y) == z["math.in_crc"]
+    h = port.normalized(a + b)  # an input of D / G (as parity_cases.run_math forms it)
+    cos = np.clip((a * b).sum(1), -1, 1).astype(np.float32)
+    F0 = np.abs(c).astype(np.float32)
+    zero = np.zeros((4, 3), np.float32)
+    f = fn_ctx.eval_fn
+    exact = {
+        "normalized": f("normalized", np.concatenate([a * scale, zero])),
+        "reflect": f("reflect", a * scale, b),
+        "refract": f("refract", a, b * scale, eta_i, eta_t),
+        "D": f("D", h, b, rough)[:, 0],
+        "mis": f("mis", x, y)[:, 0],
+        "local2world": f("local2world", a * scale, b),
+    }
+    for k, g in exact.items():
+        assert count_diff(g, z[f"math.{k}"]) == 0, k
+    loose = {
+        "fresnel": f("fresnel", a * scale, b, eta_i, eta_t)[:, 0],
+        "fresnel_schlick": f("fresnel_schlick", cos, F0),
+        "G": f("G", a, c, b, rough, h)[:, 0],
+    }
+    for k, g in loose.items():
+        w = z[f"math.{k}"]
+        close = (ulp_diff(g, w) <= 16) | (np.abs(g - w) <= 1e-6 + 2e-5 * np.abs(w)) | (np.isnan(g) & np.isnan(w))
+        assert (~close).mean() < 2e-3, (k, int((~close).sum()))
+
+
+def test_device_rng_known_answers(fn_ctx, port):
+    """Philox4x32-10 on the device: the Random123 known-answer vector with a zero last counter word (the only kind this path
+    forms), 300 random (pixel, sample, block, key) blocks against the CPU implementation, and the xi stream of one sample
+    against the reference build's golden stream"""
+    z = np.load(golden_path("functions.npz"))
+    q = np.array([[0, 0, 0, 0, 0]], np.uint32)
+    out = fn_ctx.eval_fn("philox", q).view(np.uint32)
+    assert [hex(v) for v in out[0]] == ["0x6627e8d5", "0xe169c58d", "0xbc57ac4c", "0x9b00dbd8"]
+    assert bit_equal(out[0], z["philox.out"][0])
+    r = np.random.default_rng(77)
+    q = r.integers(0, 2 ** 32, (300, 5), dtype=np.uint64).astype(np.uint32)
+    q[:, 2] &= 0x3FFFFFFF  # block = draw >> 2
+    got = fn_ctx.eval_fn("philox", q).view(np.uint32)
+    # the CPU implementation takes one key per call: check 300 rows one by one
+    for i in range(300):
+        ctr = np.array([[q[i, 0], q[i, 1], q[i, 2], 0]], np.uint32)
+        assert bit_equal(port.philox(ctr, int(q[i, 3]), int(q[i, 4]))[0], got[i]), i
+    # the xi stream: draws 0..63 of sample 7 of pixel 12345 under key (KEY0, 2)
+    rows = np.array([[12345, 7, pc.KEY0, 2, 8 * k] for k in range(8)], np.uint32)
+    xi = fn_ctx.eval_fn("rng", rows).reshape(-1)
+    assert bit_equal(xi, z["philox.stream"])
+    assert xi.min() >= 0 and xi.max() < 1
+
+
+# ------------------------------------------------------------------------------------------------------------
+# the BASELINE frames themselves
+def _frame_checks(tr, port, sc, key1, spp, n_probe_pixels=12, n_samples=2000):
+    """Properties of a full-size, full-spp frame that do not need a CPU render of it:
+      * the frame with the default four passes in flight == the frame with one pass in flight, bit for bit;
+      * a pixel of the frame == (1/spp) * the sum, in sample order and dropping NaN samples, of that pixel's per-sample
+        radiances (tutu_hip_trace_samples) -- the resolve of PathTracing.hpp:507-513, bit for bit;
+      * 2000 random (pixel, sample) pairs against the CPU restatement at the per-sample bar;
+      * the frame's mean against a low-spp CPU render of the same frame within Monte-Carlo error."""
+    W, H = sc["width"], sc["height"]
+    with tr.Context(sc) as ctx:
+        frame = ctx.render(spp, pc.KEY0, key1)                       # host-pointer path (tutu_hip_render), default work sets
+        st = ctx.last_stats
+        assert st["samples"] == W * H * spp and st["passes"] > 4 and st["n_sets"] == 4
+        ctx.set_option("sets", 1)
+        one = ctx.render(spp, pc.KEY0, key1)
+        assert ctx.last_stats["n_sets"] == 1
+        ctx.set_option("sets", 0)
+        assert bit_equal(frame, one)
+        assert np.isfinite(frame).all()
+        rng = np.random.default_rng(2024)
+        probe = rng.integers(0, W * H, n_probe_pixels)
+        pix = np.repeat(probe.astype(np.uint32), spp)
+        smp = np.tile(np.arange(spp, dtype=np.uint32), n_probe_pixels)
+        L = ctx.trace_samples(pix, smp, pc.KEY0, key1).reshape(n_probe_pixels, spp, 3)
+        acc = np.zeros((n_probe_pixels, 3), np.float32)
+        for s in range(spp):
+            ok = ~np.isnan(L[:, s]).any(1)
+            acc[ok] = acc[ok] + L[ok, s]
+        want_px = acc * np.float32(1.0 / spp)
+        assert bit_equal(frame.reshape(-1, 3)[probe], want_px)
+        pix = rng.integers(0, W * H, n_samples).astype(np.uint32)
+        smp = rng.integers(0, spp, n_samples).astype(np.uint32)
+        Lg = ctx.trace_samples(pix, smp, pc.KEY0, key1)
+    S = port.scene(sc)
+    Lw = S.trace_samples(pix, smp, pc.KEY0, key1)
+    low = S.render(2, pc.KEY0, key1, nthreads=16)
+    S.close()
+    fin = ~(np.isnan(Lg).any(1) | np.isnan(Lw).any(1))
+    err = np.abs(Lg[fin] - Lw[fin]).max(1)
+    scale = np.maximum(np.abs(Lw[fin]).max(1), 1e-3)
+    assert ((err > 1e-4 * scale + 1e-6).mean()) < 5e-3
+    # Monte-Carlo error of the 2-spp CPU mean: per-channel variance of its pixels / number of pixels (plus the frame's own, smaller)
+    for ch in range(3):
+        sigma = low[..., ch].std() / np.sqrt(low[..., ch].size) * 1.5
+        assert abs(frame[..., ch].mean() - low[..., ch].mean()) < 5 * sigma + 1e-4, (ch, frame[..., ch].mean(), low[..., ch].mean(), sigma)
+    return frame, st
+
+
+def test_headline_frame_cornell_800x800_512spp(tr, port):
+    """BASELINE configs[1], the frame bench.py times: 27 passes x 4 streams x 12 Mi record slots"""
+    from tuturenderer_amd import scenes
+
+    frame, st = _frame_checks(tr, port, scenes.cornell_box(800, 800), key1=2, spp=512)
+    assert abs(frame.mean() - 0.3960) < 0.004  # the reference's own mean at 800x800 (SURVEY.md 8c)
+    print(f"cornell 800x800x512: mean {frame.mean():.5f} passes {st['passes']} spp/pass {st['spp_per_pass']} rays/sample "
+          f"{(st['closest_rays'] + st['shadow_rays']) / st['samples']:.2f}")
+
+
+def test_config5_frame_veach_800x600_512spp(tr, port):
+    """BASELINE configs[4] at its size and spp (mixed materials: Lambertian, PERFECT_REFRACTIVE, MICROFACET_R -> SHADE_ANY)"""
+    from tuturenderer_amd import scenes
+
+    frame, st = _frame_checks(tr, port, scenes.veach_room(800, 600, small_light=False), key1=5, spp=512, n_probe_pixels=8)
+    assert abs(frame.mean() - 0.2149) < 0.01  # SURVEY.md Appendix A: veach without the small light
+
+
+def test_two_ranks_on_one_gpu_gather_the_single_process_frame(tr, tmp_path):
+    """The N > 1 path with REAL HIP contexts: two processes (gloo rendezvous, both on cuda:0) each render their pixel
+    tiles with their own TutuCtx and FrameGather assembles the frame on rank 0 -- bit-identical to one process rendering
+    everything (the RNG is keyed by global pixel and sample).  The RCCL leg of the same code is bench.py --gpus N."""
+    import subprocess
+    import sys
+
+    from conftest import ROOT
+    from tuturenderer_amd import scenes
+
+    out = str(tmp_path / "frame2.npy")
+    port_no = 29500 + (hash(out) % 400)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port_no), "bench.py", "--gpus", "2", "--same-device", "--backend", "gloo", "--config", "c1", "--spp", "6",
+           "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--dump", out]
+    r = subprocess.run(cmd, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:]
+    two = np.load(out)
+    with tr.Context(scenes.cornell_box(800, 800)) as ctx:
+        one = ctx.render(6, pc.KEY0, 1)
+    assert bit_equal(two, one)

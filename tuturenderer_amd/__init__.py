@@ -19,7 +19,7 @@ ABI_SYMBOLS = [
     "tutu_camera_frame", "tutu_bvh_build_preorder", "tutu_hip_error_string", "tutu_hip_last_error", "tutu_hip_version",
     "tutu_hip_device_count", "tutu_hip_create", "tutu_hip_destroy", "tutu_hip_render", "tutu_hip_render_device",
     "tutu_hip_trace_closest", "tutu_hip_trace_any", "tutu_hip_trace_samples", "tutu_hip_eval_bxdf", "tutu_hip_eval_pdf",
-    "tutu_hip_eval_sample", "tutu_hip_eval_sample_light", "tutu_hip_scene_info", "tutu_hip_eval_texture", "tutu_hip_set_option", "tutu_hip_get_option", "tutu_hip_postprocess", "tutu_hip_quantise",
+    "tutu_hip_eval_sample", "tutu_hip_eval_sample_light", "tutu_hip_eval_fn", "tutu_hip_scene_info", "tutu_hip_eval_texture", "tutu_hip_set_option", "tutu_hip_get_option", "tutu_hip_postprocess", "tutu_hip_quantise",
 ]
 
 
@@ -274,7 +274,7 @@ class Context:
         _check(self.lib.tutu_hip_set_option(self.h, C.c_char_p(name.encode()), C.c_int(int(value))), "tutu_hip_set_option")
 
     OPTION_NAMES = ("sets", "sets_default", "one_set", "shade_bpc", "trace_bpc", "refill_min", "inner_steps", "any_near_first",
-                    "util_stats", "class_sort", "sah_tree", "lds_scene", "shade_tab")
+                    "util_stats", "sah_tree", "lds_scene", "shade_tab")
 
     def get_option(self, name):
         v = C.c_int(0)
@@ -395,6 +395,20 @@ class Context:
         _check(self.lib.tutu_hip_eval_sample(self.h, C.c_uint32(n), _p(m), _p(wo), _p(N), C.c_float(eta_i), _p(xi3), _p(wi), _p(ok), _p(sp),
                                              _p(nd)), "tutu_hip_eval_sample")
         return wi, ok, sp, nd
+
+    FN = {"bbox": (0, 1), "tri": (1, 11), "normalized": (2, 3), "fresnel": (3, 1), "fresnel_schlick": (4, 3), "reflect": (5, 3),
+          "refract": (6, 3), "D": (7, 1), "G": (8, 1), "mis": (9, 1), "local2world": (10, 3), "rng": (11, 8), "philox": (12, 4)}
+
+    def eval_fn(self, name, *arrays):
+        """tutu_hip_eval_fn: one of the hot-path device functions on arrays (float32; the rng / philox inputs are uint32
+        rows viewed as float32 bits).  Returns an (n, width) float32 array."""
+        fn, w_out = self.FN[name]
+        arrs = [np.ascontiguousarray(a).view(np.float32) if np.asarray(a).dtype == np.uint32 else _f32(a) for a in arrays]
+        n = len(arrs[0])
+        ptrs = (C.c_void_p * 6)(*[a.ctypes.data for a in arrs] + [None] * (6 - len(arrs)))
+        out = np.zeros((n, w_out), np.float32)
+        _check(self.lib.tutu_hip_eval_fn(self.h, C.c_int32(fn), C.c_uint32(n), ptrs, _p(out)), "tutu_hip_eval_fn")
+        return out
 
     def eval_sample_light(self, xi3):
         xi3 = _f32(xi3)

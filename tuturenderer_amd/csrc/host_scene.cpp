@@ -295,6 +295,19 @@ int build_sah_tree(const std::vector<Box>& tb, std::vector<BuildNode>& out, uint
 }
 }  // namespace
 
+void make_tri_isect(uint32_t n, const float* verts9, float* out12) {
+	for (uint32_t i = 0; i < n; i++) {
+		const float* v = verts9 + 9 * (size_t)i;
+		GpuTriIsect t;
+		memcpy(t.v0, v, 12);
+		sub3(v + 3, v, t.e1);     // E1 = v1 - v0            Triangle.hpp:25
+		sub3(v + 6, v, t.e2);     // E2 = v2 - v0            Triangle.hpp:26
+		cross3(t.e1, t.e2, t.n);  // normal = E1 x E2        Triangle.hpp:34
+		normalize3(t.n);          // normalized(normal)      Triangle.hpp:35
+		memcpy(out12 + 12 * (size_t)i, &t, sizeof(t));
+	}
+}
+
 int build_reference_tree(uint32_t n_tris, const float* verts, std::vector<BuildNode>& out, uint32_t* depth) {
 	out.clear();
 	if (depth) *depth = 0;

@@ -114,6 +114,8 @@ struct BuildNode {
 	int32_t tri;          // original triangle index for a leaf, -1 otherwise
 };
 
+// the intersection record of n triangles (12 floats each: v0, E1, E2, normalised E1 x E2) from their 9 vertex floats
+void make_tri_isect(uint32_t n, const float* verts9, float* out12);
 int build_reference_tree(uint32_t n_tris, const float* verts, std::vector<BuildNode>& out, uint32_t* depth);
 int build_host_scene(const TutuSceneDesc* d, HostScene& out);
 

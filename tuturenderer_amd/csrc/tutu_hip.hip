@@ -943,6 +943,98 @@ __global__ void k_test_sample_light(SceneDev sc, const float* xi3, uint32_t n, i
 	pdf[i] = ls.pdf;
 }
 
+// Function-level parity of the remaining hot-path rows (a10 slab test, a11 triangle test, a16 math helpers,
+// a17 RNG): one generic kernel, fn selects the device function, in[k] are the input arrays (n rows each).
+struct FnArgs {
+	const float* in[6];
+	float* out;
+	uint32_t n;
+	int fn;
+};
+__global__ void k_test_fn(FnArgs a) {
+	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= a.n) return;
+	const size_t i3 = 3 * (size_t)i;
+	switch (a.fn) {
+	case TUTU_FN_BBOX: {  // BoundBox::IntersectRay: pmin, pmax, o, d -> hit
+		const RayPre r = make_ray(ld3(a.in[2] + i3), ld3(a.in[3] + i3));
+		float te;
+		a.out[i] = slab(r, a.in[0][i3], a.in[0][i3 + 1], a.in[0][i3 + 2], a.in[1][i3], a.in[1][i3 + 1], a.in[1][i3 + 2], te) ? 1.f : 0.f;
+		break;
+	}
+	case TUTU_FN_TRI: {  // Triangle::intersect on a GpuTriIsect record (in[0], 12 floats) + vertex normals (in[1], 9 floats), o, d
+		SceneGlobal sg;
+		sg.nodes = nullptr;
+		sg.tris = reinterpret_cast<const float4*>(a.in[0]);
+		const RayPre r = make_ray(ld3(a.in[2] + i3), ld3(a.in[3] + i3));
+		float t = 0.f, u = 0.f, v = 0.f;
+		const bool h = tri_test(sg, (int)i, r, t, u, v);
+		float* o = a.out + 11 * (size_t)i;
+		for (int k = 0; k < 11; k++) o[k] = 0.f;
+		if (h) {
+			const float* nn = a.in[1] + 9 * (size_t)i;
+			const V3 n0 = ld3(nn), n1 = ld3(nn + 3), n2 = ld3(nn + 6);
+			const V3 pos = r.o + t * r.d;                                            // Triangle.hpp:50
+			const V3 Ns = normalized((n0 * (1 - u - v)) + n1 * u + n2 * v);          // Triangle.hpp:54 (as k_shade forms it)
+			const float4 q2 = sg.tris[3 * i + 2];
+			const float4 q1 = sg.tris[3 * i + 1];
+			o[0] = 1.f; o[1] = t;
+			o[2] = pos.x; o[3] = pos.y; o[4] = pos.z;
+			o[5] = Ns.x; o[6] = Ns.y; o[7] = Ns.z;
+			o[8] = q2.y; o[9] = q2.z; o[10] = q2.w;                                  // Ng = the hoisted normalised E1 x E2
+			(void)q1;
+		}
+		break;
+	}
+	case TUTU_FN_NORMALIZED: {
+		const V3 r = normalized(ld3(a.in[0] + i3));
+		a.out[i3] = r.x; a.out[i3 + 1] = r.y; a.out[i3 + 2] = r.z;
+		break;
+	}
+	case TUTU_FN_FRESNEL: a.out[i] = fresnel(ld3(a.in[0] + i3), ld3(a.in[1] + i3), a.in[2][i], a.in[3][i]); break;
+	case TUTU_FN_FRESNEL_SCHLICK: {
+		const V3 r = fresnelSchlick(a.in[0][i], ld3(a.in[1] + i3));
+		a.out[i3] = r.x; a.out[i3 + 1] = r.y; a.out[i3 + 2] = r.z;
+		break;
+	}
+	case TUTU_FN_REFLECT: {
+		const V3 r = getReflectionDir(ld3(a.in[0] + i3), ld3(a.in[1] + i3));
+		a.out[i3] = r.x; a.out[i3 + 1] = r.y; a.out[i3 + 2] = r.z;
+		break;
+	}
+	case TUTU_FN_REFRACT: {
+		const V3 r = getRefractionDir(ld3(a.in[0] + i3), ld3(a.in[1] + i3), a.in[2][i], a.in[3][i]);
+		a.out[i3] = r.x; a.out[i3 + 1] = r.y; a.out[i3 + 2] = r.z;
+		break;
+	}
+	case TUTU_FN_D: a.out[i] = D_ndf(ld3(a.in[0] + i3), ld3(a.in[1] + i3), a.in[2][i]); break;
+	case TUTU_FN_G: a.out[i] = G_smf(ld3(a.in[0] + i3), ld3(a.in[1] + i3), ld3(a.in[2] + i3), a.in[3][i], ld3(a.in[4] + i3)); break;
+	case TUTU_FN_MIS: a.out[i] = getMisWeight(a.in[0][i], a.in[1][i]); break;
+	case TUTU_FN_LOCAL2WORLD: {
+		const V3 r = SphereLocal2world(ld3(a.in[0] + i3), ld3(a.in[1] + i3));
+		a.out[i3] = r.x; a.out[i3 + 1] = r.y; a.out[i3 + 2] = r.z;
+		break;
+	}
+	case TUTU_FN_RNG: {  // in[0]: pix, smp, key0, key1, first draw (as uint32 bits) -> 8 consecutive xi of that sample's stream
+		const uint32_t* q = reinterpret_cast<const uint32_t*>(a.in[0]) + 5 * (size_t)i;
+		Rng rng;
+		rng.init(q[0], q[1], q[4], q[2], q[3]);
+		for (int k = 0; k < 8; k++) a.out[8 * (size_t)i + k] = rng.next();
+		break;
+	}
+	case TUTU_FN_PHILOX: {  // in[0]: counter words 0..2 (word 3 is always 0 on this path), key0, key1 -> the four output words
+		const uint32_t* q = reinterpret_cast<const uint32_t*>(a.in[0]) + 5 * (size_t)i;
+		Rng rng;
+		rng.init(q[0], q[1], 0, q[3], q[4]);
+		rng.refill(q[2]);
+		uint32_t* o = reinterpret_cast<uint32_t*>(a.out) + 4 * (size_t)i;
+		o[0] = rng.w0; o[1] = rng.w1; o[2] = rng.w2; o[3] = rng.w3;
+		break;
+	}
+	default: break;
+	}
+}
+
 // scratch device copies for the test entry points
 struct Scratch {
 	std::vector<void*> ptrs;
@@ -1169,6 +1261,56 @@ int tutu_hip_eval_sample_light(TutuCtx* c, uint32_t n, const float* xi3, int32_t
 	HIP_TRY(hipMemcpy(pos, d_pos, sizeof(float) * 3 * (size_t)n, hipMemcpyDeviceToHost));
 	HIP_TRY(hipMemcpy(nrm, d_nrm, sizeof(float) * 3 * (size_t)n, hipMemcpyDeviceToHost));
 	HIP_TRY(hipMemcpy(pdf, d_pdf, sizeof(float) * (size_t)n, hipMemcpyDeviceToHost));
+	return TUTU_OK;
+}
+
+// widths (floats per row) of the inputs and of the output of every TutuFn
+static const struct { int n_in; int w[6]; int w_out; } kFnShape[TUTU_FN_COUNT] = {
+    /* BBOX */ {4, {3, 3, 3, 3, 0, 0}, 1},
+    /* TRI */ {4, {12, 9, 3, 3, 0, 0}, 11},
+    /* NORMALIZED */ {1, {3, 0, 0, 0, 0, 0}, 3},
+    /* FRESNEL */ {4, {3, 3, 1, 1, 0, 0}, 1},
+    /* FRESNEL_SCHLICK */ {2, {1, 3, 0, 0, 0, 0}, 3},
+    /* REFLECT */ {2, {3, 3, 0, 0, 0, 0}, 3},
+    /* REFRACT */ {4, {3, 3, 1, 1, 0, 0}, 3},
+    /* D */ {3, {3, 3, 1, 0, 0, 0}, 1},
+    /* G */ {5, {3, 3, 3, 1, 3, 0}, 1},
+    /* MIS */ {2, {1, 1, 0, 0, 0, 0}, 1},
+    /* LOCAL2WORLD */ {2, {3, 3, 0, 0, 0, 0}, 3},
+    /* RNG */ {1, {5, 0, 0, 0, 0, 0}, 8},
+    /* PHILOX */ {1, {5, 0, 0, 0, 0, 0}, 4},
+};
+
+int tutu_hip_eval_fn(TutuCtx* c, int32_t fn, uint32_t n, const float* const* in, float* out) {
+	if (!c || !in || !out || fn < 0 || fn >= TUTU_FN_COUNT) return TUTU_E_INVALID;
+	if (n == 0) return TUTU_OK;
+	HIP_TRY(hipSetDevice(c->device));
+	Scratch sc;
+	FnArgs a;
+	memset(&a, 0, sizeof(a));
+	a.n = n;
+	a.fn = fn;
+	std::vector<float> isect;
+	for (int k = 0; k < kFnShape[fn].n_in; k++) {
+		if (!in[k]) return TUTU_E_INVALID;
+		const float* src = in[k];
+		size_t w = (size_t)kFnShape[fn].w[k];
+		if (fn == TUTU_FN_TRI && k == 0) {
+			// the caller passes the 9 vertex floats; the device reads the intersection record the HOST derives from them
+			// (v0, E1, E2, normalised E1 x E2 -- host_scene.cpp), exactly as tutu_hip_create stores it
+			isect.resize(12 * (size_t)n);
+			tutu::make_tri_isect(n, in[0], isect.data());
+			src = isect.data();
+		}
+		float* d = nullptr;
+		RC(sc.up(src, w * n, &d));
+		a.in[k] = d;
+	}
+	RC(sc.alloc((size_t)kFnShape[fn].w_out * n, &a.out));
+	hipLaunchKernelGGL(k_test_fn, dim3((n + 255) / 256), dim3(256), 0, c->stream, a);
+	HIP_TRY(hipGetLastError());
+	HIP_TRY(hipStreamSynchronize(c->stream));
+	HIP_TRY(hipMemcpy(out, a.out, sizeof(float) * (size_t)kFnShape[fn].w_out * n, hipMemcpyDeviceToHost));
 	return TUTU_OK;
 }
 
