@@ -214,6 +214,14 @@ int tutu_hip_render(TutuCtx* ctx, const TutuCameraFrame* cam, const TutuRenderPa
 int tutu_hip_render_device(TutuCtx* ctx, const TutuCameraFrame* cam, const TutuRenderParams* params,
                            float* d_out_rgb, void* stream, TutuStats* stats);
 
+/* The N-device form of tutu_hip_render: `n` contexts of the SAME scene (normally one per device; several on one device
+ * work too), one host thread per context inside the call.  Replaces the static row split over std::threads of
+ * PathTracing::integrate (PathTracing.hpp:393-429): work items are dealt to the contexts in 32x32 pixel tiles,
+ * round-robin; every context renders its items and writes them to out_rgb (host pointer, item order as in
+ * tutu_hip_render).  The frame is bit-identical for any n.  stats: n entries or NULL. */
+int tutu_hip_render_multi(TutuCtx* const* ctxs, int32_t n, const TutuCameraFrame* cam, const TutuRenderParams* params,
+                          float* out_rgb, TutuStats* stats);
+
 /* Kernel-level entry points for parity tests.
  * closest: BVHStrategy::UpdateInter -> getIntersection (BVHStrategy.hpp:8-11, BVH.hpp:145-167)
  * any:     isShadowRayBlocked -> hasIntersection (IIntegrator.hpp:135-153, BVH.hpp:170-194): orig and the target

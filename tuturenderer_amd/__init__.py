@@ -17,7 +17,7 @@ LIB_PATH = os.environ.get("TUTU_HIP_LIB", os.path.join(HERE, "libtutu_hip.so")) 
 # every symbol include/tutu_hip.h declares
 ABI_SYMBOLS = [
     "tutu_camera_frame", "tutu_bvh_build_preorder", "tutu_hip_error_string", "tutu_hip_last_error", "tutu_hip_version",
-    "tutu_hip_device_count", "tutu_hip_create", "tutu_hip_destroy", "tutu_hip_render", "tutu_hip_render_device",
+    "tutu_hip_device_count", "tutu_hip_create", "tutu_hip_destroy", "tutu_hip_render", "tutu_hip_render_device", "tutu_hip_render_multi",
     "tutu_hip_trace_closest", "tutu_hip_trace_any", "tutu_hip_trace_samples", "tutu_hip_eval_bxdf", "tutu_hip_eval_pdf",
     "tutu_hip_eval_sample", "tutu_hip_eval_sample_light", "tutu_hip_eval_fn", "tutu_hip_scene_info", "tutu_hip_eval_texture", "tutu_hip_set_option", "tutu_hip_get_option", "tutu_hip_postprocess", "tutu_hip_quantise",
 ]
@@ -324,6 +324,19 @@ class Context:
             x0, y0, x1, y1 = rect
             img.reshape(self.H, self.W, 3)[y0:y1, x0:x1] = out.reshape(y1 - y0, x1 - x0, 3)
         return img.reshape(self.H, self.W, 3)
+
+    @staticmethod
+    def render_multi(ctxs, spp, key0, key1, pixels=None, rect=None, spp_per_pass=0, max_paths=0):
+        """tutu_hip_render_multi over several contexts of the same scene; returns the compact (n,3) array"""
+        c0 = ctxs[0]
+        rp, n, keep, rect = c0._params(spp, key0, key1, pixels, rect, spp_per_pass, max_paths)
+        out = np.zeros((n, 3), np.float32)
+        arr = (C.c_void_p * len(ctxs))(*[c.h for c in ctxs])
+        st = (Stats * len(ctxs))()
+        _check(c0.lib.tutu_hip_render_multi(arr, C.c_int32(len(ctxs)), C.byref(c0.cam), C.byref(rp), _p(out), st), "tutu_hip_render_multi")
+        for c, s_ in zip(ctxs, st):
+            c.last_stats = s_.as_dict()
+        return out
 
     def render_device(self, d_out_ptr, spp, key0, key1, pixels=None, rect=None, spp_per_pass=0, max_paths=0, stream=None):
         """Same, writing the compact (n,3) result to device memory at d_out_ptr (e.g. torch_tensor.data_ptr())."""

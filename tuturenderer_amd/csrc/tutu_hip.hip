@@ -9,6 +9,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/tutu_hip.h"
@@ -822,6 +823,86 @@ int tutu_hip_render(TutuCtx* c, const TutuCameraFrame* cam, const TutuRenderPara
 	rc = render_impl(c, cam, rp, c->out_stage.p, c->stream, st);
 	if (rc != TUTU_OK) return rc;
 	HIP_TRY(hipMemcpy(out_rgb, c->out_stage.p, sizeof(float) * 3 * (size_t)npix, hipMemcpyDeviceToHost));
+	return TUTU_OK;
+}
+
+
+// The N-device form of tutu_hip_render.  The reference splits image ROWS statically over its 20 threads
+// (PathTracing.hpp:393-429); here the work items are dealt to the contexts in 32x32 pixel tiles, round-robin (rows of
+// a Cornell-like frame differ a lot in cost), pixels inside a tile in 8x8 blocks so that a wavefront covers a compact
+// patch.  One host thread per context (the ABI's threading rule); every context writes its own items of out_rgb.
+// The RNG is keyed by pixel and sample, so the frame is bit-identical to the one-context call for any n.
+int tutu_hip_render_multi(TutuCtx* const* ctxs, int32_t n, const TutuCameraFrame* cam, const TutuRenderParams* rp, float* out_rgb,
+                          TutuStats* stats) {
+	if (!ctxs || n <= 0 || !cam || !rp || !out_rgb) return TUTU_E_INVALID;
+	for (int k = 0; k < n; k++)
+		if (!ctxs[k]) return TUTU_E_INVALID;
+	if (n == 1) return tutu_hip_render(ctxs[0], cam, rp, out_rgb, stats);
+	int64_t n_items;
+	int x0 = 0, y0 = 0, rect_w = 1;
+	if (rp->pixels) {
+		if (rp->n_pixels <= 0) return TUTU_E_INVALID;
+		n_items = rp->n_pixels;
+	} else {
+		if (rp->x0 < 0 || rp->y0 < 0 || rp->x1 > cam->width || rp->y1 > cam->height || rp->x1 <= rp->x0 || rp->y1 <= rp->y0) return TUTU_E_INVALID;
+		x0 = rp->x0;
+		y0 = rp->y0;
+		rect_w = rp->x1 - rp->x0;
+		n_items = (int64_t)rect_w * (rp->y1 - rp->y0);
+	}
+	// tile of an item's pixel -> owner; inside a tile: 8x8 blocks
+	const int T = 32, tiles_x = (cam->width + T - 1) / T;
+	struct Piece {
+		std::vector<int32_t> pixels, items;
+		std::vector<uint32_t> order_key;
+	};
+	std::vector<Piece> pieces((size_t)n);
+	for (int64_t i = 0; i < n_items; i++) {
+		const int32_t pix = rp->pixels ? rp->pixels[i] : (int32_t)((y0 + i / rect_w) * cam->width + x0 + i % rect_w);
+		if (pix < 0 || pix >= cam->width * cam->height) return TUTU_E_INVALID;
+		const int x = pix % cam->width, y = pix / cam->width;
+		const int tile = (y / T) * tiles_x + x / T;
+		Piece& p = pieces[(size_t)(tile % n)];
+		p.pixels.push_back(pix);
+		p.items.push_back((int32_t)i);
+		// order inside the piece: tile, then 8x8 block, then row-major inside the block
+		const int lx = x % T, ly = y % T;
+		p.order_key.push_back(((uint32_t)tile << 10) | (uint32_t)(((ly / 8) * 4 + lx / 8) << 6) | (uint32_t)((ly % 8) * 8 + lx % 8));
+	}
+	std::vector<int> rcs((size_t)n, TUTU_OK);
+	std::vector<std::string> errs((size_t)n);
+	std::vector<std::thread> threads;
+	for (int k = 0; k < n; k++) {
+		threads.emplace_back([&, k]() {
+			Piece& p = pieces[(size_t)k];
+			if (p.pixels.empty()) {
+				if (stats) memset(&stats[k], 0, sizeof(TutuStats));
+				return;
+			}
+			std::vector<uint32_t> perm(p.pixels.size());
+			for (size_t i = 0; i < perm.size(); i++) perm[i] = (uint32_t)i;
+			std::stable_sort(perm.begin(), perm.end(), [&p](uint32_t a, uint32_t b) { return p.order_key[a] < p.order_key[b]; });
+			std::vector<int32_t> pix(perm.size());
+			for (size_t i = 0; i < perm.size(); i++) pix[i] = p.pixels[perm[i]];
+			std::vector<float> piece(3 * pix.size());
+			TutuRenderParams q = *rp;
+			q.pixels = pix.data();
+			q.n_pixels = (int32_t)pix.size();
+			const int rc = tutu_hip_render(ctxs[k], cam, &q, piece.data(), stats ? &stats[k] : nullptr);
+			rcs[(size_t)k] = rc;
+			if (rc != TUTU_OK) {
+				errs[(size_t)k] = g_last_error;
+				return;
+			}
+			for (size_t i = 0; i < perm.size(); i++) memcpy(out_rgb + 3 * (size_t)p.items[perm[i]], &piece[3 * i], 12);
+		});
+	}
+	for (auto& t : threads) t.join();
+	for (int k = 0; k < n; k++)
+		if (rcs[(size_t)k] != TUTU_OK) {
+			g_last_error = errs[(size_t)k];
+			return rcs[(size_t)k];
+		}
 	return TUTU_OK;
 }
 

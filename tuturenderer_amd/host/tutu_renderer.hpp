@@ -619,154 +619,10 @@ public:
 };
 
 // IIntegrator for `integrator path`: the whole of PathTracing::integrate (PathTracing.hpp:352-516) as one call
-// into the GPU library.  Reads g->cam / g->scene.objList / g->eta / g->bkgcolor / SPP, writes
-// g->cam.FrameBuffer.rgb[y*W+x] (linear radiance, before gamma) -- the contract of sub_render_pt.
-class HipPathTracing : public IIntegrator {
-public:
-	HipPathTracing(PPMGenerator* gen, IIntersectStrategy* inters) {
-		g = gen;
-		interStrategy = inters;
-	}
-	TutuStats stats{};
-	int device = 0;
-
-	void integrate(PPMGenerator* gen) override {
-		const size_t n_obj = gen->scene.objList.size();
-		size_t n = 0;  // triangles
-		for (auto& o : gen->scene.objList) n += o->objectType == TRIANGLE ? 1 : 0;
-		std::vector<float> verts(9 * n), normals(9 * n);
-		std::vector<int32_t> mat_id(n);
-		std::vector<TutuMaterial> mats;
-		std::vector<float> uvs(6 * n, -1.f);
-		std::vector<int32_t> tex_ids(4 * n, -1);
-		std::vector<float> spheres;
-		std::vector<int32_t> sphere_mat, sphere_tex, sphere_pos;
-		bool any_texture = false;
-		auto material_index = [&mats](const Material& s) -> int32_t {
-			TutuMaterial m;
-			std::memset(&m, 0, sizeof(m));
-			m.diffuse[0] = s.diffuse.x; m.diffuse[1] = s.diffuse.y; m.diffuse[2] = s.diffuse.z;
-			m.specular[0] = s.specular.x; m.specular[1] = s.specular.y; m.specular[2] = s.specular.z;
-			m.emission[0] = s.emission.x; m.emission[1] = s.emission.y; m.emission[2] = s.emission.z;
-			m.type = (int32_t)s.mType;
-			m.alpha = s.alpha; m.eta = s.eta; m.roughness = s.roughness; m.metallic = s.metallic;
-			// consecutive objects of one loadObj share a material: check the last few entries
-			for (int k = (int)mats.size() - 1; k >= 0 && k >= (int)mats.size() - 8; k--)
-				if (std::memcmp(&mats[(size_t)k], &m, sizeof(m)) == 0) return k;
-			mats.push_back(m);
-			return (int32_t)mats.size() - 1;
-		};
-		size_t i = 0;  // running triangle index
-		for (size_t slot = 0; slot < n_obj; slot++) {
-			Object* o = gen->scene.objList[slot].get();
-			if (o->objectType == SPEHRE) {
-				const Sphere* sp = static_cast<const Sphere*>(o);
-				spheres.insert(spheres.end(), {sp->centerPos.x, sp->centerPos.y, sp->centerPos.z, sp->radius});
-				sphere_mat.push_back(material_index(o->mtlcolor));
-				const int32_t ids[4] = {o->textureIndex, o->normalMapIndex, o->roughnessMapIndex, o->metallicMapIndex};
-				for (int k = 0; k < 4; k++) sphere_tex.push_back(o->isTextureActivated ? ids[k] : -1);
-				if (o->isTextureActivated) any_texture = true;
-				sphere_pos.push_back((int32_t)slot);
-				continue;
-			}
-			if (o->objectType != TRIANGLE) die(TUTU_E_UNSUPPORTED, "scene");
-			const Triangle* t = static_cast<const Triangle*>(o);
-			if (o->isTextureActivated) {
-				any_texture = true;
-				uvs[6 * i + 0] = t->uv0.x; uvs[6 * i + 1] = t->uv0.y;
-				uvs[6 * i + 2] = t->uv1.x; uvs[6 * i + 3] = t->uv1.y;
-				uvs[6 * i + 4] = t->uv2.x; uvs[6 * i + 5] = t->uv2.y;
-				tex_ids[4 * i + 0] = o->textureIndex;
-				tex_ids[4 * i + 1] = o->normalMapIndex;
-				tex_ids[4 * i + 2] = o->roughnessMapIndex;
-				tex_ids[4 * i + 3] = o->metallicMapIndex;
-			}
-			const Vector3f* pv[3] = {&t->v0, &t->v1, &t->v2};
-			const Vector3f* pn[3] = {&t->n0, &t->n1, &t->n2};
-			for (int k = 0; k < 3; k++) {
-				verts[9 * i + 3 * k + 0] = pv[k]->x; verts[9 * i + 3 * k + 1] = pv[k]->y; verts[9 * i + 3 * k + 2] = pv[k]->z;
-				normals[9 * i + 3 * k + 0] = pn[k]->x; normals[9 * i + 3 * k + 1] = pn[k]->y; normals[9 * i + 3 * k + 2] = pn[k]->z;
-			}
-			mat_id[i] = material_index(o->mtlcolor);
-			i++;
-		}
-		TutuSceneDesc sd;
-		std::memset(&sd, 0, sizeof(sd));
-		sd.n_tris = (uint32_t)n;
-		sd.verts = verts.data();
-		sd.normals = normals.data();
-		sd.mat_id = mat_id.data();
-		sd.n_mats = (uint32_t)mats.size();
-		sd.mats = mats.data();
-		sd.eta = gen->eta;
-		sd.bkg[0] = gen->bkgcolor.x; sd.bkg[1] = gen->bkgcolor.y; sd.bkg[2] = gen->bkgcolor.z;
-		// textured triangles: the four map lists of the front-end go over as they are (Texture::rgb is already a
-		// packed float triple per texel)
-		TutuTextureSet ts;
-		std::memset(&ts, 0, sizeof(ts));
-		std::vector<TutuTexture> maps[4];
-		if (any_texture) {
-			const std::vector<Texture*>* lists[4] = {&gen->diffuseMaps, &gen->normalMaps, &gen->roughnessMaps, &gen->metallicMaps};
-			for (int k = 0; k < 4; k++) {
-				for (const Texture* t : *lists[k]) {
-					TutuTexture tt;
-					tt.width = t->width;
-					tt.height = t->height;
-					tt.rgb = t->rgb.empty() ? nullptr : &t->rgb[0].x;
-					maps[k].push_back(tt);
-				}
-				ts.n_maps[k] = (uint32_t)maps[k].size();
-				ts.maps[k] = maps[k].data();
-			}
-			ts.uvs = uvs.data();
-			ts.tex_ids = tex_ids.data();
-			sd.textures = &ts;
-		}
-		TutuSphereSet sps;
-		std::memset(&sps, 0, sizeof(sps));
-		if (!sphere_mat.empty()) {
-			sps.n_spheres = (uint32_t)sphere_mat.size();
-			sps.spheres = spheres.data();
-			sps.mat_id = sphere_mat.data();
-			sps.tex_ids = sphere_tex.data();
-			sps.pos = sphere_pos.data();
-			sd.spheres = &sps;
-		}
-
-		TutuCameraDesc cd;
-		cd.width = gen->width;
-		cd.height = gen->height;
-		cd.hfov = gen->hfov;
-		cd.eye[0] = gen->cam.position.x; cd.eye[1] = gen->cam.position.y; cd.eye[2] = gen->cam.position.z;
-		cd.viewdir[0] = gen->viewdir.x; cd.viewdir[1] = gen->viewdir.y; cd.viewdir[2] = gen->viewdir.z;
-		cd.updir[0] = gen->updir.x; cd.updir[1] = gen->updir.y; cd.updir[2] = gen->updir.z;
-		TutuCameraFrame cf;
-		int rc = tutu_camera_frame(&cd, &cf);
-		if (rc != TUTU_OK) die(rc, "tutu_camera_frame");
-
-		TutuCtx* ctx = nullptr;
-		rc = tutu_hip_create(&sd, device, &ctx);
-		if (rc != TUTU_OK) die(rc, "tutu_hip_create");
-		TutuRenderParams rp;
-		std::memset(&rp, 0, sizeof(rp));
-		rp.spp = SPP;
-		rp.key0 = TUTU_SEED0;
-		rp.key1 = TUTU_SEED1;
-		rp.x0 = 0; rp.y0 = 0; rp.x1 = gen->width; rp.y1 = gen->height;
-		rp.spp_per_pass = TUTU_SPP_PER_PASS;
-		static_assert(sizeof(Vector3f) == 3 * sizeof(float), "Vector3f must be three packed floats");
-		rc = tutu_hip_render(ctx, &cf, &rp, &gen->cam.FrameBuffer.rgb[0].x, &stats);
-		if (rc != TUTU_OK) die(rc, "tutu_hip_render");
-		tutu_hip_destroy(ctx);
-	}
-
-private:
-	[[noreturn]] static void die(int rc, const char* what) {
-		std::cout << "ERROR: " << what << ": " << tutu_hip_error_string(rc) << " " << tutu_hip_last_error()
-		          << "\n(the GPU PathTracing integrator has no host fallback)\n";
-		exit(-1);
-	}
-};
+// into the GPU library -- the same binding file a maintainer adds to the reference itself.
+#define TUTU_BINDING_KNOBS  // TUTU_SEED0 / TUTU_SEED1 / TUTU_SPP_PER_PASS are declared at the top of this header
+inline int TUTU_GPUS = 0;
+#include "../integration/HipPathTracing.hpp"
 
 // ---------------------------------------------------------------------------------------------- Renderer
 class Renderer {

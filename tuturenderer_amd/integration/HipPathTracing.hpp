@@ -1,0 +1,250 @@
+// HipPathTracing.hpp -- the ONE file a maintainer adds to bobhansky/TutuRenderer to run `integrator path` on MI355X.
+//
+// An IIntegrator (reference include/IIntegrator.hpp:17-24) whose integrate(PPMGenerator*) is PathTracing::integrate
+// (include/PathTracing.hpp:352-516) done by the GPU library behind include/tutu_hip.h.  It reads exactly what
+// sub_render_pt reads -- g->cam, g->scene.objList, the four texture lists, g->eta, g->bkgcolor, g->width/height,
+// the global SPP -- and writes g->cam.FrameBuffer.rgb[y*W+x] (linear radiance, before gamma).
+//
+// The header names no class of its own besides HipPathTracing: it compiles against whatever declares the
+// reference's class shapes BEFORE it is included --
+//   * the reference itself:   #include "PathTracing.hpp" (or IIntegrator.hpp + PPMGenerator.hpp), then this file, and in
+//                             Renderer.hpp:42  `integrator = new HipPathTracing(g, interStrategy);`
+//                             (tests/test_boundary_reference.py compiles exactly that against /root/reference/include);
+//   * the bundled front-end:  tuturenderer_amd/host/tutu_renderer.hpp includes this file after its own declarations.
+// Optional knobs (plain globals, defined here): TUTU_SEED0/1 = the Philox key (replaces the random_device seed,
+// global.hpp:193), TUTU_SPP_PER_PASS, TUTU_GPUS (0 = every HIP device; N > device count puts several contexts on a device).
+//
+// Contexts are PERSISTENT: the scene is flattened and hashed on every integrate(), the device contexts (BVH, scene
+// upload, ~4 GB of work buffers each) are only rebuilt when the hash changes, and are destroyed with the integrator.
+// With more than one context the frame is rendered by tutu_hip_render_multi (32x32 pixel tiles dealt round-robin
+// to the contexts, one host thread each) -- the replacement of the reference's row split over 20 std::threads
+// (PathTracing.hpp:393-429); the picture does not depend on the number of devices.
+#pragma once
+#include <cstdint>
+#include <cstdlib>
+#include <cstring>
+#include <iostream>
+#include <vector>
+
+#ifndef TUTU_HIP_H
+#include "tutu_hip.h"  // <repo>/include
+#endif
+
+#ifndef TUTU_BINDING_KNOBS
+#define TUTU_BINDING_KNOBS
+inline uint32_t TUTU_SEED0 = 0x5EED0001u;
+inline uint32_t TUTU_SEED1 = 0u;
+inline int TUTU_SPP_PER_PASS = 0;
+inline int TUTU_GPUS = 0;
+#endif
+
+class HipPathTracing : public IIntegrator {
+public:
+	HipPathTracing(PPMGenerator* gen, IIntersectStrategy* inters) {
+		g = gen;
+		interStrategy = inters;
+		if (const char* e = getenv("TUTU_GPUS")) TUTU_GPUS = atoi(e);
+	}
+	virtual ~HipPathTracing() { release(); }
+	HipPathTracing(const HipPathTracing&) = delete;
+	HipPathTracing& operator=(const HipPathTracing&) = delete;
+
+	TutuStats stats{};      // of the first context
+	int contexts_built = 0; // how often integrate() had to (re)build the device contexts
+
+	// what integrate() hands to tutu_hip_create: g->scene.objList flattened in list order (PPMGenerator::loadObj order)
+	struct FlatScene {
+		std::vector<float> verts, normals, uvs, spheres;
+		std::vector<int32_t> mat_id, tex_ids, sphere_mat, sphere_tex, sphere_pos;
+		std::vector<TutuMaterial> mats;
+		std::vector<TutuTexture> maps[4];
+		bool any_texture = false;
+		TutuTextureSet ts;
+		TutuSphereSet sps;
+		TutuSceneDesc sd;
+		TutuCameraDesc cd;
+		uint64_t hash = 0;
+	};
+
+	// no device call in here: usable (and tested) without a GPU
+	static void flatten(PPMGenerator* gen, FlatScene& f) {
+		const size_t n_obj = gen->scene.objList.size();
+		size_t n = 0;  // triangles
+		for (auto& o : gen->scene.objList) n += o->objectType == TRIANGLE ? 1 : 0;
+		f.verts.assign(9 * n, 0.f);
+		f.normals.assign(9 * n, 0.f);
+		f.mat_id.assign(n, 0);
+		f.uvs.assign(6 * n, -1.f);
+		f.tex_ids.assign(4 * n, -1);
+		auto material_index = [&f](const Material& s) -> int32_t {
+			TutuMaterial m;
+			std::memset(&m, 0, sizeof(m));
+			m.diffuse[0] = s.diffuse.x; m.diffuse[1] = s.diffuse.y; m.diffuse[2] = s.diffuse.z;
+			m.specular[0] = s.specular.x; m.specular[1] = s.specular.y; m.specular[2] = s.specular.z;
+			m.emission[0] = s.emission.x; m.emission[1] = s.emission.y; m.emission[2] = s.emission.z;
+			m.type = (int32_t)s.mType;
+			m.alpha = s.alpha; m.eta = s.eta; m.roughness = s.roughness; m.metallic = s.metallic;
+			// consecutive objects of one loadObj share a material: check the last few entries
+			for (int k = (int)f.mats.size() - 1; k >= 0 && k >= (int)f.mats.size() - 8; k--)
+				if (std::memcmp(&f.mats[(size_t)k], &m, sizeof(m)) == 0) return k;
+			f.mats.push_back(m);
+			return (int32_t)f.mats.size() - 1;
+		};
+		size_t i = 0;  // running triangle index
+		for (size_t slot = 0; slot < n_obj; slot++) {
+			Object* o = gen->scene.objList[slot].get();
+			if (o->objectType == SPEHRE) {  // [sic] Object.hpp:12
+				const Sphere* sp = static_cast<const Sphere*>(o);
+				const float c4[4] = {sp->centerPos.x, sp->centerPos.y, sp->centerPos.z, sp->radius};
+				f.spheres.insert(f.spheres.end(), c4, c4 + 4);
+				f.sphere_mat.push_back(material_index(o->mtlcolor));
+				const int32_t ids[4] = {o->textureIndex, o->normalMapIndex, o->roughnessMapIndex, o->metallicMapIndex};
+				for (int k = 0; k < 4; k++) f.sphere_tex.push_back(o->isTextureActivated ? ids[k] : -1);
+				if (o->isTextureActivated) f.any_texture = true;
+				f.sphere_pos.push_back((int32_t)slot);
+				continue;
+			}
+			if (o->objectType != TRIANGLE) die(TUTU_E_UNSUPPORTED, "scene");
+			const Triangle* t = static_cast<const Triangle*>(o);
+			if (o->isTextureActivated) {  // Object.hpp:31-35; PPMGenerator.hpp:182-201
+				f.any_texture = true;
+				f.uvs[6 * i + 0] = t->uv0.x; f.uvs[6 * i + 1] = t->uv0.y;
+				f.uvs[6 * i + 2] = t->uv1.x; f.uvs[6 * i + 3] = t->uv1.y;
+				f.uvs[6 * i + 4] = t->uv2.x; f.uvs[6 * i + 5] = t->uv2.y;
+				f.tex_ids[4 * i + 0] = o->textureIndex;
+				f.tex_ids[4 * i + 1] = o->normalMapIndex;
+				f.tex_ids[4 * i + 2] = o->roughnessMapIndex;
+				f.tex_ids[4 * i + 3] = o->metallicMapIndex;
+			}
+			const Vector3f* pv[3] = {&t->v0, &t->v1, &t->v2};
+			const Vector3f* pn[3] = {&t->n0, &t->n1, &t->n2};
+			for (int k = 0; k < 3; k++) {
+				f.verts[9 * i + 3 * k + 0] = pv[k]->x; f.verts[9 * i + 3 * k + 1] = pv[k]->y; f.verts[9 * i + 3 * k + 2] = pv[k]->z;
+				f.normals[9 * i + 3 * k + 0] = pn[k]->x; f.normals[9 * i + 3 * k + 1] = pn[k]->y; f.normals[9 * i + 3 * k + 2] = pn[k]->z;
+			}
+			f.mat_id[i] = material_index(o->mtlcolor);
+			i++;
+		}
+		TutuSceneDesc& sd = f.sd;
+		std::memset(&sd, 0, sizeof(sd));
+		sd.n_tris = (uint32_t)n;
+		sd.verts = f.verts.data();
+		sd.normals = f.normals.data();
+		sd.mat_id = f.mat_id.data();
+		sd.n_mats = (uint32_t)f.mats.size();
+		sd.mats = f.mats.data();
+		sd.eta = gen->eta;
+		sd.bkg[0] = gen->bkgcolor.x; sd.bkg[1] = gen->bkgcolor.y; sd.bkg[2] = gen->bkgcolor.z;
+		// textured objects: the four map lists of the front-end go over as they are (Texture::rgb is a packed float
+		// triple per texel, Texture.hpp:10-16)
+		std::memset(&f.ts, 0, sizeof(f.ts));
+		if (f.any_texture) {
+			const std::vector<Texture*>* lists[4] = {&gen->diffuseMaps, &gen->normalMaps, &gen->roughnessMaps, &gen->metallicMaps};
+			for (int k = 0; k < 4; k++) {
+				for (const Texture* t : *lists[k]) {
+					TutuTexture tt;
+					tt.width = t->width;
+					tt.height = t->height;
+					tt.rgb = t->rgb.empty() ? nullptr : &t->rgb[0].x;
+					f.maps[k].push_back(tt);
+				}
+				f.ts.n_maps[k] = (uint32_t)f.maps[k].size();
+				f.ts.maps[k] = f.maps[k].data();
+			}
+			f.ts.uvs = f.uvs.data();
+			f.ts.tex_ids = f.tex_ids.data();
+			sd.textures = &f.ts;
+		}
+		std::memset(&f.sps, 0, sizeof(f.sps));
+		if (!f.sphere_mat.empty()) {
+			f.sps.n_spheres = (uint32_t)f.sphere_mat.size();
+			f.sps.spheres = f.spheres.data();
+			f.sps.mat_id = f.sphere_mat.data();
+			f.sps.tex_ids = f.sphere_tex.data();
+			f.sps.pos = f.sphere_pos.data();
+			sd.spheres = &f.sps;
+		}
+		// camera: the config keywords; the library redoes Camera::initialize + PathTracing.hpp:357-391
+		TutuCameraDesc& cd = f.cd;
+		cd.width = gen->width;
+		cd.height = gen->height;
+		cd.hfov = gen->hfov;
+		cd.eye[0] = gen->cam.position.x; cd.eye[1] = gen->cam.position.y; cd.eye[2] = gen->cam.position.z;
+		cd.viewdir[0] = gen->viewdir.x; cd.viewdir[1] = gen->viewdir.y; cd.viewdir[2] = gen->viewdir.z;
+		cd.updir[0] = gen->updir.x; cd.updir[1] = gen->updir.y; cd.updir[2] = gen->updir.z;
+		// FNV-1a over everything tutu_hip_create reads
+		uint64_t h = 1469598103934665603ull;
+		auto mix = [&h](const void* p, size_t bytes) {
+			const unsigned char* b = static_cast<const unsigned char*>(p);
+			for (size_t k = 0; k < bytes; k++) {
+				h ^= b[k];
+				h *= 1099511628211ull;
+			}
+		};
+		mix(f.verts.data(), f.verts.size() * 4); mix(f.normals.data(), f.normals.size() * 4);
+		mix(f.mat_id.data(), f.mat_id.size() * 4); mix(f.mats.data(), f.mats.size() * sizeof(TutuMaterial));
+		mix(f.spheres.data(), f.spheres.size() * 4); mix(f.sphere_mat.data(), f.sphere_mat.size() * 4);
+		mix(f.sphere_tex.data(), f.sphere_tex.size() * 4); mix(f.sphere_pos.data(), f.sphere_pos.size() * 4);
+		mix(&sd.eta, 4); mix(sd.bkg, 12);
+		if (f.any_texture) {
+			mix(f.uvs.data(), f.uvs.size() * 4); mix(f.tex_ids.data(), f.tex_ids.size() * 4);
+			for (int k = 0; k < 4; k++)
+				for (const TutuTexture& t : f.maps[k]) {
+					mix(&t.width, 4); mix(&t.height, 4);
+					if (t.rgb) mix(t.rgb, (size_t)t.width * (size_t)t.height * 12);
+				}
+		}
+		f.hash = h;
+	}
+
+	virtual void integrate(PPMGenerator* gen) {
+		FlatScene f;
+		flatten(gen, f);
+		TutuCameraFrame cf;
+		int rc = tutu_camera_frame(&f.cd, &cf);
+		if (rc != TUTU_OK) die(rc, "tutu_camera_frame");
+		if (ctxs.empty() || f.hash != scene_hash) {
+			release();
+			int ndev = 0;
+			rc = tutu_hip_device_count(&ndev);
+			if (rc != TUTU_OK || ndev <= 0) die(rc != TUTU_OK ? rc : TUTU_E_NO_DEVICE, "tutu_hip_device_count");
+			const int want = TUTU_GPUS > 0 ? TUTU_GPUS : ndev;
+			for (int k = 0; k < want; k++) {
+				TutuCtx* c = nullptr;
+				rc = tutu_hip_create(&f.sd, k % ndev, &c);
+				if (rc != TUTU_OK) die(rc, "tutu_hip_create");
+				ctxs.push_back(c);
+			}
+			scene_hash = f.hash;
+			contexts_built++;
+		}
+		TutuRenderParams rp;
+		std::memset(&rp, 0, sizeof(rp));
+		rp.spp = SPP;  // global.hpp:19
+		rp.key0 = TUTU_SEED0;
+		rp.key1 = TUTU_SEED1;
+		rp.x0 = 0; rp.y0 = 0; rp.x1 = gen->width; rp.y1 = gen->height;
+		rp.spp_per_pass = TUTU_SPP_PER_PASS;
+		static_assert(sizeof(Vector3f) == 3 * sizeof(float), "Vector3f must be three packed floats");
+		float* frame = &gen->cam.FrameBuffer.rgb[0].x;  // straight into the reference's framebuffer (Texture.hpp:15)
+		std::vector<TutuStats> st(ctxs.size());
+		if (ctxs.size() == 1) rc = tutu_hip_render(ctxs[0], &cf, &rp, frame, st.data());
+		else rc = tutu_hip_render_multi(ctxs.data(), (int32_t)ctxs.size(), &cf, &rp, frame, st.data());
+		if (rc != TUTU_OK) die(rc, "tutu_hip_render");
+		stats = st[0];
+	}
+
+	void release() {
+		for (TutuCtx* c : ctxs) tutu_hip_destroy(c);
+		ctxs.clear();
+	}
+
+private:
+	std::vector<TutuCtx*> ctxs;
+	uint64_t scene_hash = 0;
+	[[noreturn]] static void die(int rc, const char* what) {
+		std::cout << "ERROR: " << what << ": " << tutu_hip_error_string(rc) << " " << tutu_hip_last_error()
+		          << "\n(the GPU PathTracing integrator has no host fallback)\n";
+		exit(-1);
+	}
+};
