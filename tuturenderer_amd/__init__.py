@@ -274,7 +274,7 @@ class Context:
         _check(self.lib.tutu_hip_set_option(self.h, C.c_char_p(name.encode()), C.c_int(int(value))), "tutu_hip_set_option")
 
     OPTION_NAMES = ("sets", "sets_default", "one_set", "shade_bpc", "trace_bpc", "refill_min", "inner_steps", "any_near_first",
-                    "util_stats", "sah_tree", "lds_scene", "shade_tab")
+                    "util_stats", "sah_tree", "n_refs", "lds_scene", "shade_tab")
 
     def get_option(self, name):
         v = C.c_int(0)

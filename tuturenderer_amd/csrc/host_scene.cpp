@@ -281,6 +281,109 @@ struct SahBuilder {
 	}
 };
 
+
+// ---- early split clipping of sliver / tilted triangles ----------------------------------------------------------
+// An object-split SAH tree cannot separate long thin primitives that lie at an angle to the axes: the box of a
+// bristle-like triangle is mostly empty, the boxes of neighbouring bristles overlap, and a ray that passes NEAR a
+// bristle has to test it (broom stand-in of BASELINE config 4: 101 triangle tests per ray).  So before the tree is
+// built such a triangle is given SEVERAL references: it is clipped (in double precision, Sutherland-Hodgman against
+// the two halves of its box, recursively) into pieces with tight boxes, and every piece becomes a leaf of the walked
+// tree that points to the SAME object.  Exactness is untouched: a leaf only says "test this object"; whether the
+// object is hit is still decided by the reference's triangle test and its own leaf box (device_trace.h), and hitting
+// the same object through two leaves updates (t, index) idempotently.
+// Criterion: a piece is cut at the middle of its box's longest axis when the two halves' boxes together have at most
+// kSplitGain of its box's surface area.  Cutting a compact triangle (axis-aligned or not) leaves ~0.75 -- not worth a
+// reference; cutting a sliver that runs diagonally through its box leaves ~0.5, again and again until the pieces are
+// as long as the sliver is wide.  At most kMaxPiecesPerTri pieces per triangle.  Piece boxes are padded by a few 1e-6
+// of the scene's size, far more than the rounding of the clip arithmetic and of the reference's own hit points.
+struct Ref {
+	Box box;
+	int32_t obj;
+};
+struct Poly {
+	int n;
+	double p[12][3];
+};
+static double poly_area(const Poly& q) {
+	double ax = 0, ay = 0, az = 0;
+	for (int i = 1; i + 1 < q.n; i++) {
+		const double e1[3] = {q.p[i][0] - q.p[0][0], q.p[i][1] - q.p[0][1], q.p[i][2] - q.p[0][2]};
+		const double e2[3] = {q.p[i + 1][0] - q.p[0][0], q.p[i + 1][1] - q.p[0][1], q.p[i + 1][2] - q.p[0][2]};
+		ax += e1[1] * e2[2] - e1[2] * e2[1];
+		ay += e1[2] * e2[0] - e1[0] * e2[2];
+		az += e1[0] * e2[1] - e1[1] * e2[0];
+	}
+	return 0.5 * std::sqrt(ax * ax + ay * ay + az * az);
+}
+// the part of q with coordinate `axis` <= plane (keep_low) or >= plane
+static Poly poly_clip(const Poly& q, int axis, double plane, bool keep_low) {
+	Poly r;
+	r.n = 0;
+	for (int i = 0; i < q.n; i++) {
+		const double* a = q.p[i];
+		const double* b = q.p[(i + 1) % q.n];
+		const double da = keep_low ? plane - a[axis] : a[axis] - plane;
+		const double db = keep_low ? plane - b[axis] : b[axis] - plane;
+		if (da >= 0 && r.n < 12) memcpy(r.p[r.n++], a, 24);
+		if ((da > 0 && db < 0) || (da < 0 && db > 0)) {
+			const double t = da / (da - db);
+			if (r.n < 12) {
+				for (int k = 0; k < 3; k++) r.p[r.n][k] = a[k] + t * (b[k] - a[k]);
+				r.p[r.n][axis] = plane;
+				r.n++;
+			}
+		}
+	}
+	return r;
+}
+static void poly_bounds(const Poly& q, double lo[3], double hi[3]) {
+	for (int k = 0; k < 3; k++) lo[k] = hi[k] = q.p[0][k];
+	for (int i = 1; i < q.n; i++)
+		for (int k = 0; k < 3; k++) {
+			lo[k] = std::min(lo[k], q.p[i][k]);
+			hi[k] = std::max(hi[k], q.p[i][k]);
+		}
+}
+static const double kSplitGain = 0.66;
+static const int kMaxPiecesPerTri = 64;
+static double box_half_area(const double lo[3], const double hi[3]) {
+	const double d[3] = {hi[0] - lo[0], hi[1] - lo[1], hi[2] - lo[2]};
+	return d[0] * d[1] + d[1] * d[2] + d[2] * d[0];
+}
+static void split_piece(const Poly& q, int budget, double pad, int32_t obj, std::vector<Ref>& out) {
+	double lo[3], hi[3];
+	poly_bounds(q, lo, hi);
+	const double d[3] = {hi[0] - lo[0], hi[1] - lo[1], hi[2] - lo[2]};
+	const double half_area = box_half_area(lo, hi);
+	int axis = 0;
+	for (int k = 1; k < 3; k++)
+		if (d[k] > d[axis]) axis = k;
+	if (budget >= 2 && half_area > 0 && d[axis] > 64 * pad) {
+		const double mid = 0.5 * (lo[axis] + hi[axis]);
+		const Poly a = poly_clip(q, axis, mid, true), b = poly_clip(q, axis, mid, false);
+		if (a.n >= 3 && b.n >= 3) {
+			double la[3], ha[3], lb[3], hb[3];
+			poly_bounds(a, la, ha);
+			poly_bounds(b, lb, hb);
+			if (box_half_area(la, ha) + box_half_area(lb, hb) <= kSplitGain * half_area) {
+				split_piece(a, budget / 2, pad, obj, out);
+				split_piece(b, budget - budget / 2, pad, obj, out);
+				return;
+			}
+		}
+	}
+	Ref r;
+	r.obj = obj;
+	for (int k = 0; k < 3; k++) {
+		r.box.mn[k] = (float)(lo[k] - pad);
+		r.box.mx[k] = (float)(hi[k] + pad);
+		// rounding to float must not move the planes inwards
+		if ((double)r.box.mn[k] > lo[k] - 0.5 * pad) r.box.mn[k] = std::nextafterf(r.box.mn[k], -INFINITY);
+		if ((double)r.box.mx[k] < hi[k] + 0.5 * pad) r.box.mx[k] = std::nextafterf(r.box.mx[k], INFINITY);
+	}
+	out.push_back(r);
+}
+
 int build_sah_tree(const std::vector<Box>& tb, std::vector<BuildNode>& out, uint32_t* depth) {
 	out.clear();
 	if (depth) *depth = 0;
@@ -435,10 +538,42 @@ int build_host_scene(const TutuSceneDesc* d, HostScene& hs) {
 	const bool want_sah = n > 2 && !getenv("TUTU_NO_SAH");
 	hs.has_fast_tree = false;
 	if (want_sah) {
+		// references: one per object, several for sliver / tilted triangles (early split clipping, above)
+		std::vector<Ref> refs;
+		refs.reserve(n);
+		const bool presplit = !getenv("TUTU_NO_PRESPLIT");
+		double diag = 0;
+		if (!tree.empty())
+			for (int k = 0; k < 3; k++) diag = std::max(diag, (double)tree[0].pmax[k] - (double)tree[0].pmin[k]);
+		const double pad = 4e-6 * diag;
+		for (uint32_t o = 0; o < n; o++) {
+			if (obj_sph[o] >= 0 || !presplit) {
+				refs.push_back(Ref{tb[o], (int32_t)o});
+				continue;
+			}
+			const float* v = d->verts + 9 * (size_t)obj_tri[o];
+			bool finite = true;
+			for (int k = 0; k < 9; k++) finite = finite && std::isfinite(v[k]);
+			Poly q;
+			q.n = 3;
+			for (int i = 0; i < 3; i++)
+				for (int k = 0; k < 3; k++) q.p[i][k] = v[3 * i + k];
+			const size_t before = refs.size();
+			if (finite) split_piece(q, kMaxPiecesPerTri, pad, (int32_t)o, refs);
+			if (refs.size() == before + 1 || !finite) {  // not split: keep the object's own box (exactly the reference's leaf box)
+				refs.resize(before);
+				refs.push_back(Ref{tb[o], (int32_t)o});
+			}
+		}
+		std::vector<Box> rb(refs.size());
+		for (size_t i = 0; i < refs.size(); i++) rb[i] = refs[i].box;
+		hs.n_refs = (uint32_t)refs.size();
 		std::vector<BuildNode> sah;
 		uint32_t sah_depth = 0;
-		rc = build_sah_tree(tb, sah, &sah_depth);
+		rc = build_sah_tree(rb, sah, &sah_depth);
 		if (rc != TUTU_OK) return rc;
+		for (BuildNode& bn : sah)
+			if (bn.tri >= 0) bn.tri = refs[(size_t)bn.tri].obj;  // a leaf says which OBJECT to test
 		if (sah_depth <= TUTU_MAX_BVH_DEPTH) {
 			hs.root_ref = flatten(sah);
 			hs.n_fast_inner = (int32_t)hs.nodes.size();

@@ -101,6 +101,7 @@ struct HostScene {
 	bool has_fast_tree = false;  // root_ref is the SAH tree (else both roots are the reference tree)
 	int32_t n_fast_inner = 0;    // nodes [0, n_fast_inner) belong to the walked tree
 	uint32_t fast_depth = 0, ref_depth = 0;
+	uint32_t n_refs = 0;         // leaves of the walked tree (>= objects: sliver triangles get several references)
 	std::vector<float> leaf_boxes;  // [leaf][8]: min xyz pad, max xyz pad -- the reference's leaf boxes
 	uint32_t depth;  // max over both trees: sizes the traversal stack
 	float eta;

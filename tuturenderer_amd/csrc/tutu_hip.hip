@@ -775,6 +775,10 @@ int tutu_hip_get_option(TutuCtx* c, const char* name, int* value) {
 		*value = c->hs.has_fast_tree ? 1 : 0;
 		return TUTU_OK;
 	}
+	if (strcmp(name, "n_refs") == 0) {  // leaves of the walked tree (sliver triangles get several references)
+		*value = (int)c->hs.n_refs;
+		return TUTU_OK;
+	}
 	if (strcmp(name, "lds_scene") == 0) {
 		*value = c->lds_scene ? 1 : 0;
 		return TUTU_OK;
