@@ -266,6 +266,14 @@ def main():
                                    "the timed region (N > 1 or --no-extras: launches of several passes overlap, durations include shared time)",
                     "lds_scene": lds_scene,
                     "measured_per_ray": {"N_closest": n_c, "T_closest": t_c, "N_shadow": n_s, "T_shadow": t_s},
+                    "traversal": {
+                        "closest_Grays_per_s": src["k_trace_closest"]["units"] / max(src["k_trace_closest"]["ms"], 1e-9) / 1e6,
+                        "any_Grays_per_s": src["k_trace_any"]["units"] / max(src["k_trace_any"]["ms"], 1e-9) / 1e6,
+                        "lanes_active_node_step_closest": agg["nodes_closest"] / max(64 * agg["wave_node_steps_closest"], 1),
+                        "lanes_active_leaf_step_closest": agg["leaves_closest"] / max(64 * agg["wave_leaf_steps_closest"], 1),
+                        "lanes_active_node_step_any": agg["nodes_any"] / max(64 * agg["wave_node_steps_any"], 1),
+                        "lanes_active_leaf_step_any": agg["leaves_any"] / max(64 * agg["wave_leaf_steps_any"], 1),
+                        "note": "G rays/s of the kernel alone (exclusive step); lanes_active = share of a wave's 64 lanes with work in a step"},
                     "per_kernel": {k: dict(priced(src, k), algorithmic_bytes_per_unit=per_unit[k], hbm_bytes_per_unit=hbm_unit[k]) for k in src}}
         if excl is not None:
             roofline["exclusive_step_ms"] = excl["ms_total"]

@@ -155,6 +155,9 @@ typedef struct TutuStats {
 	uint64_t nodes_closest, leaves_closest, nodes_any, leaves_any;
 	uint32_t spp_per_pass; /* samples per pixel of a full wavefront pass of this call (the last pass may be shorter) */
 	uint32_t n_sets;       /* passes that were in flight at once */
+	/* how often a WAVE of the traversal kernels executed its inner-node step / its leaf step: nodes_* (without the leaves)
+	 * / (64 * wave_node_steps_*) = the fraction of lanes that had a node to test in such a step */
+	uint64_t wave_node_steps_closest, wave_leaf_steps_closest, wave_node_steps_any, wave_leaf_steps_any;
 } TutuStats;
 
 typedef struct TutuHit {

@@ -1,11 +1,13 @@
 #!/usr/bin/env python3
-"""HBM traffic per launch of the three pipeline stages, from rocprofv3 --pmc passes (profiles/run_pmc.sh).
+"""HBM traffic of the pipeline's kernels from rocprofv3 --pmc passes (profiles/run_pmc.sh), stored PER UNIT (per shaded
+vertex / per ray) together with the config and pass size they were collected at -- bench.py refuses them for any other.
 
-    python profiles/make_traffic.py gpurun_out/pmc_<tag>  ->  profiles/traffic.json
+    python profiles/make_traffic.py gpurun_out/pmc_<tag>_<config> <tag> <config>   ->  updates profiles/traffic.json
 
-Corrections per /opt/skills/guides/MI355X_MICROARCH.md (section HBM): FETCH_SIZE and WRITE_SIZE are in KiB;
-on gfx950 FETCH_SIZE reports half the bytes of wide (16 B/lane) coalesced reads, so it is doubled; WRITE_SIZE is
-exact for 16 B/lane stores.  The record arrays of this pipeline are read and written as dwordx4 per lane."""
+Corrections per /opt/skills/guides/MI355X_MICROARCH.md (section HBM): FETCH_SIZE and WRITE_SIZE are in KiB; on gfx950
+FETCH_SIZE reports half the bytes of wide (16 B/lane) coalesced reads, so it is doubled; WRITE_SIZE is exact for
+16 B/lane stores.  The record arrays of this pipeline are read and written as dwordx4 per lane.  Units per kernel come
+from the bench line of the same run (g2.log): extension rays for k_trace_closest and k_shade, shadow rays for k_trace_any."""
 import csv
 import glob
 import json
@@ -18,13 +20,16 @@ def stage(name):
     if "k_trace<" in name:
         params = name.split("k_trace<")[1].split(">")[0].replace(" ", "").split(",")  # <LDS_SCENE, ANY, SPH>
         return "k_trace_any" if params[1] == "true" else "k_trace_closest"
-    if "k_shade<" in name:  # the per-material-class launches at depth >= 1 (MODE 1..4); depth 0 and connect-only are separate
+    if "k_shade<" in name:  # the stage launches at depth >= 1 (MODE 1..4, 6); depth 0 (MODE 0) and connect-only (MODE 5) are separate
         mode = name.split("k_shade<")[1].split(",")[0].strip()
-        return "k_shade" if mode in ("1", "2", "3", "4") else None
+        return {"0": "k_shade_depth0", "5": "k_shade_connect_only"}.get(mode, "k_shade")
+    for k in ("k_list_count", "k_list_scan", "k_list_scatter", "k_resolve", "k_finalize", "k_primary"):
+        if k in name:
+            return "other"
     return None
 
 
-def main(root):
+def main(root, tag, cfg):
     val = defaultdict(lambda: defaultdict(float))
     disp = defaultdict(lambda: defaultdict(set))
     for f in glob.glob(f"{root}/g*/**/*counter_collection.csv", recursive=True):
@@ -33,17 +38,34 @@ def main(root):
             if st and row["Counter_Name"] in ("FETCH_SIZE", "WRITE_SIZE"):
                 val[st][row["Counter_Name"]] += float(row["Counter_Value"])
                 disp[st][row["Counter_Name"]].add(row["Dispatch_Id"])
-    out = {}
+    line = json.loads([x for x in open(f"{root}/g2.log") if x.startswith("{")][0])
+    pk = line["roofline"]["per_kernel"]
+    units = {k: pk[k]["units_per_launch"] * pk[k]["launches"] for k in pk}
+    samples = line["value"] * 1e6 * line["ms_per_step"] * 1e-3 * line["steps"]
+    kernels, total = {}, 0.0
     for st in val:
-        n = max(len(v) for v in disp[st].values())
         fetch = 2.0 * val[st]["FETCH_SIZE"] * 1024.0
         write = val[st]["WRITE_SIZE"] * 1024.0
-        out[st] = {"bytes_per_launch": (fetch + write) / n, "launches_profiled": n, "fetch_bytes_corrected": fetch, "write_bytes": write,
-                   "note": "FETCH_SIZE x2 (gfx950 wide-read correction) + WRITE_SIZE, KiB -> bytes, averaged over the profiled launches"}
+        total += fetch + write
+        n = max(len(v) for v in disp[st].values())
+        e = {"launches_profiled": n, "fetch_bytes_x2": fetch, "write_bytes": write, "hbm_bytes_per_launch": (fetch + write) / n}
+        if st in units and units[st] > 0:
+            e["units"] = units[st]
+            e["hbm_bytes_per_unit"] = (fetch + write) / units[st]
+        kernels[st] = e
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "traffic.json")
+    try:
+        out = json.load(open(path))
+        if not all(isinstance(v, dict) and "kernels" in v for v in out.values()):
+            out = {}
+    except (OSError, ValueError):
+        out = {}
+    out[cfg] = {"tag": tag, "config": cfg, "spp": line["config"]["workload"], "spp_per_pass": line["config"]["spp_per_pass"],
+                "samples": samples, "hbm_bytes_per_sample": total / samples, "kernels": kernels,
+                "note": "FETCH_SIZE x2 (gfx950 wide-read correction) + WRITE_SIZE, KiB -> bytes; per unit = / the run's own ray counts"}
     json.dump(out, open(path, "w"), indent=1, sort_keys=True)
-    print(json.dumps(out, indent=1))
+    print(json.dumps(out[cfg], indent=1))
 
 
 if __name__ == "__main__":
-    main(sys.argv[1])
+    main(sys.argv[1], sys.argv[2], sys.argv[3])

@@ -1,17 +1,14 @@
 #!/bin/bash
-# Copy the artefacts of `bash profiles/collect.sh <tag>` (merged back under gpurun_out/) into profiles/, replacing the
-# ones of <old-tag>:   bash profiles/publish.sh <tag> [old-tag]
+# Copy the artefacts of `bash profiles/collect.sh <tag>` (merged back under gpurun_out/) into profiles/:  bash profiles/publish.sh <tag>
 set -e
-TAG=$1; OLD=$2
+TAG=$1
 R=$(cd "$(dirname "$0")/.." && pwd)
 O=$R/gpurun_out/$TAG
-[ -n "$OLD" ] && rm -f $R/profiles/${OLD}_*
-cp $O/bench_line.json $R/profiles/${TAG}_bench_line.json
+for c in c1 c2 c3 c4 c5; do cp $O/bench_line_$c.json $R/profiles/${TAG}_bench_line_$c.json; done
 cp $O/bench_line_under_rocprof.json $R/profiles/${TAG}_bench_line_under_rocprof.json
 cp $O/gpu_tests.log $R/profiles/${TAG}_gpu_tests.log
-cp $O/scenes.jsonl $R/profiles/${TAG}_scenes.jsonl
 cp $(find $O/rocprof -name "*kernel_stats.csv" | head -1) $R/profiles/${TAG}_bench_kernel_stats.csv
 cp $(find $O/rocprof_exclusive -name "*kernel_stats.csv" | head -1) $R/profiles/${TAG}_bench_exclusive_kernel_stats.csv
-python3 $R/profiles/pmc_summary.py $R/gpurun_out/pmc_$TAG > $R/profiles/${TAG}_pmc_summary.json
-python3 $R/profiles/make_traffic.py $R/gpurun_out/pmc_$TAG > /dev/null
+python3 $R/profiles/pmc_summary.py $R/gpurun_out/pmc_${TAG}_c2 > $R/profiles/${TAG}_pmc_summary_c2.json
+python3 $R/profiles/make_traffic.py $R/gpurun_out/pmc_${TAG}_c2 $TAG c2 > /dev/null
 ls $R/profiles/${TAG}_*

@@ -119,7 +119,9 @@ class Stats(C.Structure):
                 ("ms_trace_any", C.c_float), ("ms_shade", C.c_float), ("ms_other", C.c_float), ("ms_shade_first", C.c_float),
                 ("ms_shade_material", C.c_float), ("ms_shade_terminal", C.c_float), ("shade_material_launches", C.c_uint32),
                 ("nodes_closest", C.c_uint64), ("leaves_closest", C.c_uint64), ("nodes_any", C.c_uint64), ("leaves_any", C.c_uint64),
-                ("spp_per_pass", C.c_uint32), ("n_sets", C.c_uint32)]
+                ("spp_per_pass", C.c_uint32), ("n_sets", C.c_uint32),
+                ("wave_node_steps_closest", C.c_uint64), ("wave_leaf_steps_closest", C.c_uint64),
+                ("wave_node_steps_any", C.c_uint64), ("wave_leaf_steps_any", C.c_uint64)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

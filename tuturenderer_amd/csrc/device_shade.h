@@ -661,11 +661,11 @@ struct TraceParams {
 	const uint8_t* tri_class;  // per triangle (leaf order): class of its material
 	int stack_entries;
 	// work counters, per block: [block][0] nodes entered, [1] leaf tests (SURVEY.md 8(d)'s N and T, measured on the tree
-	// that is actually walked).  Plain read-modify-write by one thread per block; each work set has its own array.
+	// that is actually walked), [2] / [3] wave-level inner-node / leaf steps.  Plain read-modify-write by one thread per
+	// block and counter; each work set has its own array.
 	unsigned long long* part;
 	int refill_min;  // idle lanes a wave waits for before it fetches new rays (1 = refill at once)
 	int inner_steps;  // node visits between two leaf / finish / refill rounds
-	unsigned long long* util;  // optional [3]: wave-level node steps, leaf steps, outer iterations (TUTU_UTIL_STATS)
 	int any_near_first;  // any-hit: descend into the nearer child first
 };
 
@@ -690,7 +690,7 @@ TUTU_DEV void trace_persistent(const S& ss, const TraceParams& tp, int* stack, c
 	int best_tri = -1;
 	bool validate = false;  // this lane walks the SAH tree: candidates are checked against the reference's leaf box
 	uint32_t n_nodes = 0, n_leaves = 0;  // work counters of this lane
-	uint32_t w_node_steps = 0, w_leaf_steps = 0, w_outer = 0;  // wave-uniform: how often each phase ran (TUTU_UTIL_STATS)
+	uint32_t w_node_steps = 0, w_leaf_steps = 0;  // wave-uniform: how often each phase ran
 	// any-hit only
 	float dis = 0.f;
 	float4 Lpre = make_float4(0.f, 0.f, 0.f, 0.f);  // TUTU_KEY_FINAL requests: the path's radiance | home slot and the
@@ -780,7 +780,6 @@ TUTU_DEV void trace_persistent(const S& ss, const TraceParams& tp, int* stack, c
 		{
 			const bool has_pend = pend != TUTU_TRAV_IDLE;
 			const bool on_leaf = cur < 0 && cur > TUTU_TRAV_IDLE;
-			w_outer++;
 			if (__ballot(has_pend || on_leaf) != 0ull) w_leaf_steps++;
 			if (has_pend || on_leaf) {
 				n_leaves++;
@@ -833,30 +832,26 @@ TUTU_DEV void trace_persistent(const S& ss, const TraceParams& tp, int* stack, c
 			cur = TUTU_TRAV_IDLE;
 		}
 	}
-	// work counters: wave sum, then one plain add per wave leader into this block's slots (waves of a block take turns)
+	// work counters: wave sum, then one plain add per block into this block's own slots (no global atomics: a counter word
+	// shared by all waves sustains ~88 atomics/us and would cost more than the traversal).  [0] nodes entered, [1] leaf
+	// tests, [2] how often a wave ran its inner-node step, [3] its leaf step.
 	if (tp.part) {
 		unsigned long long a = n_nodes, b = n_leaves;
 		for (int off = 32; off > 0; off >>= 1) {
 			a += __shfl_xor(a, off);
 			b += __shfl_xor(b, off);
 		}
-		__shared__ unsigned long long acc[2];
-		if (threadIdx.x == 0) acc[0] = acc[1] = 0ull;
+		__shared__ unsigned long long acc[4];
+		if (threadIdx.x < 4) acc[threadIdx.x] = 0ull;
 		__syncthreads();
 		if (lane == 0) {
 			atomicAdd(&acc[0], a);
 			atomicAdd(&acc[1], b);
+			atomicAdd(&acc[2], (unsigned long long)w_node_steps);
+			atomicAdd(&acc[3], (unsigned long long)w_leaf_steps);
 		}
 		__syncthreads();
-		if (threadIdx.x == 0) {
-			tp.part[2 * blockIdx.x + 0] += acc[0];
-			tp.part[2 * blockIdx.x + 1] += acc[1];
-		}
-		if (tp.util && lane == 0) {  // profiling aid: phase executions per wave
-			atomicAdd(&tp.util[0], (unsigned long long)w_node_steps);
-			atomicAdd(&tp.util[1], (unsigned long long)w_leaf_steps);
-			atomicAdd(&tp.util[2], (unsigned long long)w_outer);
-		}
+		if (threadIdx.x < 4) tp.part[4 * blockIdx.x + threadIdx.x] += acc[threadIdx.x];
 	}
 }
 

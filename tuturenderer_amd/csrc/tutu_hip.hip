@@ -212,7 +212,7 @@ int ensure_set(WorkSet& w, size_t want_slots) {
 		w.cap = cap;
 	}
 	if ((rc = w.list_meta.ensure(TUTU_META_STRIDE * (TUTU_MAX_DEPTH + 3))) != TUTU_OK) return rc;
-	if ((rc = w.part.ensure(2 * TUTU_PART_BLOCKS * 2 + 8)) != TUTU_OK) return rc;
+	if ((rc = w.part.ensure(2 * TUTU_PART_BLOCKS * 4)) != TUTU_OK) return rc;
 	if (!w.ev_resolved) HIP_TRY(hipEventCreateWithFlags(&w.ev_resolved, hipEventDisableTiming));
 	return TUTU_OK;
 }
@@ -395,13 +395,11 @@ int run_pass(TutuCtx* c, WorkSet& w, hipStream_t s, const TutuCameraFrame* cam, 
 		tp.inner_steps = c->knobs.inner_steps;
 		tp.any_near_first = c->knobs.any_near_first;
 		tp.part = w.part.p;
-		tp.util = c->knobs.util_stats ? w.part.p + 4 * TUTU_PART_BLOCKS : nullptr;
 		TIMED(EV_TRACE_CLOSEST, launch_trace<false>(c, s, trace_grid, tp));
 		(*n_trace_launches)++;
 		tp.list = w.lists.p + w.cap;
 		tp.n_ptr = meta + 1;
-		tp.part = w.part.p + 2 * TUTU_PART_BLOCKS;
-		if (tp.util) tp.util += 4;
+		tp.part = w.part.p + 4 * TUTU_PART_BLOCKS;
 		TIMED(EV_TRACE_ANY, launch_trace<true>(c, s, trace_grid, tp));
 	}
 	return TUTU_OK;
@@ -444,25 +442,27 @@ int collect_stats(TutuCtx* c, hipStream_t s, TutuStats* st, uint64_t samples, ui
 	st->passes = passes;
 	st->trace_launches = trace_launches;
 	{
-		std::vector<unsigned long long> h(2 * TUTU_PART_BLOCKS * 2 + 8);
-		unsigned long long util[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+		std::vector<unsigned long long> h(2 * TUTU_PART_BLOCKS * 4);
 		for (int k = 0; k < TUTU_MAX_SETS; k++) {
 			if (!c->ws[k].part.p) continue;
 			HIP_TRY(hipMemcpy(h.data(), c->ws[k].part.p, sizeof(unsigned long long) * h.size(), hipMemcpyDeviceToHost));
 			for (int b = 0; b < TUTU_PART_BLOCKS; b++) {
-				st->nodes_closest += h[2 * b];
-				st->leaves_closest += h[2 * b + 1];
-				st->nodes_any += h[2 * TUTU_PART_BLOCKS + 2 * b];
-				st->leaves_any += h[2 * TUTU_PART_BLOCKS + 2 * b + 1];
+				st->nodes_closest += h[4 * b];
+				st->leaves_closest += h[4 * b + 1];
+				st->wave_node_steps_closest += h[4 * b + 2];
+				st->wave_leaf_steps_closest += h[4 * b + 3];
+				st->nodes_any += h[4 * TUTU_PART_BLOCKS + 4 * b];
+				st->leaves_any += h[4 * TUTU_PART_BLOCKS + 4 * b + 1];
+				st->wave_node_steps_any += h[4 * TUTU_PART_BLOCKS + 4 * b + 2];
+				st->wave_leaf_steps_any += h[4 * TUTU_PART_BLOCKS + 4 * b + 3];
 			}
-			for (int j = 0; j < 8; j++) util[j] += h[4 * TUTU_PART_BLOCKS + j];
 		}
 		if (c->knobs.util_stats)
-			fprintf(stderr, "[tutu util] closest: lanes/node-step %.1f lanes/leaf-step %.1f node-steps/outer %.2f leaf-steps/outer %.2f | any: %.1f %.1f %.2f %.2f\n",
-			        util[0] ? (double)st->nodes_closest / util[0] : 0.0, util[1] ? (double)st->leaves_closest / util[1] : 0.0,
-			        util[2] ? (double)util[0] / util[2] : 0.0, util[2] ? (double)util[1] / util[2] : 0.0,
-			        util[4] ? (double)st->nodes_any / util[4] : 0.0, util[5] ? (double)st->leaves_any / util[5] : 0.0,
-			        util[6] ? (double)util[4] / util[6] : 0.0, util[6] ? (double)util[5] / util[6] : 0.0);
+			fprintf(stderr, "[tutu util] closest: lanes/node-step %.1f lanes/leaf-step %.1f | any: %.1f %.1f\n",
+			        st->wave_node_steps_closest ? (double)st->nodes_closest / st->wave_node_steps_closest : 0.0,
+			        st->wave_leaf_steps_closest ? (double)st->leaves_closest / st->wave_leaf_steps_closest : 0.0,
+			        st->wave_node_steps_any ? (double)st->nodes_any / st->wave_node_steps_any : 0.0,
+			        st->wave_leaf_steps_any ? (double)st->leaves_any / st->wave_leaf_steps_any : 0.0);
 	}
 	float ms[EV_NKIND] = {0, 0, 0, 0, 0, 0};
 	uint32_t launches[EV_NKIND] = {0, 0, 0, 0, 0, 0};
@@ -537,7 +537,7 @@ int render_impl(TutuCtx* c, const TutuCameraFrame* cam, const TutuRenderParams* 
 	c->ev_used = 0;
 	HIP_TRY(hipMemsetAsync(c->totals.p, 0, sizeof(Totals), s));
 	for (int k = 0; k < TUTU_MAX_SETS; k++)
-		if (c->ws[k].part.p) HIP_TRY(hipMemsetAsync(c->ws[k].part.p, 0, sizeof(unsigned long long) * (2 * TUTU_PART_BLOCKS * 2 + 8), s));
+		if (c->ws[k].part.p) HIP_TRY(hipMemsetAsync(c->ws[k].part.p, 0, sizeof(unsigned long long) * (2 * TUTU_PART_BLOCKS * 4), s));
 	if ((rc = launch_primary(c, s, cam, npix, d_pixels, nullptr, x0, y0, rect_w)) != TUTU_OK) return rc;
 	HIP_TRY(hipMemsetAsync(c->accum.p, 0, sizeof(float4) * (size_t)npix, s));
 	hipStream_t streams[TUTU_MAX_SETS];
@@ -928,7 +928,7 @@ int tutu_hip_trace_samples(TutuCtx* c, const TutuCameraFrame* cam, uint32_t n, c
 	c->ev_used = 0;
 	HIP_TRY(hipMemsetAsync(c->totals.p, 0, sizeof(Totals), s));
 	for (int k = 0; k < TUTU_MAX_SETS; k++)
-		if (c->ws[k].part.p) HIP_TRY(hipMemsetAsync(c->ws[k].part.p, 0, sizeof(unsigned long long) * (2 * TUTU_PART_BLOCKS * 2 + 8), s));
+		if (c->ws[k].part.p) HIP_TRY(hipMemsetAsync(c->ws[k].part.p, 0, sizeof(unsigned long long) * (2 * TUTU_PART_BLOCKS * 4), s));
 	if ((rc = launch_primary(c, s, cam, (int)n, nullptr, c->u32a.p, 0, 0, 1)) != TUTU_OK) return rc;
 	uint32_t tl = 0;
 	if ((rc = run_pass(c, c->ws[0], s, cam, key0, key1, (int)n, 0, 1, c->u32b.p, &tl)) != TUTU_OK) return rc;
@@ -1177,7 +1177,6 @@ static int run_trace_kernel(TutuCtx* c, uint32_t n, bool any) {
 	tp.refill_min = 1;
 	tp.inner_steps = TUTU_INNER_STEPS;
 	tp.any_near_first = 1;
-	tp.util = nullptr;
 	const int grid = persistent_grid(n, c->n_cu, c->trace_blocks_per_cu);
 	if (any) launch_trace<true>(c, s, grid, tp);
 	else launch_trace<false>(c, s, grid, tp);
