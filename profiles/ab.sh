@@ -1,8 +1,11 @@
 #!/bin/bash
-# A/B of two builds on the same box: profiles/ab.sh <base.so> <new.so> [reps]   (one-set kernel times + overlapped value)
-B=$1; N=$2; REPS=${3:-2}
-for rep in $(seq $REPS); do for lib in $B $N; do
-  one=$(TUTU_HIP_LIB=$lib TUTU_ONE_SET=1 python bench.py --steps 2 --warmup 1 --no-cpu-baseline 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); k=d['roofline']['kernel_ms_per_step']; print(round(d['value'],1), {a:round(b,1) for a,b in k.items()})")
-  ovl=$(TUTU_HIP_LIB=$lib python bench.py --steps 4 --warmup 1 --no-cpu-baseline 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(round(d['value'],1))")
-  echo "$(basename $lib) overlapped=$ovl one_set=$one"
-done; done
+# A/B of two builds on the SAME box (boxes differ by up to 12 %, runs on one box by ~1 %):
+#   profiles/ab.sh <base.so> <new.so> [reps] [configs...]      prints bench summaries, alternating the libraries
+B=$1; N=$2; REPS=${3:-2}; shift 3
+CFGS=${@:-c2}
+O=gpurun_out/ab; mkdir -p $O
+for rep in $(seq $REPS); do for c in $CFGS; do for lib in $B $N; do
+  tag=$(basename $lib .so)_${c}_r$rep
+  TUTU_HIP_LIB=$lib timeout -k 10 300 python bench.py --config $c --steps 3 --warmup 1 --no-cpu-baseline > $O/$tag.log 2>&1
+  python profiles/summarize_bench.py $O/$tag.log | sed "s#^$O/##" | cut -c1-250
+done; done; done

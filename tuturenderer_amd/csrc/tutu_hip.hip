@@ -524,6 +524,15 @@ int render_impl(TutuCtx* c, const TutuCameraFrame* cam, const TutuRenderParams* 
 		spp_pass = (rp->spp + n_passes - 1) / n_passes;
 		n_passes = (rp->spp + spp_pass - 1) / spp_pass;
 	}
+	if (rp->spp_per_pass <= 0 && n_passes < want_sets && !c->knobs.one_set) {
+		// a frame that fits fewer passes than there are streams (few spp): smaller passes, so that the stages of several
+		// passes can still overlap -- as long as a pass keeps at least 1 Mi paths to fill the chip
+		const int split = (int)std::min<int64_t>(std::min(want_sets, rp->spp), std::max<int64_t>(1, ((int64_t)npix * rp->spp) >> 20));
+		if (split > n_passes) {
+			spp_pass = (rp->spp + split - 1) / split;
+			n_passes = (rp->spp + spp_pass - 1) / spp_pass;
+		}
+	}
 	const int n_sets = c->knobs.one_set ? 1 : std::min(want_sets, n_passes);  // one_set: profiling aid, no overlap, clean per-kernel times
 	const size_t cap = (size_t)((npix + 255) / 256 * 256) * (size_t)spp_pass;  // stage 0 fills one 64-slot chunk per wave
 	int rc = ensure_work(c, cap, (size_t)npix, n_sets);
