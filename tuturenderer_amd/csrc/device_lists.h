@@ -131,8 +131,12 @@ __global__ void __launch_bounds__(1024) k_list_scan(ListParams p) {
 	}
 }
 
+// The tile's entries are first ranked into LDS (per-thread runs of up to 16 entries: written straight to memory they
+// would be 4-B stores 64 B apart, 16 store instructions each touching 64 lines) and then copied out in order, 256
+// consecutive entries per store instruction.
 __global__ void __launch_bounds__(256) k_list_scatter(ListParams p) {
 	__shared__ uint32_t lds[4];
+	__shared__ uint32_t staged[2][TUTU_LIST_TILE];
 	const uint32_t range = list_range(p);
 	if (blockIdx.x * (uint32_t)TUTU_LIST_TILE >= range) return;  // whole tile beyond the slots in use (block-uniform)
 	const uint32_t slot0 = (blockIdx.x * 256u + threadIdx.x) * 16u;
@@ -140,9 +144,7 @@ __global__ void __launch_bounds__(256) k_list_scatter(ListParams p) {
 	const uint32_t c = load_and_count(p, slot0, range, k);
 	uint32_t total;
 	const uint32_t excl = block_scan_incl(c, lds, total) - c;
-	if (c == 0) return;
-	uint32_t pos0 = p.tile_offsets[blockIdx.x * 2 + 0] + (excl & 0xFFFFu);
-	uint32_t pos1 = p.stride + p.tile_offsets[blockIdx.x * 2 + 1] + (excl >> 16);
+	uint32_t pos0 = excl & 0xFFFFu, pos1 = excl >> 16;
 	const uint32_t w[4] = {k.x, k.y, k.z, k.w};
 #pragma unroll
 	for (int i = 0; i < 4; i++)
@@ -150,9 +152,15 @@ __global__ void __launch_bounds__(256) k_list_scatter(ListParams p) {
 		for (int j = 0; j < 4; j++) {
 			const uint32_t a = (w[i] >> (8 * j)) & 0xFFu;
 			const uint32_t slot = slot0 + 4 * i + j;
-			if (a & TUTU_KEY_NEXT) p.out[pos0++] = slot;
-			if (a & TUTU_KEY_SHADOW) p.out[pos1++] = slot;
+			if (a & TUTU_KEY_NEXT) staged[0][pos0++] = slot;
+			if (a & TUTU_KEY_SHADOW) staged[1][pos1++] = slot;
 		}
+	__syncthreads();
+	const uint32_t n0 = total & 0xFFFFu, n1 = total >> 16;
+	uint32_t* out0 = p.out + p.tile_offsets[blockIdx.x * 2 + 0];
+	uint32_t* out1 = p.out + p.stride + p.tile_offsets[blockIdx.x * 2 + 1];
+	for (uint32_t i = threadIdx.x; i < n0; i += 256u) out0[i] = staged[0][i];
+	for (uint32_t i = threadIdx.x; i < n1; i += 256u) out1[i] = staged[1][i];
 }
 
 }  // namespace tutu
