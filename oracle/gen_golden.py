@@ -147,3 +147,40 @@ def main_standins():
 
 if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "standins":
     main_standins()
+
+
+# ---- the other integrators behind the seam: small frames rendered by the REFERENCE'S OWN LightTracing::integrate,
+# NaivePT::integrate and sub_render_bdpt with one sequential Philox stream (oracle/ref_harness.cpp: tor_render_integrator)
+def integrator_cases():
+    return {
+        "cornell": (lambda: scenes.cornell_box(40, 30), 41),
+        "cornell_ggxR_glass": (lambda: scenes.cornell_box(
+            40, 30, tall=make_material(MICROFACET_R, (0.725, 0.71, 0.68), roughness=0.3, metallic=0.5),
+            short=make_material(PERFECT_REFRACTIVE, (0.725, 0.71, 0.68), eta=1.5)), 42),
+        "cornell_ggxT_mirror": (lambda: scenes.cornell_box(
+            40, 30, tall=make_material(MICROFACET_T, (0.725, 0.71, 0.68), eta=1.5, roughness=0.2),
+            short=make_material(PERFECT_REFLECTIVE, (0.725, 0.71, 0.68))), 43),
+        "veach_slight": (lambda: scenes.veach_room(40, 30, small_light=True), 44),
+        "cornell_textured": (lambda: scenes.cornell_textured(40, 30), 45),
+    }
+
+
+INTEGRATOR_TYPES = {"light": 1, "naivept": 2, "bdpt": 3}
+INTEGRATOR_SPP = 4
+
+
+def main_integrators():
+    R = Oracle("reference")
+    out = {}
+    for name, (mk, key1) in integrator_cases().items():
+        S = R.scene(mk())
+        for iname, itype in INTEGRATOR_TYPES.items():
+            img = S.render_integrator(itype, INTEGRATOR_SPP, pc.KEY0, key1)
+            out[f"{name}.{iname}"] = img
+            print(name, iname, "mean", float(img.mean()), "nan", int(np.isnan(img).sum()))
+        S.close()
+    np.savez_compressed(os.path.join(GOLD, "integrators.npz"), **out)
+
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "integrators":
+    main_integrators()

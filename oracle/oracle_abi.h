@@ -129,6 +129,17 @@ int tor_trace_samples(void* h, int n, const uint32_t* pix, const uint32_t* smp, 
 int tor_render(void* h, int spp, uint32_t key0, uint32_t key1, int x0, int y0, int x1, int y1, int nthreads,
                float* rgb);
 
+/* ---- the other integrators behind the IIntegrator seam (Renderer.hpp:41-49): type 1 LightTracing,
+ * 2 NaivePT, 3 BDPT.  A whole frame in the reference's own loop order, single-threaded, with ONE sequential random
+ * stream (Philox counter (0xFFFFFFFF, type, draw >> 2, 0)); rgb = H*W*3, starts as the background colour like
+ * Camera::initialize leaves the framebuffer.  Implemented by both libraries: the reference harness calls the reference's
+ * own LightTracing::integrate / NaivePT::integrate / sub_render_bdpt. */
+int tor_render_integrator(void* h, int type, int spp, uint32_t key0, uint32_t key1, float* rgb);
+/* port only: single (pixel, sample) units with their own stream, and a frame assembled from such units */
+int tor_integrator_samples(void* h, int type, int spp, int n, const uint32_t* pix, const uint32_t* smp, uint32_t key0, uint32_t key1,
+                           float* own3, uint8_t* alive, int max_ev, int32_t* n_ev, int32_t* ev_op, int32_t* ev_index, float* ev_rgb);
+int tor_render_integrator_units(void* h, int type, int spp, uint32_t key0, uint32_t key1, int nthreads, float* rgb);
+
 #ifdef __cplusplus
 }
 #endif

@@ -431,6 +431,40 @@ class OracleScene:
                 "N_shadow": nodes_sh / max(shadow, 1), "T_shadow": tris_sh / max(shadow, 1),
                 "N_all": nodes / max(closest + shadow, 1), "T_all": tris / max(closest + shadow, 1)}
 
+    def render_integrator(self, itype, spp, key0, key1):
+        """LightTracing (1) / NaivePT (2) / BDPT (3): a whole frame in the reference's own loop order, single-threaded, one
+        sequential random stream"""
+        rgb = np.zeros((self.H, self.W, 3), np.float32)
+        rc = self.lib.tor_render_integrator(self.h, C.c_int(itype), C.c_int(spp), C.c_uint32(key0), C.c_uint32(key1), _p(rgb))
+        if rc != 0:
+            raise RuntimeError(f"tor_render_integrator failed: {rc}")
+        return rgb
+
+    def render_integrator_units(self, itype, spp, key0, key1):
+        """port only: the same frame from per-(pixel, sample) streams -- what the HIP integrators render"""
+        rgb = np.zeros((self.H, self.W, 3), np.float32)
+        rc = self.lib.tor_render_integrator_units(self.h, C.c_int(itype), C.c_int(spp), C.c_uint32(key0), C.c_uint32(key1), C.c_int(1), _p(rgb))
+        if rc != 0:
+            raise RuntimeError(f"tor_render_integrator_units failed: {rc}")
+        return rgb
+
+    def integrator_samples(self, itype, spp, pix, smp, key0, key1, max_ev=8):
+        """port only: per-unit outputs -- own (n,3), alive (n,), n_ev (n,), ev_op / ev_index (n,max_ev), ev_rgb (n,max_ev,3)"""
+        pix = np.ascontiguousarray(pix, dtype=np.uint32)
+        smp = np.ascontiguousarray(smp, dtype=np.uint32)
+        n = len(pix)
+        own = np.zeros((n, 3), np.float32)
+        alive = np.zeros(n, np.uint8)
+        n_ev = np.zeros(n, np.int32)
+        op = np.full((n, max_ev), -1, np.int32)
+        idx = np.full((n, max_ev), -1, np.int32)
+        rgb = np.zeros((n, max_ev, 3), np.float32)
+        rc = self.lib.tor_integrator_samples(self.h, C.c_int(itype), C.c_int(spp), C.c_int(n), _p(pix), _p(smp), C.c_uint32(key0),
+                                             C.c_uint32(key1), _p(own), _p(alive), C.c_int(max_ev), _p(n_ev), _p(op), _p(idx), _p(rgb))
+        if rc != 0:
+            raise RuntimeError(f"tor_integrator_samples failed: {rc}")
+        return own, alive, n_ev, op, idx, rgb
+
     def render(self, spp, key0, key1, rect=None, nthreads=None):
         if rect is None:
             rect = (0, 0, self.W, self.H)

@@ -584,6 +584,55 @@ int tor_render(void* h, int spp, uint32_t key0, uint32_t key1, int x0, int y0, i
 	return 0;
 }
 
+// ---- the other integrators behind the seam (Renderer.hpp:41-49), driven through the reference's OWN code:
+// LightTracing::integrate and NaivePT::integrate are single-threaded and self-contained and are called as they are; for
+// BDPT the worker sub_render_bdpt (BDPT.hpp:634-899, the live MULTITHREAD == 1 body) is called directly on all rows with a
+// stable argument -- BDPT::integrate's thread launcher has the same dangling `&arg` as PathTracing's (BDPT.hpp:583-611) --
+// after the camera-frame lines of BDPT::integrate (:390-418).  ONE sequential random stream for the whole frame.
+int tor_render_integrator(void* h, int type, int spp, uint32_t key0, uint32_t key1, float* rgb) {
+	RefScene* s = (RefScene*)h;
+	if (type < 1 || type > 3 || spp <= 0) return -1;
+	CoutSilencer quiet;
+	PPMGenerator* g = s->g;
+	SPP = spp;
+	SPP_inv = 1.f / SPP;
+	Camera& cam = g->cam;
+	cam.FrameBuffer.rgb.assign((size_t)cam.width * cam.height, Vector3f(g->bkgcolor.x, g->bkgcolor.y, g->bkgcolor.z));  // Camera.hpp:26-27
+	tutu_ref::RngState& r = tutu_ref::rng_state();
+	r = tutu_ref::RngState();
+	r.pix = 0xFFFFFFFFu; r.smp = (uint32_t)type; r.key0 = key0; r.key1 = key1;
+	if (type == 1) {
+		LightTracing lt(g, s->strat);
+		lt.integrate(g);
+	} else if (type == 2) {
+		NaivePT np(g, s->strat);
+		np.integrate(g);
+	} else {
+		BDPT bd(g, s->strat);
+		Vector3f u = normalized(crossProduct(cam.fwdDir, cam.upDir));
+		Vector3f v = normalized(crossProduct(u, cam.fwdDir));
+		float d = cam.imagePlaneDist;
+		float width_half = fabs(tan(degree2Radians(cam.hfov / 2.f)) * d);
+		float aspect_ratio = cam.width / (float)cam.height;
+		float height_half = width_half / aspect_ratio;
+		Vector3f n = normalized(g->viewdir);
+		Vector3f eyePos = cam.position;
+		Vector3f ul = eyePos + d * n - width_half * u + height_half * v;
+		Vector3f ur = eyePos + d * n + width_half * u + height_half * v;
+		Vector3f ll = eyePos + d * n - width_half * u - height_half * v;
+		Vector3f delta_h = Vector3f(0, 0, 0);
+		if (g->width != 1) delta_h = (ur - ul) / (g->width - 1);
+		Vector3f delta_v = Vector3f(0, 0, 0);
+		if (g->height != 1) delta_v = (ll - ul) / (g->height - 1);
+		Vector3f c_off_h = (ur - ul) / (float)(g->width * 2);
+		Vector3f c_off_v = (ll - ul) / (float)(g->height * 2);
+		Thread_arg_bdpt arg{&ul, &delta_v, &delta_h, &c_off_h, &c_off_v, &eyePos, g, &bd};
+		sub_render_bdpt(&arg, 0, 0, g->height);
+	}
+	for (size_t i = 0; i < cam.FrameBuffer.rgb.size(); i++) S(rgb + 3 * i, cam.FrameBuffer.rgb[i]);
+	return 0;
+}
+
 int tor_texture_lookup(const struct TorTexture* t, int n, const float* u, const float* v, float* rgb) {
 	Texture* tex = make_texture(t, 9, 0);
 	for (int i = 0; i < n; i++) S(rgb + 3 * i, tex->getRGBat(u[i], v[i]));

@@ -1157,6 +1157,8 @@ static void index_leaves(Scene* s, int node, int& counter) {
 	index_leaves(s, n.right, counter);
 }
 
+#include "tutu_oracle_bidir.inc"
+
 } // namespace tor
 
 using namespace tor;
@@ -1637,6 +1639,80 @@ int tor_port_path_stats(void* h, int n, const uint32_t* pix, const uint32_t* smp
 	}
 	out6[0] = n; out6[1] = c.segs; out6[2] = c.closest; out6[3] = c.shadow; out6[4] = c.nodes; out6[5] = c.tris;
 	out6[6] = c.nodes_shadow; out6[7] = c.tris_shadow;
+	return 0;
+}
+
+
+// ---- the other integrators: type 1 LightTracing, 2 NaivePT, 3 BDPT ----------------------------------
+// whole frame, the reference's loop order, ONE sequential random stream (counter (0xFFFFFFFF, type, draw >> 2, 0))
+int tor_render_integrator(void* h, int type, int spp, uint32_t key0, uint32_t key1, float* rgb) {
+	Scene* s = (Scene*)h;
+	if (type < 1 || type > 3 || spp <= 0) return -1;
+	Rng r;
+	r.pix = 0xFFFFFFFFu; r.smp = (uint32_t)type; r.key0 = key0; r.key1 = key1;
+	std::vector<V3> fb;
+	render_integrator_sequential(*s, type, spp, r, fb);
+	for (size_t i = 0; i < fb.size(); i++) ST(rgb + 3 * i, fb[i]);
+	return 0;
+}
+// single (pixel, sample) units with their own stream (counter (pix, smp, draw >> 2, 0), like tor_trace_samples).
+// own3[i] = the unit's contribution to its OWN pixel before the 1/spp scaling (NaivePT: res; BDPT: the s != 1..., t >= 2
+// strategies; LightTracing: nothing), alive[i] = 0 when the reference's loop `break`s / `continue`s before any draw;
+// events: up to max_ev film events per unit (op 0 = set, 1 = add; pixel index; rgb, already scaled by 1/spp as the reference does)
+int tor_integrator_samples(void* h, int type, int spp, int n, const uint32_t* pix, const uint32_t* smp, uint32_t key0, uint32_t key1,
+                           float* own3, uint8_t* alive, int max_ev, int32_t* n_ev, int32_t* ev_op, int32_t* ev_index, float* ev_rgb) {
+	Scene* s = (Scene*)h;
+	if (type < 1 || type > 3 || spp <= 0) return -1;
+	const Cam cam = make_cam(*s);
+	const float SPP_inv = 1.f / spp;
+	for (int i = 0; i < n; i++) {
+		Rng r;
+		r.pix = pix[i]; r.smp = smp[i]; r.key0 = key0; r.key1 = key1;
+		EventFilm film(s->W * s->H);
+		V3 own;
+		bool ok = true;
+		const int x = (int)(pix[i] % (uint32_t)s->W), y = (int)(pix[i] / (uint32_t)s->W);
+		if (type == 1) lt_sample(*s, cam, SPP_inv, r, film);
+		else if (type == 2) ok = naive_sample(*s, cam, pixel_pos_centre(*s, x, y), r, own);
+		else ok = bdpt_sample(*s, cam, pixel_pos_centre(*s, x, y), SPP_inv, r, own, film);
+		ST(own3 + 3 * (size_t)i, own);
+		alive[i] = ok ? 1 : 0;
+		const int ne = (int)film.ev.size();
+		n_ev[i] = ne;
+		for (int k = 0; k < ne && k < max_ev; k++) {
+			ev_op[(size_t)i * max_ev + k] = film.ev[(size_t)k].op;
+			ev_index[(size_t)i * max_ev + k] = film.ev[(size_t)k].index;
+			ST(ev_rgb + 3 * ((size_t)i * max_ev + k), film.ev[(size_t)k].v);
+		}
+	}
+	return 0;
+}
+// a whole frame from per-unit streams: the picture the HIP integrators produce (units in (pixel, sample) order)
+int tor_render_integrator_units(void* h, int type, int spp, uint32_t key0, uint32_t key1, int nthreads, float* rgb) {
+	Scene* s = (Scene*)h;
+	if (type < 1 || type > 3 || spp <= 0) return -1;
+	(void)nthreads;
+	const Cam cam = make_cam(*s);
+	const float SPP_inv = 1.f / spp;
+	std::vector<V3> fb((size_t)s->W * s->H, s->bkg);
+	FrameFilm film(fb);
+	for (int y = 0; y < s->H; y++)
+		for (int x = 0; x < s->W; x++) {
+			const uint32_t p = (uint32_t)(x + y * s->W);
+			V3 estimate;
+			for (int i = 0; i < spp; i++) {
+				Rng r;
+				r.pix = p; r.smp = (uint32_t)i; r.key0 = key0; r.key1 = key1;
+				if (type == 1) lt_sample(*s, cam, SPP_inv, r, film);
+				else if (type == 2) {
+					V3 res;
+					if (naive_sample(*s, cam, pixel_pos_centre(*s, x, y), r, res)) estimate = estimate + res;
+				} else if (!bdpt_sample(*s, cam, pixel_pos_centre(*s, x, y), SPP_inv, r, estimate, film)) break;
+			}
+			if (type == 2) fb[p] = estimate * SPP_inv;
+			else if (type == 3) film.add((int)p, estimate * SPP_inv);
+		}
+	for (size_t i = 0; i < fb.size(); i++) ST(rgb + 3 * i, fb[i]);
 	return 0;
 }
 

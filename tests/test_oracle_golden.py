@@ -157,3 +157,20 @@ def test_port_matches_reference_on_standin_scenes(port, name):
     # drops the result (PathTracing.hpp:128-133); the restatement stops there -- fewer draws / rays on those samples, same radiance
     assert (nd <= z["samples.ndraws"]).all() and (nc <= z["samples.nclosest"]).all()
     assert (nd != z["samples.ndraws"]).mean() < 0.01
+
+
+@pytest.mark.parametrize("iname", ["light", "naivept", "bdpt"])
+def test_other_integrators_match_reference_frames(port, iname):
+    """the restatement of LightTracing / NaivePT / BDPT against frames rendered by the reference's OWN
+    LightTracing::integrate, NaivePT::integrate and sub_render_bdpt (tests/golden/integrators.npz, `gen_golden.py
+    integrators`): same loop order, one sequential Philox stream -- bit for bit, on five scenes incl. rough glass, mirror,
+    the veach room and textures"""
+    from oracle.gen_golden import INTEGRATOR_SPP, INTEGRATOR_TYPES, integrator_cases
+
+    z = np.load(golden_path("integrators.npz"))
+    for name, (mk, key1) in integrator_cases().items():
+        S = port.scene(mk())
+        img = S.render_integrator(INTEGRATOR_TYPES[iname], INTEGRATOR_SPP, pc.KEY0, key1)
+        S.close()
+        assert bit_equal(img, z[f"{name}.{iname}"]), (name, iname, float(np.abs(img - z[f"{name}.{iname}"]).max()))
+        assert np.isfinite(img).all()

@@ -32,3 +32,17 @@ def test_live_veach_scene_rays(reference, port):
     assert_dict_bit_equal(pc.run_scene(P, seed=205), pc.run_scene(R, seed=205))
     R.close()
     P.close()
+
+
+def test_live_other_integrators(reference, port):
+    """LightTracing / NaivePT / BDPT on a fresh key: the port == the reference's own integrators, frame for frame"""
+    from tuturenderer_amd import scenes
+
+    sc = scenes.veach_room(32, 24, small_light=True)
+    R, P = reference.scene(sc), port.scene(sc)
+    for itype in (1, 2, 3):
+        a = R.render_integrator(itype, 3, pc.KEY0, 900 + itype)
+        b = P.render_integrator(itype, 3, pc.KEY0, 900 + itype)
+        assert a.tobytes() == b.tobytes(), itype
+    R.close()
+    P.close()
