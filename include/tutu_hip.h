@@ -184,6 +184,17 @@ typedef struct TutuCtx TutuCtx;
  * (PathTracing.hpp:357-391). */
 int tutu_camera_frame(const TutuCameraDesc* cam, TutuCameraFrame* out);
 
+/* What LightTracing / NaivePT / BDPT read from g->cam (Camera.hpp:12-79): position, fwdDir, the three scalars of
+ * Camera::initialize (:43-47) and world2Raster = scale(w/2, h/2, 0) * translate(1, 1, 0) * perspective(hfov, 0.1, 10000,
+ * w/h) * world2Cam (:29-41; Vector.hpp:338-373), row-major -- the matrix behind Camera::worldPos2PixelIndex (:61-79). */
+typedef struct TutuCameraRaster {
+	float position[3], fwdDir[3];
+	int32_t width, height;
+	float imagePlaneDist, filmPlaneAreaInv, lensAreaInv;
+	float world2raster[16];
+} TutuCameraRaster;
+int tutu_camera_raster(const TutuCameraDesc* cam, TutuCameraRaster* out);
+
 /* BVHAccel::recursiveBuild (BVH.hpp:47-123) over the triangle list: median split on the centroid along the
  * longest axis, one triangle per leaf, same std::sort, same tie order.  Writes the tree in pre-order like the
  * parity oracles do: bounds6[i] = pMin,pMax ; leaf_tri[i] = triangle index or -1 for an inner node.
@@ -236,6 +247,33 @@ int tutu_hip_trace_any(TutuCtx* ctx, uint32_t n, const float* orig, const float*
  * (PathTracing.hpp:509), NaN samples returned as they are.  Runs the same wavefront pipeline as tutu_hip_render. */
 int tutu_hip_trace_samples(TutuCtx* ctx, const TutuCameraFrame* cam, uint32_t n, const uint32_t* pix,
                            const uint32_t* smp, uint32_t key0, uint32_t key1, float* L3);
+
+/* The reference's OTHER integrators behind the same seam (Renderer.hpp:41-49 picks by PPMGenerator::integrateType;
+ * SURVEY.md 8f-4) -- IIntegrator::integrate of
+ *   TUTU_INTEGRATOR_LIGHT    LightTracing::integrate  (LightTracing.hpp:23-207: one light path per (pixel, sample) splatted
+ *                            onto the pixel it projects to; the directly visible light is a setRGB [sic])
+ *   TUTU_INTEGRATOR_NAIVEPT  NaivePT::integrate       (NaivePT.hpp:24-164: emission of the first hit times the camera terms)
+ *   TUTU_INTEGRATOR_BDPT     BDPT::integrate          (BDPT.hpp:387-900: sub_render_bdpt, every (s, t) strategy up to path
+ *                            length 7, MISweight :70-230)
+ * over the whole frame: out_rgb (HOST, width*height*3) = g->cam.FrameBuffer.rgb after integrate(), starting from the
+ * background colour (Camera.hpp:26-27).  The reference draws from one global rand() stream shared by its threads, so its
+ * own picture is not reproducible; here unit (pixel p, sample s) has the Philox stream (p, s) of tutu_hip_render, and the
+ * frame is what ONE thread running the reference's loops in (y, x, sample) order would leave behind with those streams:
+ * setRGB / addRGB are applied per target pixel in that order (a later setRGB replaces what earlier units added, as there).
+ * TUTU_INTEGRATOR_PATH is refused here (tutu_hip_render is that integrator).  stats: samples, ms_total; may be NULL. */
+enum TutuIntegrator { TUTU_INTEGRATOR_PATH = 0, TUTU_INTEGRATOR_LIGHT = 1, TUTU_INTEGRATOR_NAIVEPT = 2, TUTU_INTEGRATOR_BDPT = 3 };
+int tutu_hip_render_integrator(TutuCtx* ctx, int32_t type, const TutuCameraDesc* cam, int32_t spp, uint32_t key0,
+                               uint32_t key1, float* out_rgb, TutuStats* stats);
+/* Individual units of those integrators, for parity tests: unit i = (pix[i], smp[i]) of an spp-sample frame.
+ * own3[i] = what the unit adds to its own pixel's estimate (before the 1/spp scaling; zero for LightTracing),
+ * alive[i] = 0 when the primary ray missed (NaivePT `continue`, BDPT `break`), and the unit's frame-buffer events in
+ * program order: n_ev[i] of them (at most TUTU_MAX_UNIT_EVENTS), event k at [i * max_ev + k]: ev_op 0 = setRGB /
+ * 1 = addRGB, ev_index = target pixel, ev_rgb = the value (already scaled by 1/spp, as the reference passes it). */
+#define TUTU_MAX_UNIT_EVENTS 8
+int tutu_hip_integrator_samples(TutuCtx* ctx, int32_t type, const TutuCameraDesc* cam, int32_t spp, uint32_t n,
+                                const uint32_t* pix, const uint32_t* smp, uint32_t key0, uint32_t key1, float* own3,
+                                uint8_t* alive, int32_t max_ev, int32_t* n_ev, int32_t* ev_op, int32_t* ev_index,
+                                float* ev_rgb);
 
 /* Device evaluation of the material functions on arrays (one material, n evaluations), for function-level parity:
  * Material::BxDF (Material.hpp:62-191), Material::pdf (:350-439), Material::sampleDirection (:200-343) with the
@@ -294,7 +332,8 @@ int tutu_hip_quantise(TutuCtx* ctx, uint32_t n, const float* values, int32_t* le
  *   "sets_default" TUTU_SETS [1,4] | "one_set" TUTU_ONE_SET {0,1} | "shade_bpc" TUTU_SHADE_BPC [1,16] |
  *   "trace_bpc" TUTU_TRACE_BPC [0,8] (0 = from the LDS footprint) | "refill_min" TUTU_REFILL_MIN [1,64] |
  *   "inner_steps" TUTU_INNER_STEPS [1,64] | "any_near_first" TUTU_ANY_NEAR_FIRST {0,1} |
- *   "util_stats" TUTU_UTIL_STATS {0,1}.
+ *   "util_stats" TUTU_UTIL_STATS {0,1} | "bidir_units" TUTU_BIDIR_UNITS [64, 2^24] ((pixel, sample) units per batch of
+ *   tutu_hip_render_integrator; batches are whole pixels).
  * tutu_hip_get_option reports the effective value of any of them, plus the read-only facts "sah_tree", "lds_scene"
  * and "shade_tab" -- a benchmark line should echo them (bench.py does). */
 int tutu_hip_set_option(TutuCtx* ctx, const char* name, int value);

@@ -120,6 +120,8 @@ int tor_scene_light_pdf(void* h, int n, const int32_t* tri, float* pdf);
 /* out18 = ul, delta_h, delta_v, c_off_h, c_off_v, eye  (PathTracing.hpp:357-391) */
 int tor_camera(void* h, float* out18);
 int tor_camera_raydir(void* h, int n, const int32_t* px, const int32_t* py, float* d);
+/* out22 = world2Raster (row-major 4x4), imagePlaneDist, filmPlaneAreaInv, lensAreaInv, fwdDir  (Camera.hpp:12-49) */
+int tor_camera_raster(void* h, float* out22);
 
 /* ---- estimator ---- */
 /* radiance of individual samples (pixel index = y*W+x, sample index) under key (k0,k1); ndraws/nclosest optional */

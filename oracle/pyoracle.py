@@ -398,6 +398,11 @@ class OracleScene:
         self.lib.tor_camera(self.h, _p(out))
         return out.reshape(6, 3)
 
+    def camera_raster(self):
+        out = np.empty(22, np.float32)
+        self.lib.tor_camera_raster(self.h, _p(out))
+        return out
+
     def raydir(self, px, py):
         px = np.ascontiguousarray(px, dtype=np.int32)
         py = np.ascontiguousarray(py, dtype=np.int32)

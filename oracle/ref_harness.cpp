@@ -527,6 +527,15 @@ int tor_camera(void* h, float* out18) {
 	return 0;
 }
 
+int tor_camera_raster(void* h, float* out22) {  // the reference's own Camera after initialize()
+	RefScene* s = (RefScene*)h;
+	Camera& cam = s->g->cam;
+	for (int i = 0; i < 16; i++) out22[i] = cam.world2Raster.ele[i];
+	out22[16] = cam.imagePlaneDist; out22[17] = cam.filmPlaneAreaInv; out22[18] = cam.lensAreaInv;
+	S(out22 + 19, cam.fwdDir);
+	return 0;
+}
+
 int tor_camera_raydir(void* h, int n, const int32_t* px, const int32_t* py, float* d) {
 	RefScene* s = (RefScene*)h;
 	for (int i = 0; i < n; i++) S(d + 3 * i, pixel_raydir(s, px[i], py[i]));

@@ -1556,6 +1556,14 @@ int tor_camera(void* h, float* out18) {
 	ST(out18 + 9, s->c_off_h); ST(out18 + 12, s->c_off_v); ST(out18 + 15, s->eyePos);
 	return 0;
 }
+int tor_camera_raster(void* h, float* out22) {  // world2Raster[16], imagePlaneDist, filmPlaneAreaInv, lensAreaInv, fwdDir
+	Scene* s = (Scene*)h;
+	const Cam c = make_cam(*s);
+	memcpy(out22, c.w2r, sizeof(c.w2r));
+	out22[16] = c.imagePlaneDist; out22[17] = c.filmPlaneAreaInv; out22[18] = c.lensAreaInv;
+	ST(out22 + 19, c.fwdDir);
+	return 0;
+}
 int tor_camera_raydir(void* h, int n, const int32_t* px, const int32_t* py, float* d) {
 	Scene* s = (Scene*)h;
 	for (int i = 0; i < n; i++) ST(d + 3 * i, s->raydir(px[i], py[i]));

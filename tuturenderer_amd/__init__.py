@@ -20,6 +20,7 @@ ABI_SYMBOLS = [
     "tutu_hip_device_count", "tutu_hip_create", "tutu_hip_destroy", "tutu_hip_render", "tutu_hip_render_device", "tutu_hip_render_multi",
     "tutu_hip_trace_closest", "tutu_hip_trace_any", "tutu_hip_trace_samples", "tutu_hip_eval_bxdf", "tutu_hip_eval_pdf",
     "tutu_hip_eval_sample", "tutu_hip_eval_sample_light", "tutu_hip_eval_fn", "tutu_hip_scene_info", "tutu_hip_eval_texture", "tutu_hip_set_option", "tutu_hip_get_option", "tutu_hip_postprocess", "tutu_hip_quantise",
+    "tutu_camera_raster", "tutu_hip_render_integrator", "tutu_hip_integrator_samples",
 ]
 
 
@@ -179,14 +180,37 @@ def device_count():
     return n.value if rc == 0 else 0
 
 
-def camera_frame(scene):
-    """tutu_camera_frame: Camera::initialize + the camera-frame lines of PathTracing::integrate."""
-    lib = load_library()
+class CameraRaster(C.Structure):
+    _fields_ = [("position", C.c_float * 3), ("fwdDir", C.c_float * 3), ("width", C.c_int32), ("height", C.c_int32),
+                ("imagePlaneDist", C.c_float), ("filmPlaneAreaInv", C.c_float), ("lensAreaInv", C.c_float), ("world2raster", C.c_float * 16)]
+
+
+INTEGRATORS = {"path": 0, "light": 1, "naivept": 2, "bdpt": 3}  # PPMGenerator::integrateType (Renderer.hpp:41-49)
+MAX_UNIT_EVENTS = 8
+
+
+def camera_desc(scene):
     cd = CameraDesc()
     cd.width, cd.height, cd.hfov = int(scene["width"]), int(scene["height"]), int(scene["hfov"])
     cd.eye = (C.c_float * 3)(*[float(x) for x in scene["eye"]])
     cd.viewdir = (C.c_float * 3)(*[float(x) for x in scene["viewdir"]])
     cd.updir = (C.c_float * 3)(*[float(x) for x in scene["updir"]])
+    return cd
+
+
+def camera_raster(scene):
+    """tutu_camera_raster: what LightTracing / NaivePT / BDPT read from g->cam (Camera.hpp:12-79)."""
+    lib = load_library()
+    cd = camera_desc(scene)
+    cr = CameraRaster()
+    _check(lib.tutu_camera_raster(C.byref(cd), C.byref(cr)), "tutu_camera_raster")
+    return cr
+
+
+def camera_frame(scene):
+    """tutu_camera_frame: Camera::initialize + the camera-frame lines of PathTracing::integrate."""
+    lib = load_library()
+    cd = camera_desc(scene)
     cf = CameraFrame()
     _check(lib.tutu_camera_frame(C.byref(cd), C.byref(cf)), "tutu_camera_frame")
     return cf
@@ -238,6 +262,7 @@ class Context:
         self.h = C.c_void_p()
         _check(self.lib.tutu_hip_create(C.byref(d), C.c_int(device), C.byref(self.h)), "tutu_hip_create")
         self.cam = camera_frame(scene)
+        self.cam_desc = camera_desc(scene)
         self.device = device
         self.last_stats = None
 
@@ -276,7 +301,7 @@ class Context:
         _check(self.lib.tutu_hip_set_option(self.h, C.c_char_p(name.encode()), C.c_int(int(value))), "tutu_hip_set_option")
 
     OPTION_NAMES = ("sets", "sets_default", "one_set", "shade_bpc", "trace_bpc", "refill_min", "inner_steps", "any_near_first",
-                    "util_stats", "sah_tree", "n_refs", "lds_scene", "shade_tab")
+                    "util_stats", "bidir_units", "sah_tree", "n_refs", "lds_scene", "shade_tab")
 
     def get_option(self, name):
         v = C.c_int(0)
@@ -356,6 +381,34 @@ class Context:
         _check(self.lib.tutu_hip_trace_samples(self.h, C.byref(self.cam), C.c_uint32(len(pix)), _p(pix), _p(smp), C.c_uint32(key0),
                                                C.c_uint32(key1), _p(L)), "tutu_hip_trace_samples")
         return L
+
+    # ---- the other integrators behind the seam (LightTracing / NaivePT / BDPT)
+    def render_integrator(self, integrator, spp, key0, key1):
+        """IIntegrator::integrate of LightTracing / NaivePT / BDPT over the whole frame -> (H, W, 3) linear radiance."""
+        t = INTEGRATORS[integrator] if isinstance(integrator, str) else int(integrator)
+        out = np.zeros((self.H, self.W, 3), np.float32)
+        st = Stats()
+        _check(self.lib.tutu_hip_render_integrator(self.h, C.c_int32(t), C.byref(self.cam_desc), C.c_int32(int(spp)), C.c_uint32(key0), C.c_uint32(key1),
+                                                   _p(out), C.byref(st)), "tutu_hip_render_integrator")
+        self.last_stats = st.as_dict()
+        return out
+
+    def integrator_samples(self, integrator, spp, pix, smp, key0, key1):
+        """Units (pixel, sample) of those integrators: dict(own (n,3), alive (n,), n_ev (n,), ev_op / ev_index (n, 8), ev_rgb (n, 8, 3))."""
+        t = INTEGRATORS[integrator] if isinstance(integrator, str) else int(integrator)
+        pix = np.ascontiguousarray(pix, dtype=np.uint32)
+        smp = np.ascontiguousarray(smp, dtype=np.uint32)
+        n, m = len(pix), MAX_UNIT_EVENTS
+        own = np.zeros((n, 3), np.float32)
+        alive = np.zeros(n, np.uint8)
+        n_ev = np.zeros(n, np.int32)
+        ev_op = np.full((n, m), -1, np.int32)
+        ev_index = np.full((n, m), -1, np.int32)
+        ev_rgb = np.zeros((n, m, 3), np.float32)
+        _check(self.lib.tutu_hip_integrator_samples(self.h, C.c_int32(t), C.byref(self.cam_desc), C.c_int32(int(spp)), C.c_uint32(n), _p(pix), _p(smp),
+                                                    C.c_uint32(key0), C.c_uint32(key1), _p(own), _p(alive), C.c_int32(m), _p(n_ev), _p(ev_op), _p(ev_index),
+                                                    _p(ev_rgb)), "tutu_hip_integrator_samples")
+        return dict(own=own, alive=alive, n_ev=n_ev, ev_op=ev_op, ev_index=ev_index, ev_rgb=ev_rgb)
 
     # ---- kernel-level entry points
     def trace_closest(self, o, d):

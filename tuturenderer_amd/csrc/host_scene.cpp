@@ -856,6 +856,70 @@ int tutu_camera_frame(const TutuCameraDesc* cam, TutuCameraFrame* out) {
 	return TUTU_OK;
 }
 
+// ---- the camera as the OTHER integrators read it (LightTracing / NaivePT / BDPT; tutu_hip_render_integrator)
+namespace {
+// Mat4f::operator* (Vector.hpp:338-349): every element starts at 0 and adds l(row, i) * r(i, col) for i = 0..3
+void mat4_mul(const float* l, const float* r, float* out) {
+	float res[16];
+	for (int row = 0; row < 4; row++)
+		for (int col = 0; col < 4; col++) {
+			float acc = 0;
+			for (int i = 0; i < 4; i++) acc += l[i + row * 4] * r[col + i * 4];
+			res[col + row * 4] = acc;
+		}
+	memcpy(out, res, sizeof(res));
+}
+// getPerspectiveMatrix (Vector.hpp:352-373): perspective-to-orthographic, then the orthographic translate and scale
+// (y flipped: 2 / -(t - b))
+void perspective4(float fov, float zn, float zf, float aspect, float* proj) {
+	const float p2o[16] = {zn, 0, 0, 0, 0, zn, 0, 0, 0, 0, (zn + zf), zn * zf, 0, 0, -1.0f, 0};
+	const float r = tanf((fov / 2) * 3.1415926535897f / 180) * zn;
+	const float l = -r;
+	const float t = r / aspect;
+	const float b = -t;
+	const float trans[16] = {1, 0, 0, -(r + l) / 2, 0, 1, 0, -(t + b) / 2, 0, 0, 1, -(zn + zf) / 2, 0, 0, 0, 1};
+	const float scale[16] = {2 / (r - l), 0, 0, 0, 0, 2 / -(t - b), 0, 0, 0, 0, 2 / (zn - zf), 0, 0, 0, 0, 1};
+	float orth[16];
+	mat4_mul(scale, trans, orth);
+	mat4_mul(orth, p2o, proj);
+}
+}  // namespace
+
+int tutu_camera_raster(const TutuCameraDesc* cam, TutuCameraRaster* out) {  // Camera::initialize, Camera.hpp:12-49
+	if (!cam || !out || cam->width <= 0 || cam->height <= 0) return TUTU_E_INVALID;
+	using namespace tutu;
+	float fwd[3] = {cam->viewdir[0], cam->viewdir[1], cam->viewdir[2]};
+	normalize3(fwd);
+	float right[3], up[3];
+	cross3(fwd, cam->updir, right);
+	normalize3(right);
+	cross3(right, fwd, up);
+	normalize3(up);
+	const float nfwd[3] = {-fwd[0], -fwd[1], -fwd[2]};
+	const float px = right[0] * cam->eye[0] + right[1] * cam->eye[1] + right[2] * cam->eye[2];
+	const float py = up[0] * cam->eye[0] + up[1] * cam->eye[1] + up[2] * cam->eye[2];
+	const float pz = nfwd[0] * cam->eye[0] + nfwd[1] * cam->eye[1] + nfwd[2] * cam->eye[2];
+	const float w2c[16] = {right[0], right[1], right[2], -px, up[0], up[1], up[2], -py, nfwd[0], nfwd[1], nfwd[2], -pz, 0.f, 0.f, 0.f, 1.f};
+	float persp[16], w2ndc[16], tmp[16];
+	perspective4((float)cam->hfov, 0.1f, 10000.f, (float)cam->width / cam->height, persp);
+	mat4_mul(persp, w2c, w2ndc);
+	const float tr[16] = {1, 0, 0, 1.f, 0, 1, 0, 1.f, 0, 0, 1, 0, 0, 0, 0, 1};                              // getTranslate((1, 1, 0))
+	const float sc[16] = {cam->width * 0.5f, 0, 0, 0, 0, cam->height * 0.5f, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1};  // getScale((w/2, h/2, 0))
+	mat4_mul(tr, w2ndc, tmp);
+	mat4_mul(sc, tmp, out->world2raster);
+	const float tanHalfHfov = tanf((cam->hfov * 0.5f) * 3.1415926535897f / 180.f);
+	out->width = cam->width;
+	out->height = cam->height;
+	for (int k = 0; k < 3; k++) {
+		out->position[k] = cam->eye[k];
+		out->fwdDir[k] = fwd[k];
+	}
+	out->imagePlaneDist = cam->width / (2.f * tanHalfHfov);
+	out->filmPlaneAreaInv = 1.f / (cam->width * cam->height);
+	out->lensAreaInv = 1.f;
+	return TUTU_OK;
+}
+
 const char* tutu_hip_error_string(int code) {
 	switch (code) {
 	case TUTU_OK: return "ok";

@@ -2,6 +2,7 @@
 // No CPU fallback exists anywhere in this file: without a HIP device every device entry point returns
 // TUTU_E_NO_DEVICE / TUTU_E_HIP.
 #include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
 
 #include <algorithm>
 #include <climits>
@@ -15,6 +16,7 @@
 #include "../../include/tutu_hip.h"
 #include "device_shade.h"
 #include "device_post.h"
+#include "device_bidir.h"
 #include "host_scene.hpp"
 
 using namespace tutu;
@@ -97,6 +99,7 @@ struct TutuCtx {
 		int inner_steps = TUTU_INNER_STEPS;  // TUTU_INNER_STEPS node visits per round            [1, 64]
 		int any_near_first = 1;   // TUTU_ANY_NEAR_FIRST any-hit: nearer child first              {0, 1}
 		int util_stats = 0;       // TUTU_UTIL_STATS     phase counters of the traversal kernels  {0, 1}
+		int bidir_units = 1 << 21;  // TUTU_BIDIR_UNITS  LightTracing / NaivePT / BDPT: (pixel, sample) units per batch  [64, 2^24]
 	} knobs;
 	int shade_mode_all = SHADE_ANY;  // the kernel of that launch: the scene's only scattering class, or SHADE_ANY
 	DevBuf<float4> d_tri_tex, d_texels, d_tex_desc, d_leaf_boxes;
@@ -123,6 +126,15 @@ struct TutuCtx {
 	DevBuf<int32_t> pixels;
 	DevBuf<uint32_t> u32a, u32b;
 	DevBuf<float> out_stage;
+	// the other integrators (device_bidir.h): per-unit results, frame-buffer events and their sorted order
+	struct Bidir {
+		DevBuf<float4> own, own_list, ev_val;
+		DevBuf<unsigned long long> ev_key, ev_key_sorted;
+		DevBuf<uint32_t> idx, idx_sorted;
+		DevBuf<uint8_t> sort_tmp;
+		DevBuf<float> frame;
+		hipEvent_t t0 = nullptr, t1 = nullptr;
+	} bd;
 	std::vector<EvPair> ev_pool;
 	size_t ev_used = 0;
 };
@@ -145,6 +157,7 @@ const KnobDesc kKnobs[] = {
     {"inner_steps", "TUTU_INNER_STEPS", &TutuCtx::Knobs::inner_steps, 1, 64},
     {"any_near_first", "TUTU_ANY_NEAR_FIRST", &TutuCtx::Knobs::any_near_first, 0, 1},
     {"util_stats", "TUTU_UTIL_STATS", &TutuCtx::Knobs::util_stats, 0, 1},
+    {"bidir_units", "TUTU_BIDIR_UNITS", &TutuCtx::Knobs::bidir_units, 64, 1 << 24},
 };
 
 // strict integer parse: the whole string must be a number inside [lo, hi]
@@ -753,6 +766,10 @@ int tutu_hip_destroy(TutuCtx* c) {
 	c->prim_dir.release(); c->prim_hit.release(); c->accum.release();
 	c->totals.release(); c->pixels.release(); c->u32a.release(); c->u32b.release();
 	c->out_stage.release();
+	c->bd.own.release(); c->bd.own_list.release(); c->bd.ev_val.release(); c->bd.ev_key.release(); c->bd.ev_key_sorted.release();
+	c->bd.idx.release(); c->bd.idx_sorted.release(); c->bd.sort_tmp.release(); c->bd.frame.release();
+	if (c->bd.t0) (void)hipEventDestroy(c->bd.t0);
+	if (c->bd.t1) (void)hipEventDestroy(c->bd.t1);
 	if (c->stream) (void)hipStreamDestroy(c->stream);
 	delete c;
 	return TUTU_OK;
@@ -946,6 +963,192 @@ int tutu_hip_trace_samples(TutuCtx* c, const TutuCameraFrame* cam, uint32_t n, c
 	HIP_TRY(hipStreamSynchronize(s));
 	c->ev_used = 0;
 	HIP_TRY(hipMemcpy(L3, c->out_stage.p, sizeof(float) * 3 * (size_t)n, hipMemcpyDeviceToHost));
+	return TUTU_OK;
+}
+
+}  // extern "C"
+
+// ---------------------------------------------------------------------------------------------------------
+// LightTracing / NaivePT / BDPT (device_bidir.h)
+namespace {
+
+int bidir_params(TutuCtx* c, int type, const TutuCameraDesc* cam, int spp, uint32_t key0, uint32_t key1, BidirParams* p) {
+	TutuCameraRaster cr;
+	int rc = tutu_camera_raster(cam, &cr);
+	if (rc != TUTU_OK) return rc;
+	if ((rc = tutu_camera_frame(cam, &p->frame)) != TUTU_OK) return rc;
+	p->sc = c->sc;
+	for (int k = 0; k < 3; k++) {
+		p->cam.position[k] = cr.position[k];
+		p->cam.fwdDir[k] = cr.fwdDir[k];
+	}
+	p->cam.width = cr.width;
+	p->cam.height = cr.height;
+	p->cam.imagePlaneDist = cr.imagePlaneDist;
+	p->cam.filmPlaneAreaInv = cr.filmPlaneAreaInv;
+	p->cam.lensAreaInv = cr.lensAreaInv;
+	memcpy(p->cam.w2r, cr.world2raster, sizeof(cr.world2raster));
+	p->key0 = key0;
+	p->key1 = key1;
+	p->type = type;
+	p->spp = spp;
+	p->spp_inv = 1.f / spp;  // SPP_inv, global.hpp:20
+	p->n_mats = (int)c->hs.mats.size();
+	p->stack_entries = c->stack_entries;
+	p->ev_stride = type == TUTU_INTEGRATOR_LIGHT ? 2 : (type == TUTU_INTEGRATOR_BDPT ? TUTU_BIDIR_MAX_EVENTS : 1);
+	p->pix_list = nullptr;
+	p->smp_list = nullptr;
+	p->first_unit = 0;
+	p->own_list = nullptr;
+	return TUTU_OK;
+}
+
+int bidir_launch(TutuCtx* c, hipStream_t s, const BidirParams& p) {
+	const dim3 grid((p.n_units + 255) / 256);
+	if (c->lds_scene) hipLaunchKernelGGL(k_bidir<true>, grid, dim3(256), c->trace_lds_bytes, s, p);
+	else hipLaunchKernelGGL(k_bidir<false>, grid, dim3(256), c->trace_lds_bytes, s, p);
+	HIP_TRY(hipGetLastError());
+	return TUTU_OK;
+}
+
+int bidir_check(TutuCtx* c, int type, const TutuCameraDesc* cam, int spp) {
+	if (!c || !cam) return TUTU_E_INVALID;
+	if (type != TUTU_INTEGRATOR_LIGHT && type != TUTU_INTEGRATOR_NAIVEPT && type != TUTU_INTEGRATOR_BDPT) return TUTU_E_INVALID;
+	if (spp <= 0 || cam->width <= 0 || cam->height <= 0) return TUTU_E_INVALID;
+	const unsigned long long npix = (unsigned long long)cam->width * (unsigned long long)cam->height;
+	if (npix >= (1ull << 24) || npix * (unsigned long long)spp >= (1ull << 36)) return TUTU_E_INVALID;  // event key: 24 + 40 bits
+	return TUTU_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int tutu_hip_render_integrator(TutuCtx* c, int32_t type, const TutuCameraDesc* cam, int32_t spp, uint32_t key0, uint32_t key1, float* out_rgb,
+                               TutuStats* st) {
+	int rc = bidir_check(c, type, cam, spp);
+	if (rc != TUTU_OK) return rc;
+	if (!out_rgb) return TUTU_E_INVALID;
+	HIP_TRY(hipSetDevice(c->device));
+	hipStream_t s = c->stream;
+	BidirParams p;
+	if ((rc = bidir_params(c, type, cam, spp, key0, key1, &p)) != TUTU_OK) return rc;
+	const uint32_t npix = (uint32_t)cam->width * (uint32_t)cam->height;
+	// batches of whole pixels, in pixel order: the events of a batch all come before those of the next
+	const uint32_t unit_budget = (uint32_t)c->knobs.bidir_units;
+	uint32_t pix_per_batch = unit_budget / (uint32_t)spp;
+	if (pix_per_batch == 0) pix_per_batch = 1;
+	if (pix_per_batch > npix) pix_per_batch = npix;
+	const size_t max_units = (size_t)pix_per_batch * (size_t)spp;
+	const size_t max_ev = max_units * (size_t)p.ev_stride + pix_per_batch;
+	TutuCtx::Bidir& b = c->bd;
+	if ((rc = b.own.ensure(max_units)) != TUTU_OK) return rc;
+	if (type == TUTU_INTEGRATOR_BDPT && (rc = b.own_list.ensure(max_units * TUTU_BIDIR_MAX_OWN)) != TUTU_OK) return rc;
+	if ((rc = b.ev_val.ensure(max_ev)) != TUTU_OK) return rc;
+	if ((rc = b.ev_key.ensure(max_ev)) != TUTU_OK) return rc;
+	if ((rc = b.ev_key_sorted.ensure(max_ev)) != TUTU_OK) return rc;
+	if ((rc = b.idx.ensure(max_ev)) != TUTU_OK) return rc;
+	if ((rc = b.idx_sorted.ensure(max_ev)) != TUTU_OK) return rc;
+	if ((rc = b.frame.ensure(3 * (size_t)npix)) != TUTU_OK) return rc;
+	size_t tmp_bytes = 0;
+	HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, b.ev_key.p, b.ev_key_sorted.p, b.idx.p, b.idx_sorted.p, (int)max_ev, 0, 64, s));
+	if ((rc = b.sort_tmp.ensure(tmp_bytes)) != TUTU_OK) return rc;
+	if (!b.t0) {
+		HIP_TRY(hipEventCreate(&b.t0));
+		HIP_TRY(hipEventCreate(&b.t1));
+	}
+	HIP_TRY(hipEventRecord(b.t0, s));
+	hipLaunchKernelGGL(k_fill3, dim3((npix + 255) / 256), dim3(256), 0, s, b.frame.p, npix, c->sc.bkg[0], c->sc.bkg[1], c->sc.bkg[2]);  // Camera.hpp:26-27
+	hipLaunchKernelGGL(k_iota, dim3((unsigned)((max_ev + 255) / 256)), dim3(256), 0, s, b.idx.p, (uint32_t)max_ev);
+	p.own = b.own.p;
+	p.own_list = type == TUTU_INTEGRATOR_BDPT ? b.own_list.p : nullptr;
+	p.ev_key = b.ev_key.p;
+	p.ev_val = b.ev_val.p;
+	for (uint32_t pix0 = 0; pix0 < npix; pix0 += pix_per_batch) {
+		const uint32_t np = std::min(pix_per_batch, npix - pix0);
+		p.n_units = np * (uint32_t)spp;
+		p.first_unit = pix0 * (uint32_t)spp;  // < 2^36 checked; the kernel splits it again with 32-bit arithmetic:
+		if ((unsigned long long)pix0 * (unsigned long long)spp + p.n_units > 0xFFFFFFFFull) return TUTU_E_INVALID;
+		if ((rc = bidir_launch(c, s, p)) != TUTU_OK) return rc;
+		size_t n_ev = (size_t)p.n_units * (size_t)p.ev_stride;
+		if (type != TUTU_INTEGRATOR_LIGHT) {
+			hipLaunchKernelGGL(k_bidir_own, dim3((np + 255) / 256), dim3(256), 0, s, b.own.p, p.own_list, type, spp, p.spp_inv, pix0, np, b.ev_key.p + n_ev,
+			                   b.ev_val.p + n_ev);
+			n_ev += np;
+		}
+		HIP_TRY(hipcub::DeviceRadixSort::SortPairs(b.sort_tmp.p, tmp_bytes, b.ev_key.p, b.ev_key_sorted.p, b.idx.p, b.idx_sorted.p, (int)n_ev, 0, 64, s));
+		hipLaunchKernelGGL(k_bidir_replay, dim3((unsigned)((n_ev + 255) / 256)), dim3(256), 0, s, b.ev_key_sorted.p, b.idx_sorted.p, b.ev_val.p, (uint32_t)n_ev,
+		                   b.frame.p);
+		HIP_TRY(hipGetLastError());
+	}
+	HIP_TRY(hipEventRecord(b.t1, s));
+	HIP_TRY(hipStreamSynchronize(s));
+	HIP_TRY(hipMemcpy(out_rgb, b.frame.p, sizeof(float) * 3 * (size_t)npix, hipMemcpyDeviceToHost));
+	if (st) {
+		memset(st, 0, sizeof(*st));
+		st->samples = (uint64_t)npix * (uint64_t)spp;
+		st->passes = (npix + pix_per_batch - 1) / pix_per_batch;
+		HIP_TRY(hipEventElapsedTime(&st->ms_total, b.t0, b.t1));
+	}
+	return TUTU_OK;
+}
+
+int tutu_hip_integrator_samples(TutuCtx* c, int32_t type, const TutuCameraDesc* cam, int32_t spp, uint32_t n, const uint32_t* pix, const uint32_t* smp,
+                                uint32_t key0, uint32_t key1, float* own3, uint8_t* alive, int32_t max_ev, int32_t* n_ev, int32_t* ev_op, int32_t* ev_index,
+                                float* ev_rgb) {
+	int rc = bidir_check(c, type, cam, spp);
+	if (rc != TUTU_OK) return rc;
+	if (!pix || !smp || !own3 || !alive || !n_ev || max_ev < 0 || (max_ev > 0 && (!ev_op || !ev_index || !ev_rgb))) return TUTU_E_INVALID;
+	if (n == 0) return TUTU_OK;
+	const uint32_t npix = (uint32_t)cam->width * (uint32_t)cam->height;
+	for (uint32_t i = 0; i < n; i++)
+		if (pix[i] >= npix || smp[i] >= (uint32_t)spp) return TUTU_E_INVALID;
+	HIP_TRY(hipSetDevice(c->device));
+	hipStream_t s = c->stream;
+	BidirParams p;
+	if ((rc = bidir_params(c, type, cam, spp, key0, key1, &p)) != TUTU_OK) return rc;
+	TutuCtx::Bidir& b = c->bd;
+	const size_t nev = (size_t)n * (size_t)p.ev_stride;
+	if ((rc = b.own.ensure(n)) != TUTU_OK) return rc;
+	if ((rc = b.ev_val.ensure(nev)) != TUTU_OK) return rc;
+	if ((rc = b.ev_key.ensure(nev)) != TUTU_OK) return rc;
+	if ((rc = c->u32a.ensure(n)) != TUTU_OK) return rc;
+	if ((rc = c->u32b.ensure(n)) != TUTU_OK) return rc;
+	HIP_TRY(hipMemcpyAsync(c->u32a.p, pix, sizeof(uint32_t) * n, hipMemcpyHostToDevice, s));
+	HIP_TRY(hipMemcpyAsync(c->u32b.p, smp, sizeof(uint32_t) * n, hipMemcpyHostToDevice, s));
+	p.n_units = n;
+	p.pix_list = c->u32a.p;
+	p.smp_list = c->u32b.p;
+	p.own = b.own.p;
+	p.ev_key = b.ev_key.p;
+	p.ev_val = b.ev_val.p;
+	if ((rc = bidir_launch(c, s, p)) != TUTU_OK) return rc;
+	HIP_TRY(hipStreamSynchronize(s));
+	std::vector<float4> h_own(n), h_val(nev);
+	std::vector<unsigned long long> h_key(nev);
+	HIP_TRY(hipMemcpy(h_own.data(), b.own.p, sizeof(float4) * n, hipMemcpyDeviceToHost));
+	HIP_TRY(hipMemcpy(h_val.data(), b.ev_val.p, sizeof(float4) * nev, hipMemcpyDeviceToHost));
+	HIP_TRY(hipMemcpy(h_key.data(), b.ev_key.p, sizeof(unsigned long long) * nev, hipMemcpyDeviceToHost));
+	for (uint32_t i = 0; i < n; i++) {
+		own3[3 * (size_t)i + 0] = h_own[i].x;
+		own3[3 * (size_t)i + 1] = h_own[i].y;
+		own3[3 * (size_t)i + 2] = h_own[i].z;
+		alive[i] = h_own[i].w < 0.f ? 0 : 1;
+		int k = 0;
+		for (; k < p.ev_stride; k++) {
+			const size_t e = (size_t)i * p.ev_stride + k;
+			if (h_key[e] == ~0ull) break;
+			if (k < max_ev) {
+				const size_t o = (size_t)i * max_ev + k;
+				ev_op[o] = (int32_t)h_val[e].w;
+				ev_index[o] = (int32_t)(h_key[e] >> 40);
+				ev_rgb[3 * o + 0] = h_val[e].x;
+				ev_rgb[3 * o + 1] = h_val[e].y;
+				ev_rgb[3 * o + 2] = h_val[e].z;
+			}
+		}
+		n_ev[i] = k;
+	}
 	return TUTU_OK;
 }
 
