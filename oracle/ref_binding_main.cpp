@@ -70,7 +70,7 @@ int main(int argc, char* argv[]) {
 	SPP_inv = 1.f / SPP;
 	g.scene.initializeBVH();  // Renderer::Renderer, Renderer.hpp:53 (also: Scene::~Scene deletes the accel pointer, Scene.hpp:37-39)
 	g.initializeLights();     // Renderer::render, Renderer.hpp:64
-	HipPathTracing integ(&g, nullptr);
+	HipPathTracing integ(&g, nullptr, g.integrateType);  // the `integrator` keyword of the config (Renderer.hpp:41-49)
 	if (dry) {
 		HipPathTracing::FlatScene f;
 		HipPathTracing::flatten(&g, f);

@@ -100,6 +100,19 @@ def test_reference_front_end_renders_through_the_binding(built, tmp_path):
         lv = ctx.quantise(img.reshape(-1))
     got = np.array(ppm["ref"].split()[4:], np.int32)
     assert (got != lv).mean() < 1e-3  # quantise() on the device vs powf on the host: isolated one-level differences
+    # `integrator bdpt` in the config: the reference's front-end hands g->integrateType to the same binding
+    bcfg = run / "b.txt"
+    bcfg.write_text(CONFIG.replace("integrator path", "integrator bdpt"))
+    r = subprocess.run([os.path.join(REF_BIN, "ref_binding"), str(bcfg), "--spp", "4", "--key1", "7"] + specs, cwd=run, capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    got = np.array(open(run / "b.ppm", "rb").read().split()[4:], np.int32)
+    # (the mesh specs give the light the Material default diffuse 0.9, as src/main_cornellBox.cpp does; BDPT connects through
+    # light-path vertices that landed on the emitter and reads it there, PathTracing never does)
+    emissive = np.flatnonzero(np.asarray(sc["mats"]["emission"]).any(1))
+    sc["mats"]["diffuse"][emissive] = np.float32(0.9)
+    with tr.Context(sc) as ctx:
+        lv = ctx.quantise(ctx.render_integrator("bdpt", 4, 0x5EED0001, 7).reshape(-1))
+    assert (got != lv).mean() < 1e-3
 
 
 @pytest.mark.gpu
@@ -118,11 +131,21 @@ def test_reference_scene_programs_over_the_bundled_front_end(built, tmp_path):
         os.remove(run / "cfg.ppm")
     assert out["ref_main"] == out["app"]
     assert len(out["app"].split()) == 4 + 96 * 72 * 3
-    # the veach program's config asks for `integrator bdpt`: outside the path this library replaces -> refused, not ignored
-    vcfg = run / "v.txt"
-    vcfg.write_text(CONFIG.replace("integrator path", "integrator bdpt"))
-    r = subprocess.run([os.path.join(REF_BIN, "main_veach_ref"), str(vcfg)], cwd=run, capture_output=True, text=True)
-    assert r.returncode != 0 and "ERROR" in r.stdout
+    # the other branches of Renderer's switch (Renderer.hpp:44-49): `integrator light | naivept | bdpt` select the device
+    # versions of LightTracing / NaivePT / BDPT through the same binding, from both front-ends
+    for integ in ("light", "naivept", "bdpt"):
+        icfg = run / f"{integ}.txt"
+        icfg.write_text(CONFIG.replace("integrator path", f"integrator {integ}"))
+        got = {}
+        for tag, exe in (("ref_main", os.path.join(REF_BIN, "main_cornellBox_ref")), ("app", os.path.join(APPS, "main_cornellBox"))):
+            r = subprocess.run([exe, str(icfg)], cwd=run, capture_output=True, text=True)
+            assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+            got[tag] = open(run / f"{integ}.ppm", "rb").read()
+            os.remove(run / f"{integ}.ppm")
+        assert got["ref_main"] == got["app"]
+        levels = np.array(got["app"].split()[4:], np.int32)
+        # (NaivePT shows the emitter and nothing else: the emission of the first hit, NaivePT.hpp:158)
+        assert len(levels) == 96 * 72 * 3 and (levels > 0).mean() > (0.003 if integ == "naivept" else 0.3) and got["app"] != out["app"]
 
 
 @pytest.mark.gpu

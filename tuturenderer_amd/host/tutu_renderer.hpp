@@ -629,11 +629,8 @@ class Renderer {
 public:
 	explicit Renderer(PPMGenerator* ppmg) : g(ppmg) {
 		interStrategy = new IIntersectStrategy();  // traversal lives on the device; kept for the member's sake
-		if (g->integrateType == 0) integrator = new HipPathTracing(g, interStrategy);
-		else {
-			std::cout << "ERROR: only `integrator path` is built into the GPU renderer (light / naivept / bdpt are outside its scope)\n";
-			exit(-1);
-		}
+		// Renderer.hpp:41-49: path / light / naivept / bdpt -- all four run on the device
+		integrator = new HipPathTracing(g, interStrategy, g->integrateType);
 		g->scene.initializeBVH();
 	}
 	~Renderer() {

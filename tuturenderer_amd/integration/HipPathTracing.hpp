@@ -10,6 +10,8 @@
 //   * the reference itself:   #include "PathTracing.hpp" (or IIntegrator.hpp + PPMGenerator.hpp), then this file, and in
 //                             Renderer.hpp:42  `integrator = new HipPathTracing(g, interStrategy);`
 //                             (tests/test_boundary_reference.py compiles exactly that against /root/reference/include);
+//                             the other three branches of that switch (Renderer.hpp:44-49: LightTracing, NaivePT, BDPT) become
+//                             `new HipPathTracing(g, interStrategy, g->integrateType)` -- tutu_hip_render_integrator;
 //   * the bundled front-end:  tuturenderer_amd/host/tutu_renderer.hpp includes this file after its own declarations.
 // Optional knobs (plain globals, defined here): TUTU_SEED0/1 = the Philox key (replaces the random_device seed,
 // global.hpp:193), TUTU_SPP_PER_PASS, TUTU_GPUS (0 = every HIP device; N > device count puts several contexts on a device).
@@ -40,7 +42,8 @@ inline int TUTU_GPUS = 0;
 
 class HipPathTracing : public IIntegrator {
 public:
-	HipPathTracing(PPMGenerator* gen, IIntersectStrategy* inters) {
+	// integrateType: PPMGenerator::integrateType -- 0 path (the hot path this library is about), 1 light, 2 naivept, 3 bdpt
+	HipPathTracing(PPMGenerator* gen, IIntersectStrategy* inters, int integrateType = 0) : type(integrateType) {
 		g = gen;
 		interStrategy = inters;
 		if (const char* e = getenv("TUTU_GPUS")) TUTU_GPUS = atoi(e);
@@ -208,7 +211,7 @@ public:
 			int ndev = 0;
 			rc = tutu_hip_device_count(&ndev);
 			if (rc != TUTU_OK || ndev <= 0) die(rc != TUTU_OK ? rc : TUTU_E_NO_DEVICE, "tutu_hip_device_count");
-			const int want = TUTU_GPUS > 0 ? TUTU_GPUS : ndev;
+			const int want = type != 0 ? 1 : (TUTU_GPUS > 0 ? TUTU_GPUS : ndev);
 			for (int k = 0; k < want; k++) {
 				TutuCtx* c = nullptr;
 				rc = tutu_hip_create(&f.sd, k % ndev, &c);
@@ -228,6 +231,14 @@ public:
 		static_assert(sizeof(Vector3f) == 3 * sizeof(float), "Vector3f must be three packed floats");
 		float* frame = &gen->cam.FrameBuffer.rgb[0].x;  // straight into the reference's framebuffer (Texture.hpp:15)
 		std::vector<TutuStats> st(ctxs.size());
+		if (type != 0) {
+			// LightTracing / NaivePT / BDPT: what a unit does to the frame depends on the units before it (setRGB replaces),
+			// so the frame is assembled on ONE device (the first context)
+			rc = tutu_hip_render_integrator(ctxs[0], type, &f.cd, SPP, TUTU_SEED0, TUTU_SEED1, frame, st.data());
+			if (rc != TUTU_OK) die(rc, "tutu_hip_render_integrator");
+			stats = st[0];
+			return;
+		}
 		if (ctxs.size() == 1) rc = tutu_hip_render(ctxs[0], &cf, &rp, frame, st.data());
 		else rc = tutu_hip_render_multi(ctxs.data(), (int32_t)ctxs.size(), &cf, &rp, frame, st.data());
 		if (rc != TUTU_OK) die(rc, "tutu_hip_render");
@@ -240,6 +251,7 @@ public:
 	}
 
 private:
+	int type = 0;
 	std::vector<TutuCtx*> ctxs;
 	uint64_t scene_hash = 0;
 	[[noreturn]] static void die(int rc, const char* what) {
