@@ -237,7 +237,12 @@ def main():
                     "achieved": ach, "frac": ach / HBM_PEAK_GBS}
 
         src = kernel_table(excl, npix) if excl is not None else tab
-        dom = max(src, key=lambda k: src[k]["ms"])
+        # The roofline object prices a kernel against HBM.  With the scene staged in LDS (lds_scene) the traversal kernels read
+        # their nodes and triangles from LDS and touch HBM only for 48 B of ray / hit per ray: their bound is VALU issue (the
+        # committed PMC collection gives the share of issue cycles, `valu_issue_frac` below), pricing them against 8 TB/s says
+        # nothing.  The top-level kernel is then the HBM-bound one, k_shade; otherwise the kernel with the most exclusive time.
+        by_time = max(src, key=lambda k: src[k]["ms"])
+        dom = "k_shade" if lds_scene else by_time
         top = priced(src, dom)
         # measured HBM traffic of that kernel: a committed PMC collection (profiles/make_traffic.py), stored per unit
         # together with the config and pass size it was collected at; refused when either does not match this run
@@ -257,7 +262,16 @@ def main():
                     pipeline_hbm = {"hbm_bytes_per_sample": tj["hbm_bytes_per_sample"],
                                     "frac": value * 1e6 * tj["hbm_bytes_per_sample"] / (HBM_PEAK_GBS * 1e9),
                                     "note": "measured HBM bytes per sample (all kernels, committed PMC collection) x this run's samples/s / 8 TB/s"}
-        roofline = {"bound": "hbm", "kernel": dom, "achieved": top["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": top["frac"],
+        sq = {}
+        if os.path.exists(prof):
+            tj2 = json.load(open(prof)).get(args.config)
+            if isinstance(tj2, dict) and tj2.get("spp_per_pass") == spp_per_pass:
+                for k, e in tj2["kernels"].items():
+                    sq[k] = {m: e[m] for m in ("valu_issue_frac", "valu_lanes_active", "salu_per_valu", "hbm_bytes_per_unit") if m in e}
+        roofline = {"bound": "hbm", "kernel": dom, "dominant_by_time": by_time,
+                    "kernel_note": ("scene in LDS: the traversal kernels are VALU-issue bound (per_kernel.*.pmc.valu_issue_frac), "
+                                    "k_shade is the HBM-bound kernel") if lds_scene else "the kernel with the most exclusive time",
+                    "achieved": top["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": top["frac"],
                     "traffic": traffic, "traffic_note": traffic_note,
                     "avg_launch_ms": top["avg_launch_ms"], "launches": top["launches"], "units_per_launch": top["units_per_launch"],
                     "algorithmic_bytes_per_unit": per_unit[dom], "hbm_bytes_per_unit": hbm_unit[dom],
@@ -274,7 +288,8 @@ def main():
                         "lanes_active_node_step_any": agg["nodes_any"] / max(64 * agg["wave_node_steps_any"], 1),
                         "lanes_active_leaf_step_any": agg["leaves_any"] / max(64 * agg["wave_leaf_steps_any"], 1),
                         "note": "G rays/s of the kernel alone (exclusive step); lanes_active = share of a wave's 64 lanes with work in a step"},
-                    "per_kernel": {k: dict(priced(src, k), algorithmic_bytes_per_unit=per_unit[k], hbm_bytes_per_unit=hbm_unit[k]) for k in src}}
+                    "per_kernel": {k: dict(priced(src, k), algorithmic_bytes_per_unit=per_unit[k], hbm_bytes_per_unit=hbm_unit[k],
+                                           bound=("valu" if (lds_scene and k != "k_shade") else "hbm"), pmc=sq.get(k)) for k in src}}
         if excl is not None:
             roofline["exclusive_step_ms"] = excl["ms_total"]
             roofline["exclusive_kernel_ms_per_step"] = {"k_trace_closest": excl["ms_trace_closest"], "k_trace_any": excl["ms_trace_any"],

@@ -7,7 +7,14 @@ vertex / per ray) together with the config and pass size they were collected at 
 Corrections per /opt/skills/guides/MI355X_MICROARCH.md (section HBM): FETCH_SIZE and WRITE_SIZE are in KiB; on gfx950
 FETCH_SIZE reports half the bytes of wide (16 B/lane) coalesced reads, so it is doubled; WRITE_SIZE is exact for
 16 B/lane stores.  The record arrays of this pipeline are read and written as dwordx4 per lane.  Units per kernel come
-from the bench line of the same run (g2.log): extension rays for k_trace_closest and k_shade, shadow rays for k_trace_any."""
+from the bench line of the same run (g2.log): extension rays for k_trace_closest and k_shade, shadow rays for k_trace_any.
+
+Also per kernel, from the SQ counters of the same collection (totals over the same dispatches, one counter group per pass):
+  valu_issue_frac   = 4 * SQ_INSTS_VALU / (GRBM_GUI_ACTIVE / 8 * 256 CUs * 4 SIMDs): the share of the SIMDs' issue cycles
+                      taken by vector instructions (a wave64 VALU instruction occupies its 16-lane SIMD for 4 cycles;
+                      GRBM_GUI_ACTIVE is summed over the 8 XCDs) -- the roofline of a kernel that does not touch memory;
+  valu_lanes_active = SQ_THREAD_CYCLES_VALU / (64 * SQ_ACTIVE_INST_VALU): lanes switched on in an average vector instruction;
+  salu_per_valu     = SQ_INSTS_SALU / SQ_INSTS_VALU."""
 import csv
 import glob
 import json
@@ -35,7 +42,8 @@ def main(root, tag, cfg):
     for f in glob.glob(f"{root}/g*/**/*counter_collection.csv", recursive=True):
         for row in csv.DictReader(open(f)):
             st = stage(row["Kernel_Name"])
-            if st and row["Counter_Name"] in ("FETCH_SIZE", "WRITE_SIZE"):
+            if st and row["Counter_Name"] in ("FETCH_SIZE", "WRITE_SIZE", "SQ_INSTS_VALU", "GRBM_GUI_ACTIVE", "SQ_THREAD_CYCLES_VALU",
+                                              "SQ_ACTIVE_INST_VALU", "SQ_INSTS_SALU"):
                 val[st][row["Counter_Name"]] += float(row["Counter_Value"])
                 disp[st][row["Counter_Name"]].add(row["Dispatch_Id"])
     line = json.loads([x for x in open(f"{root}/g2.log") if x.startswith("{")][0])
@@ -47,11 +55,17 @@ def main(root, tag, cfg):
         fetch = 2.0 * val[st]["FETCH_SIZE"] * 1024.0
         write = val[st]["WRITE_SIZE"] * 1024.0
         total += fetch + write
-        n = max(len(v) for v in disp[st].values())
+        n = max(len(disp[st][c]) for c in ("FETCH_SIZE", "WRITE_SIZE") if c in disp[st])
         e = {"launches_profiled": n, "fetch_bytes_x2": fetch, "write_bytes": write, "hbm_bytes_per_launch": (fetch + write) / n}
         if st in units and units[st] > 0:
             e["units"] = units[st]
             e["hbm_bytes_per_unit"] = (fetch + write) / units[st]
+        v = val[st]
+        if v.get("GRBM_GUI_ACTIVE") and v.get("SQ_INSTS_VALU"):
+            e["valu_issue_frac"] = 4.0 * v["SQ_INSTS_VALU"] / (v["GRBM_GUI_ACTIVE"] / 8.0 * 256 * 4)
+            e["salu_per_valu"] = v.get("SQ_INSTS_SALU", 0.0) / v["SQ_INSTS_VALU"]
+        if v.get("SQ_ACTIVE_INST_VALU") and v.get("SQ_THREAD_CYCLES_VALU"):
+            e["valu_lanes_active"] = v["SQ_THREAD_CYCLES_VALU"] / (64.0 * v["SQ_ACTIVE_INST_VALU"])
         kernels[st] = e
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "traffic.json")
     try:

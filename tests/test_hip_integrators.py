@@ -89,6 +89,9 @@ def test_frame_matches_the_restatement_and_the_reference_build(tr, port, name, i
         assert ctx.last_stats["passes"] > 10
     assert st["samples"] == sc["width"] * sc["height"] * spp
     assert bit_equal(img, img_small)
+    assert (np.isnan(img) == np.isnan(want)).all()  # (LightTracing / BDPT do not drop NaN splats; PathTracing.hpp:507-513 does)
+    fin = ~np.isnan(want).any(-1)
+    img, want, gold = img[fin], want[fin], gold[fin]
     l2 = np.sqrt(((img.astype(np.float64) - want) ** 2).sum(-1))
     same = (img.view(np.uint32) == want.view(np.uint32)).all(-1).mean()
     rel = l2 / np.maximum(np.sqrt((want.astype(np.float64) ** 2).sum(-1)), 1.0)
@@ -101,7 +104,7 @@ def test_frame_matches_the_restatement_and_the_reference_build(tr, port, name, i
         assert np.abs(img - gold).max() <= 1e-5 * max(1.0, float(np.abs(gold).max()))
     else:
         # (MICROFACET_T under BDPT is heavy-tailed -- frame means of 31 and 113 from two streams: its clipped mean moves by 10 %)
-        a, b = np.minimum(img, 10.0).mean(), np.minimum(gold, 10.0).mean()
+        a, b = np.nanmean(np.minimum(img, 10.0)), np.nanmean(np.minimum(gold, 10.0))
         assert abs(a - b) < (0.15 if name == "cornell_ggxT_mirror" else 0.06) * max(b, 1e-3) + 2e-3, (a, b)
 
 
@@ -117,7 +120,7 @@ def test_larger_frame_batches_and_argument_checks(tr, port):
             ctx.set_option("bidir_units", 20000)
             b = ctx.render_integrator(iname, 8, pc.KEY0, 77)
             assert ctx.last_stats["passes"] == 8
-            assert bit_equal(a, b) and np.isfinite(a).all() and a.mean() > 0.1
+            assert bit_equal(a, b) and np.nanmean(a) > 0.1
             # probe pixels against the restatement's units: the own-pixel estimate of BDPT, the splats of both
         with pytest.raises(tr.TutuError):
             ctx.render_integrator("path", 4, pc.KEY0, 1)   # tutu_hip_render is that integrator
@@ -130,6 +133,9 @@ def test_larger_frame_batches_and_argument_checks(tr, port):
     S = port.scene(sc)
     want = S.render_integrator_units(3, 8, pc.KEY0, 77)
     S.close()
+    assert (np.isnan(b) == np.isnan(want)).all()
+    fin = ~np.isnan(want).any(-1)
+    b, want = b[fin], want[fin]
     l2 = np.sqrt(((b.astype(np.float64) - want) ** 2).sum(-1))
     rel = l2 / np.maximum(np.sqrt((want.astype(np.float64) ** 2).sum(-1)), 1.0)
     print(f"160x120x8 bdpt: pixels off by > 1e-3 relative {(rel > 1e-3).mean():.4f}, mean L2 of the rest {l2[rel <= 1e-3].mean():.3e}")
