@@ -421,6 +421,42 @@ def test_full_size_properties(tr):
     assert np.allclose(c[lit], np.array(scenes.CB_EMISSION, np.float32))
 
 
+def test_sliver_mesh_reference_cap_and_threaded_build(tr, monkeypatch):
+    """90 000 long thin triangles at random angles: early split clipping would give each ~50 references; the scene's extra
+    references are capped at 4 Mi (the per-triangle limit is halved until they fit).  The walked tree is built on several host
+    threads; it is the tree one thread builds, and the hits are the reference tree's, bit for bit."""
+    from tuturenderer_amd import scenes
+
+    rng = np.random.default_rng(9)
+    n = 90000
+    c = rng.uniform(0, 100, (n, 1, 3)).astype(np.float32)
+    d = rng.normal(size=(n, 1, 3)).astype(np.float32)
+    d /= np.linalg.norm(d, axis=-1, keepdims=True)
+    w = rng.normal(size=(n, 1, 3)).astype(np.float32) * np.float32(0.15)
+    verts = np.concatenate([c - 20 * d, c + 20 * d + w, c + 20 * d - w], 1).astype(np.float32)  # (n, 3, 3)
+    sc = scenes.cornell_box(64, 64)
+    sc = dict(sc, verts=verts.reshape(-1, 9), normals=scenes.face_normals(verts.reshape(-1, 9)), mat_id=np.zeros(n, np.int32))
+    o = rng.uniform(0, 100, (200000, 3)).astype(np.float32)
+    dd = rng.normal(size=(200000, 3)).astype(np.float32)
+    dd /= np.linalg.norm(dd, axis=1, keepdims=True)
+    hits = {}
+    for tag, env in (("threads", {}), ("serial", {"TUTU_BUILD_SERIAL": "1"}), ("reference_tree", {"TUTU_NO_SAH": "1"})):
+        for k in ("TUTU_BUILD_SERIAL", "TUTU_NO_SAH"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        with tr.Context(sc) as ctx:
+            refs = ctx.get_option("n_refs")
+            hits[tag] = ctx.trace_closest(o, dd)
+        if tag != "reference_tree":
+            assert 10 * n < refs <= n + (4 << 20), refs
+    for k in ("TUTU_BUILD_SERIAL", "TUTU_NO_SAH"):
+        monkeypatch.delenv(k, raising=False)
+    assert (hits["threads"]["tri"] >= 0).mean() > 0.2
+    for tag in ("serial", "reference_tree"):
+        assert bit_equal(hits["threads"]["tri"], hits[tag]["tri"]) and bit_equal(hits["threads"]["t"], hits[tag]["t"]), tag
+
+
 @pytest.mark.parametrize("name", ["bunny", "broom"])
 def test_stand_in_scenes_per_sample_parity(tr, name):
     """BASELINE configs 3 and 4 (synthetic stand-ins, 82 k / 48 k triangles, BVH depth 17 / 16, rough glass /

@@ -7,6 +7,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <thread>
 
 namespace tutu {
 
@@ -272,13 +273,35 @@ struct SahBuilder {
 				return c1 < c2 || (c1 == c2 && o1 < o2);
 			});
 		}
-		const int l = build(first, middle, depth + 1);
-		const int r = build(middle, last, depth + 1);
+		int l, r;
+		if (n >= kForkMin && depth < kForkDepth && !serial) {
+			// big subtrees near the root: the right one on another thread, into its own node array, appended afterwards with
+			// its indices shifted -- the array stays in pre-order and the tree is the one the sequential build produces
+			std::vector<BuildNode> ro;
+			SahBuilder rb{tb, ro};
+			std::thread th([&rb, middle, last, depth] { rb.build(middle, last, depth + 1); });
+			l = build(first, middle, depth + 1);
+			th.join();
+			const int off = (int)out.size();
+			for (BuildNode& bn : ro) {
+				if (bn.left >= 0) bn.left += off;
+				if (bn.right >= 0) bn.right += off;
+			}
+			out.insert(out.end(), ro.begin(), ro.end());
+			r = off;
+			if (rb.max_depth > max_depth) max_depth = rb.max_depth;
+		} else {
+			l = build(first, middle, depth + 1);
+			r = build(middle, last, depth + 1);
+		}
 		out[id].left = l;
 		out[id].right = r;
 		set_bounds(id, nb);
 		return id;
 	}
+	bool serial = getenv("TUTU_BUILD_SERIAL") != nullptr;  // one thread (the tree is the same either way)
+	static constexpr size_t kForkMin = 32768;   // objects below which a subtree is not worth a thread
+	static constexpr uint32_t kForkDepth = 4;   // at most 2^4 threads
 };
 
 
@@ -546,24 +569,32 @@ int build_host_scene(const TutuSceneDesc* d, HostScene& hs) {
 		if (!tree.empty())
 			for (int k = 0; k < 3; k++) diag = std::max(diag, (double)tree[0].pmax[k] - (double)tree[0].pmin[k]);
 		const double pad = 4e-6 * diag;
-		for (uint32_t o = 0; o < n; o++) {
-			if (obj_sph[o] >= 0 || !presplit) {
-				refs.push_back(Ref{tb[o], (int32_t)o});
-				continue;
+		// The extra references of a scene are capped (a mesh of a million slivers would otherwise grow 64-fold: tree memory
+		// and build time go with the reference count): when the cap is exceeded the per-triangle limit is halved and the
+		// references are generated again.  4 Mi extra references ~ 0.5 GB of nodes and a few seconds of build.
+		const size_t extra_cap = (size_t)4 << 20;
+		for (int per_tri = kMaxPiecesPerTri; per_tri >= 1; per_tri /= 2) {
+			refs.clear();
+			for (uint32_t o = 0; o < n; o++) {
+				if (obj_sph[o] >= 0 || !presplit || per_tri == 1) {
+					refs.push_back(Ref{tb[o], (int32_t)o});
+					continue;
+				}
+				const float* v = d->verts + 9 * (size_t)obj_tri[o];
+				bool finite = true;
+				for (int k = 0; k < 9; k++) finite = finite && std::isfinite(v[k]);
+				Poly q;
+				q.n = 3;
+				for (int i = 0; i < 3; i++)
+					for (int k = 0; k < 3; k++) q.p[i][k] = v[3 * i + k];
+				const size_t before = refs.size();
+				if (finite) split_piece(q, per_tri, pad, (int32_t)o, refs);
+				if (refs.size() == before + 1 || !finite) {  // not split: keep the object's own box (exactly the reference's leaf box)
+					refs.resize(before);
+					refs.push_back(Ref{tb[o], (int32_t)o});
+				}
 			}
-			const float* v = d->verts + 9 * (size_t)obj_tri[o];
-			bool finite = true;
-			for (int k = 0; k < 9; k++) finite = finite && std::isfinite(v[k]);
-			Poly q;
-			q.n = 3;
-			for (int i = 0; i < 3; i++)
-				for (int k = 0; k < 3; k++) q.p[i][k] = v[3 * i + k];
-			const size_t before = refs.size();
-			if (finite) split_piece(q, kMaxPiecesPerTri, pad, (int32_t)o, refs);
-			if (refs.size() == before + 1 || !finite) {  // not split: keep the object's own box (exactly the reference's leaf box)
-				refs.resize(before);
-				refs.push_back(Ref{tb[o], (int32_t)o});
-			}
+			if (refs.size() <= (size_t)n + extra_cap) break;
 		}
 		std::vector<Box> rb(refs.size());
 		for (size_t i = 0; i < refs.size(); i++) rb[i] = refs[i].box;
