@@ -592,7 +592,7 @@ def test_device_rng_known_answers(fn_ctx, port):
 
 # ------------------------------------------------------------------------------------------------------------
 # the BASELINE frames themselves
-def _frame_checks(tr, port, sc, key1, spp, n_probe_pixels=12, n_samples=2000):
+def _frame_checks(tr, port, sc, key1, spp, n_probe_pixels=12, n_samples=2000, low_spp=2):
     """Properties of a full-size, full-spp frame that do not need a CPU render of it:
       * the frame with the default four passes in flight == the frame with one pass in flight, bit for bit;
       * a pixel of the frame == (1/spp) * the sum, in sample order and dropping NaN samples, of that pixel's per-sample
@@ -626,13 +626,13 @@ def _frame_checks(tr, port, sc, key1, spp, n_probe_pixels=12, n_samples=2000):
         Lg = ctx.trace_samples(pix, smp, pc.KEY0, key1)
     S = port.scene(sc)
     Lw = S.trace_samples(pix, smp, pc.KEY0, key1)
-    low = S.render(2, pc.KEY0, key1, nthreads=16)
+    low = S.render(low_spp, pc.KEY0, key1, nthreads=16)
     S.close()
     fin = ~(np.isnan(Lg).any(1) | np.isnan(Lw).any(1))
     err = np.abs(Lg[fin] - Lw[fin]).max(1)
     scale = np.maximum(np.abs(Lw[fin]).max(1), 1e-3)
     assert ((err > 1e-4 * scale + 1e-6).mean()) < 5e-3
-    # Monte-Carlo error of the 2-spp CPU mean: per-channel variance of its pixels / number of pixels (plus the frame's own, smaller)
+    # Monte-Carlo error of the low-spp CPU mean: per-channel variance of its pixels / number of pixels (plus the frame's own, smaller)
     for ch in range(3):
         sigma = low[..., ch].std() / np.sqrt(low[..., ch].size) * 1.5
         assert abs(frame[..., ch].mean() - low[..., ch].mean()) < 5 * sigma + 1e-4, (ch, frame[..., ch].mean(), low[..., ch].mean(), sigma)
@@ -655,6 +655,23 @@ def test_config5_frame_veach_800x600_512spp(tr, port):
 
     frame, st = _frame_checks(tr, port, scenes.veach_room(800, 600, small_light=False), key1=5, spp=512, n_probe_pixels=8)
     assert abs(frame.mean() - 0.2149) < 0.01  # veach without the small light
+
+
+def test_config3_frame_bunny_stand_in_1024x1024_256spp(tr, port):
+    """BASELINE configs[2] at its size and spp on the stand-in mesh (81 942 triangles, MICROFACET_T blob: tree in HBM)"""
+    from tuturenderer_amd import scenes
+
+    frame, st = _frame_checks(tr, port, scenes.bunny_box(1024, 1024), key1=3, spp=256, n_probe_pixels=8)
+    assert 0.2 < frame.mean() < 0.6 and st["passes"] >= 16
+
+
+def test_config4_frame_broom_stand_in_1600x900_1024spp(tr, port):
+    """BASELINE configs[3] at its size and spp on the stand-in (48 012 thin prisms, 1.37 M references in the walked tree):
+    1.47 G samples per frame, twice (four passes in flight == one)"""
+    from tuturenderer_amd import scenes
+
+    frame, st = _frame_checks(tr, port, scenes.broom_room(1600, 900), key1=4, spp=1024, n_probe_pixels=4, n_samples=1500, low_spp=1)
+    assert st["samples"] == 1600 * 900 * 1024 and frame.mean() > 0.01
 
 
 def test_two_ranks_on_one_gpu_gather_the_single_process_frame(tr, tmp_path):
