@@ -299,6 +299,18 @@ def main():
                 "note": "four wavefront passes in flight on four streams: a launch's HIP-event duration includes the time it shares the device "
                         "with other streams' kernels, so these are NOT kernel durations (they sum to more than ms_per_step)",
                 "per_kernel_ms_per_step": {k: tab[k]["ms"] / args.steps for k in tab}}
+        # The pipeline as a whole against the VALU roofline: every kernel's exclusive time x the share of the SIMDs' issue cycles
+        # its vector instructions take (committed PMC collection) = the time the frame would need if vector instructions were
+        # issued back to back on every SIMD; divided by the measured frame time (four passes overlapped).
+        pipeline_valu = None
+        if excl is not None and sq:
+            names = {"k_trace_closest": "ms_trace_closest", "k_trace_any": "ms_trace_any", "k_shade": "ms_shade_material",
+                     "k_shade_depth0": "ms_shade_first", "k_shade_connect_only": "ms_shade_terminal", "other": "ms_other"}
+            if all(k in sq and "valu_issue_frac" in sq[k] for k in names):
+                busy = sum(excl[f] * sq[k]["valu_issue_frac"] for k, f in names.items())
+                pipeline_valu = {"valu_busy_ms_per_step": busy, "frac": busy / (dt / args.steps * 1e3),
+                                 "note": "sum over kernels of exclusive ms x valu_issue_frac (PMC: 4 x SQ_INSTS_VALU / SIMD cycles), / ms_per_step: "
+                                         "the share of the chip's vector issue slots the overlapped frame uses"}
         rendered = max(npix * spp * args.steps, 1)
         seg_per_sample = tab["k_shade"]["units"] / rendered
         sh_per_sample = agg["shadow_rays"] / rendered
@@ -306,7 +318,7 @@ def main():
             "segments_per_sample": seg_per_sample, "shadow_rays_per_sample": sh_per_sample,
             "algorithmic_bytes_per_sample": seg_per_sample * (per_unit["k_trace_closest"] + per_unit["k_shade"]) + sh_per_sample * per_unit["k_trace_any"],
             "of_which_lds_served": (seg_per_sample * scene_bytes["k_trace_closest"] + sh_per_sample * scene_bytes["k_trace_any"]) if lds_scene else 0.0,
-            "measured_hbm": pipeline_hbm}
+            "measured_hbm": pipeline_hbm, "valu": pipeline_valu}
         line = {
             "metric": METRIC if args.config == "c2" else "Msamples/sec (rays traced/sec)",
             "value": value, "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
