@@ -422,9 +422,9 @@ def test_full_size_properties(tr):
 
 
 def test_sliver_mesh_reference_cap_and_threaded_build(tr, monkeypatch):
-    """90 000 long thin triangles at random angles: early split clipping would give each ~50 references; the scene's extra
-    references are capped at 4 Mi (the per-triangle limit is halved until they fit).  The walked tree is built on several host
-    threads; it is the tree one thread builds, and the hits are the reference tree's, bit for bit."""
+    """90 000 long thin triangles at random angles: early split clipping gives each ~14 references; the scene's extra references
+    are capped (4 Mi by default, 1 Mi here: the per-triangle limit is halved until they fit).  The walked tree is built on
+    several host threads; it is the tree one thread builds, and the hits are the reference tree's, bit for bit."""
     from tuturenderer_amd import scenes
 
     rng = np.random.default_rng(9)
@@ -445,13 +445,16 @@ def test_sliver_mesh_reference_cap_and_threaded_build(tr, monkeypatch):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
+        monkeypatch.setenv("TUTU_SPLIT_CAP_MI", "1")
         with tr.Context(sc) as ctx:
             refs = ctx.get_option("n_refs")
             hits[tag] = ctx.trace_closest(o, dd)
         if tag != "reference_tree":
-            assert 10 * n < refs <= n + (4 << 20), refs
-    for k in ("TUTU_BUILD_SERIAL", "TUTU_NO_SAH"):
+            assert 5 * n < refs <= n + (1 << 20), refs
+    for k in ("TUTU_BUILD_SERIAL", "TUTU_NO_SAH", "TUTU_SPLIT_CAP_MI"):
         monkeypatch.delenv(k, raising=False)
+    with tr.Context(sc) as ctx:
+        assert ctx.get_option("n_refs") > n + (1 << 20)  # without the lowered cap: ~14 references per sliver
     assert (hits["threads"]["tri"] >= 0).mean() > 0.2
     for tag in ("serial", "reference_tree"):
         assert bit_equal(hits["threads"]["tri"], hits[tag]["tri"]) and bit_equal(hits["threads"]["t"], hits[tag]["t"]), tag

@@ -315,7 +315,7 @@ struct SahBuilder {
 // object is hit is still decided by the reference's triangle test and its own leaf box (device_trace.h), and hitting
 // the same object through two leaves updates (t, index) idempotently.
 // Criterion: a piece is cut at the middle of its box's longest axis when the two halves' boxes together have at most
-// kSplitGain of its box's surface area.  Cutting a compact triangle (axis-aligned or not) leaves ~0.75 -- not worth a
+// kSplitGain (0.70) of its box's surface area.  Cutting a compact triangle (axis-aligned or not) leaves ~0.75 -- not worth a
 // reference; cutting a sliver that runs diagonally through its box leaves ~0.5, again and again until the pieces are
 // as long as the sliver is wide.  At most kMaxPiecesPerTri pieces per triangle.  Piece boxes are padded by a few 1e-6
 // of the scene's size, far more than the rounding of the clip arithmetic and of the reference's own hit points.
@@ -367,8 +367,8 @@ static void poly_bounds(const Poly& q, double lo[3], double hi[3]) {
 			hi[k] = std::max(hi[k], q.p[i][k]);
 		}
 }
-static const double kSplitGain = 0.66;
-static const int kMaxPiecesPerTri = 64;
+static double kSplitGain = 0.70;    // (0.66 / 64 pieces at first; swept on the two scenes that have slivers: 16 pieces at 0.70 are
+static int kMaxPiecesPerTri = 16;   //  +16 % on the broom stand-in, +9 % on the veach room -- fewer, deeper-cut references)
 static double box_half_area(const double lo[3], const double hi[3]) {
 	const double d[3] = {hi[0] - lo[0], hi[1] - lo[1], hi[2] - lo[2]};
 	return d[0] * d[1] + d[1] * d[2] + d[2] * d[0];
@@ -572,7 +572,10 @@ int build_host_scene(const TutuSceneDesc* d, HostScene& hs) {
 		// The extra references of a scene are capped (a mesh of a million slivers would otherwise grow 64-fold: tree memory
 		// and build time go with the reference count): when the cap is exceeded the per-triangle limit is halved and the
 		// references are generated again.  4 Mi extra references ~ 0.5 GB of nodes and a few seconds of build.
-		const size_t extra_cap = (size_t)4 << 20;
+		// (environment overrides for experiments and tests; none of them can change a hit, only the walked tree)
+		if (const char* e = getenv("TUTU_SPLIT_MAX")) kMaxPiecesPerTri = std::max(1, std::min(4096, atoi(e)));
+		if (const char* e = getenv("TUTU_SPLIT_GAIN")) kSplitGain = std::max(0.3, std::min(0.99, atof(e)));
+		const size_t extra_cap = (size_t)(getenv("TUTU_SPLIT_CAP_MI") ? std::max(0, std::min(64, atoi(getenv("TUTU_SPLIT_CAP_MI")))) : 4) << 20;
 		for (int per_tri = kMaxPiecesPerTri; per_tri >= 1; per_tri /= 2) {
 			refs.clear();
 			for (uint32_t o = 0; o < n; o++) {
