@@ -250,8 +250,42 @@ struct SahBuilder {
 				}
 			}
 		}
+		// small nodes: every split position of every axis, exactly (objects sorted by centroid; prefix / suffix boxes) --
+		// the binned search above only sees 15 planes per axis, and the last levels of the tree are where most node visits
+		// and all leaf tests happen
+		int sweep_axis = -1, sweep_split = -1;  // left side = the first sweep_split objects in centroid order of sweep_axis
+		if (!force_median && n > 2 && n <= (size_t)sweep_max) {
+			double sw_cost = best_axis >= 0 ? best_cost : 1e300;
+			std::vector<int32_t> ord(n);
+			std::vector<double> ra(n);
+			for (int axis = 0; axis < 3; axis++) {
+				for (size_t i = 0; i < n; i++) ord[i] = first[i];
+				const std::vector<Box>& b = tb;
+				std::stable_sort(ord.begin(), ord.end(), [&b, axis](int32_t o1, int32_t o2) { return centroid(b[o1], axis) < centroid(b[o2], axis); });
+				Box acc = tb[ord[n - 1]];
+				for (size_t i = n - 1; i >= 1; i--) {
+					acc = i == n - 1 ? tb[ord[i]] : box_union(acc, tb[ord[i]]);
+					ra[i] = area(acc);
+				}
+				acc = tb[ord[0]];
+				for (size_t i = 1; i < n; i++) {  // left = ord[0..i), right = ord[i..n)
+					if (i > 1) acc = box_union(acc, tb[ord[i - 1]]);
+					const double cost = area(acc) * (double)i + ra[i] * (double)(n - i);
+					if (cost < sw_cost) {
+						sw_cost = cost;
+						sweep_axis = axis;
+						sweep_split = (int)i;
+					}
+				}
+			}
+		}
 		int32_t* middle;
-		if (best_axis >= 0) {
+		if (sweep_axis >= 0) {
+			const std::vector<Box>& b = tb;
+			const int axis = sweep_axis;
+			std::stable_sort(first, last, [&b, axis](int32_t o1, int32_t o2) { return centroid(b[o1], axis) < centroid(b[o2], axis); });
+			middle = first + sweep_split;
+		} else if (best_axis >= 0) {
 			const float lo = cmin[best_axis], scale = (float)kBins / (cmax[best_axis] - cmin[best_axis]);
 			const std::vector<Box>& b = tb;
 			const int axis = best_axis, split = best_split;
@@ -300,6 +334,7 @@ struct SahBuilder {
 		return id;
 	}
 	bool serial = getenv("TUTU_BUILD_SERIAL") != nullptr;  // one thread (the tree is the same either way)
+	int sweep_max = getenv("TUTU_SWEEP_MAX") ? atoi(getenv("TUTU_SWEEP_MAX")) : 64;  // nodes of at most this many objects: exact SAH sweep
 	static constexpr size_t kForkMin = 32768;   // objects below which a subtree is not worth a thread
 	static constexpr uint32_t kForkDepth = 4;   // at most 2^4 threads
 };
