@@ -38,7 +38,7 @@ struct BidirParams {
 	int spp;
 	float spp_inv;
 	uint32_t n_units;
-	uint32_t first_unit;          // implicit units: unit u = first_unit + i -> pixel u / spp, sample u % spp
+	uint32_t first_pix;           // implicit units (a batch of whole pixels): unit i -> pixel first_pix + i / spp, sample i % spp
 	const uint32_t* pix_list;     // explicit units (tutu_hip_integrator_samples), else null
 	const uint32_t* smp_list;
 	int n_mats;
@@ -627,9 +627,8 @@ __global__ void __launch_bounds__(256) k_bidir(BidirParams p) {
 		pix = p.pix_list[i];
 		smp = p.smp_list[i];
 	} else {
-		const uint32_t u = p.first_unit + i;
-		pix = u / (uint32_t)p.spp;
-		smp = u % (uint32_t)p.spp;
+		pix = p.first_pix + i / (uint32_t)p.spp;
+		smp = i % (uint32_t)p.spp;
 	}
 	ShadeTabs tb;
 	tb.mats = p.sc.mats;

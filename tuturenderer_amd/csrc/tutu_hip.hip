@@ -998,7 +998,7 @@ int bidir_params(TutuCtx* c, int type, const TutuCameraDesc* cam, int spp, uint3
 	p->ev_stride = type == TUTU_INTEGRATOR_LIGHT ? 2 : (type == TUTU_INTEGRATOR_BDPT ? TUTU_BIDIR_MAX_EVENTS : 1);
 	p->pix_list = nullptr;
 	p->smp_list = nullptr;
-	p->first_unit = 0;
+	p->first_pix = 0;
 	p->own_list = nullptr;
 	return TUTU_OK;
 }
@@ -1014,7 +1014,7 @@ int bidir_launch(TutuCtx* c, hipStream_t s, const BidirParams& p) {
 int bidir_check(TutuCtx* c, int type, const TutuCameraDesc* cam, int spp) {
 	if (!c || !cam) return TUTU_E_INVALID;
 	if (type != TUTU_INTEGRATOR_LIGHT && type != TUTU_INTEGRATOR_NAIVEPT && type != TUTU_INTEGRATOR_BDPT) return TUTU_E_INVALID;
-	if (spp <= 0 || cam->width <= 0 || cam->height <= 0) return TUTU_E_INVALID;
+	if (spp <= 0 || spp > (1 << 24) || cam->width <= 0 || cam->height <= 0) return TUTU_E_INVALID;  // (as tutu_hip_render)
 	const unsigned long long npix = (unsigned long long)cam->width * (unsigned long long)cam->height;
 	if (npix >= (1ull << 24) || npix * (unsigned long long)spp >= (1ull << 36)) return TUTU_E_INVALID;  // event key: 24 + 40 bits
 	return TUTU_OK;
@@ -1067,8 +1067,7 @@ int tutu_hip_render_integrator(TutuCtx* c, int32_t type, const TutuCameraDesc* c
 	for (uint32_t pix0 = 0; pix0 < npix; pix0 += pix_per_batch) {
 		const uint32_t np = std::min(pix_per_batch, npix - pix0);
 		p.n_units = np * (uint32_t)spp;
-		p.first_unit = pix0 * (uint32_t)spp;  // < 2^36 checked; the kernel splits it again with 32-bit arithmetic:
-		if ((unsigned long long)pix0 * (unsigned long long)spp + p.n_units > 0xFFFFFFFFull) return TUTU_E_INVALID;
+		p.first_pix = pix0;
 		if ((rc = bidir_launch(c, s, p)) != TUTU_OK) return rc;
 		size_t n_ev = (size_t)p.n_units * (size_t)p.ev_stride;
 		if (type != TUTU_INTEGRATOR_LIGHT) {
