@@ -3,8 +3,10 @@
 #include "host_scene.hpp"
 
 #include <algorithm>
+#include <chrono>
 #include <climits>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <thread>
@@ -100,8 +102,26 @@ struct Builder {
 		const std::vector<Box>& b = tb;
 		std::sort(first, last, [&b, axis](int32_t o1, int32_t o2) -> bool { return centroid(b[o1], axis) < centroid(b[o2], axis); });
 		int32_t* middle = first + (n / 2);
-		const int l = build(first, middle, depth + 1);
-		const int r = build(middle, last, depth + 1);
+		int l, r;
+		if (n >= 65536 && depth < 4 && !getenv("TUTU_BUILD_SERIAL")) {
+			// the right half on its own thread into its own node array (as SahBuilder below): same pre-order array
+			std::vector<BuildNode> ro;
+			Builder rb{tb, ro};
+			std::thread th([&rb, middle, last, depth] { rb.build(middle, last, depth + 1); });
+			l = build(first, middle, depth + 1);
+			th.join();
+			const int off = (int)out.size();
+			for (BuildNode& bn : ro) {
+				if (bn.left >= 0) bn.left += off;
+				if (bn.right >= 0) bn.right += off;
+			}
+			out.insert(out.end(), ro.begin(), ro.end());
+			r = off;
+			if (rb.max_depth > max_depth) max_depth = rb.max_depth;
+		} else {
+			l = build(first, middle, depth + 1);
+			r = build(middle, last, depth + 1);
+		}
 		out[id].left = l;
 		out[id].right = r;
 		set_bounds(id, box_union(get_bounds(l), get_bounds(r)));
@@ -481,6 +501,15 @@ int build_reference_tree(uint32_t n_tris, const float* verts, std::vector<BuildN
 
 int build_host_scene(const TutuSceneDesc* d, HostScene& hs) {
 	if (!d) return TUTU_E_INVALID;
+	// TUTU_BUILD_TIMING: the phases of the host build on stderr
+	const bool timing = getenv("TUTU_BUILD_TIMING") != nullptr;
+	auto t_last = std::chrono::steady_clock::now();
+	auto lap = [&](const char* what) {
+		if (!timing) return;
+		const auto now = std::chrono::steady_clock::now();
+		fprintf(stderr, "[tutu build] %-28s %8.3f s\n", what, std::chrono::duration<double>(now - t_last).count());
+		t_last = now;
+	};
 	const uint32_t n_tri_in = d->n_tris;
 	if (n_tri_in > 0 && (!d->verts || !d->normals || !d->mat_id)) return TUTU_E_INVALID;
 	if (d->n_mats > 0 && !d->mats) return TUTU_E_INVALID;
@@ -534,6 +563,7 @@ int build_host_scene(const TutuSceneDesc* d, HostScene& hs) {
 	std::vector<Box> tb(n);
 	for (uint32_t o = 0; o < n; o++)
 		tb[o] = obj_sph[o] >= 0 ? sphere_box(ss->spheres + 4 * (size_t)obj_sph[o]) : triangle_box(d->verts + 9 * (size_t)obj_tri[o]);
+	lap("objects, boxes, materials");
 	rc = build_tree_of_boxes(tb, tree, &hs.depth);
 	if (rc != TUTU_OK) return rc;
 	if (hs.depth > TUTU_MAX_BVH_DEPTH) return TUTU_E_BVH_DEPTH;
@@ -593,6 +623,7 @@ int build_host_scene(const TutuSceneDesc* d, HostScene& hs) {
 	hs.nodes.clear();
 	// The tree the kernels walk first in the node array (so that a partial LDS copy holds ITS top), then the
 	// reference's own tree, which rays with a zero / non-finite direction component fall back to.
+	lap("reference tree");
 	const bool want_sah = n > 2 && !getenv("TUTU_NO_SAH");
 	hs.has_fast_tree = false;
 	if (want_sah) {
@@ -612,34 +643,49 @@ int build_host_scene(const TutuSceneDesc* d, HostScene& hs) {
 		if (const char* e = getenv("TUTU_SPLIT_GAIN")) kSplitGain = std::max(0.3, std::min(0.99, atof(e)));
 		const size_t extra_cap = (size_t)(getenv("TUTU_SPLIT_CAP_MI") ? std::max(0, std::min(64, atoi(getenv("TUTU_SPLIT_CAP_MI")))) : 4) << 20;
 		for (int per_tri = kMaxPiecesPerTri; per_tri >= 1; per_tri /= 2) {
+			// object ranges on their own threads, each into its own list, concatenated in object order (the same list as one thread makes)
+			const uint32_t n_thr = (n >= 65536 && !getenv("TUTU_BUILD_SERIAL")) ? std::min<uint32_t>(16, std::max<uint32_t>(1, std::thread::hardware_concurrency())) : 1;
+			std::vector<std::vector<Ref>> part(n_thr);
+			auto work = [&](uint32_t t) {
+				std::vector<Ref>& out_refs = part[t];
+				const uint32_t o0 = (uint32_t)((uint64_t)n * t / n_thr), o1 = (uint32_t)((uint64_t)n * (t + 1) / n_thr);
+				out_refs.reserve(o1 - o0);
+				for (uint32_t o = o0; o < o1; o++) {
+					if (obj_sph[o] >= 0 || !presplit || per_tri == 1) {
+						out_refs.push_back(Ref{tb[o], (int32_t)o});
+						continue;
+					}
+					const float* v = d->verts + 9 * (size_t)obj_tri[o];
+					bool finite = true;
+					for (int k = 0; k < 9; k++) finite = finite && std::isfinite(v[k]);
+					Poly q;
+					q.n = 3;
+					for (int i = 0; i < 3; i++)
+						for (int k = 0; k < 3; k++) q.p[i][k] = v[3 * i + k];
+					const size_t before = out_refs.size();
+					if (finite) split_piece(q, per_tri, pad, (int32_t)o, out_refs);
+					if (out_refs.size() == before + 1 || !finite) {  // not split: keep the object's own box (exactly the reference's leaf box)
+						out_refs.resize(before);
+						out_refs.push_back(Ref{tb[o], (int32_t)o});
+					}
+				}
+			};
+			std::vector<std::thread> pool;
+			for (uint32_t t = 1; t < n_thr; t++) pool.emplace_back(work, t);
+			work(0);
+			for (std::thread& th : pool) th.join();
 			refs.clear();
-			for (uint32_t o = 0; o < n; o++) {
-				if (obj_sph[o] >= 0 || !presplit || per_tri == 1) {
-					refs.push_back(Ref{tb[o], (int32_t)o});
-					continue;
-				}
-				const float* v = d->verts + 9 * (size_t)obj_tri[o];
-				bool finite = true;
-				for (int k = 0; k < 9; k++) finite = finite && std::isfinite(v[k]);
-				Poly q;
-				q.n = 3;
-				for (int i = 0; i < 3; i++)
-					for (int k = 0; k < 3; k++) q.p[i][k] = v[3 * i + k];
-				const size_t before = refs.size();
-				if (finite) split_piece(q, per_tri, pad, (int32_t)o, refs);
-				if (refs.size() == before + 1 || !finite) {  // not split: keep the object's own box (exactly the reference's leaf box)
-					refs.resize(before);
-					refs.push_back(Ref{tb[o], (int32_t)o});
-				}
-			}
+			for (uint32_t t = 0; t < n_thr; t++) refs.insert(refs.end(), part[t].begin(), part[t].end());
 			if (refs.size() <= (size_t)n + extra_cap) break;
 		}
+		lap("references (split clipping)");
 		std::vector<Box> rb(refs.size());
 		for (size_t i = 0; i < refs.size(); i++) rb[i] = refs[i].box;
 		hs.n_refs = (uint32_t)refs.size();
 		std::vector<BuildNode> sah;
 		uint32_t sah_depth = 0;
 		rc = build_sah_tree(rb, sah, &sah_depth);
+		lap("walked tree (SAH)");
 		if (rc != TUTU_OK) return rc;
 		for (BuildNode& bn : sah)
 			if (bn.tri >= 0) bn.tri = refs[(size_t)bn.tri].obj;  // a leaf says which OBJECT to test
@@ -652,6 +698,7 @@ int build_host_scene(const TutuSceneDesc* d, HostScene& hs) {
 		}
 	}
 	hs.root_ref_exact = flatten(tree);
+	lap("flatten both trees");
 	if (!hs.has_fast_tree) {
 		hs.root_ref = hs.root_ref_exact;
 		hs.n_fast_inner = (int32_t)hs.nodes.size();
@@ -837,6 +884,7 @@ int build_host_scene(const TutuSceneDesc* d, HostScene& hs) {
 		L.tri = li;
 		L.pad = 0;
 	}
+	lap("leaf-order tables, lights");
 	return TUTU_OK;
 }
 
