@@ -589,7 +589,7 @@ TUTU_DEV bool bdpt_unit(BdCtx<S>& c, V3 pixelPos) {
 }
 
 // ---------------------------------------------------------------------------------------------- kernels
-template <typename S>
+template <int TYPE, typename S>
 TUTU_DEV void run_unit(const S* ss, const BidirParams& p, const ShadeTabs& tb, int* stack, uint32_t i, uint32_t pix, uint32_t smp,
                        unsigned long long seq0, V3 pixelPos) {
 	BdCtx<S> c;
@@ -604,13 +604,13 @@ TUTU_DEV void run_unit(const S* ss, const BidirParams& p, const ShadeTabs& tb, i
 	c.own = mk1(0.f);
 	c.rng.init(pix, smp, 0, p.key0, p.key1);
 	bool alive = true;
-	if (p.type == 1) lt_unit(c);
-	else if (p.type == 2) alive = naive_unit(c, pixelPos);
+	if (TYPE == 1) lt_unit(c);  // (compile-time: LightTracing and NaivePT do not carry BDPT's registers and scratch)
+	else if (TYPE == 2) alive = naive_unit(c, pixelPos);
 	else alive = bdpt_unit(c, pixelPos);
 	p.own[i] = make_float4(c.own.x, c.own.y, c.own.z, alive ? (float)c.n_own : -1.f);
 }
 
-template <bool LDS_SCENE>
+template <int TYPE, bool LDS_SCENE>
 __global__ void __launch_bounds__(256) k_bidir(BidirParams p) {
 	extern __shared__ int lds[];  // [stack entries][256 lanes] | optional scene copy ; shade tables are read from memory
 	SceneLds sl;
@@ -644,8 +644,8 @@ __global__ void __launch_bounds__(256) k_bidir(BidirParams p) {
 	const V3 h_off = (float)x * ld3(p.frame.delta_h);
 	const V3 pixelPos = ld3(p.frame.ul) + h_off + v_off + ld3(p.frame.c_off_h) + ld3(p.frame.c_off_v);
 	const unsigned long long seq0 = ((unsigned long long)pix * (unsigned long long)p.spp + smp) * 16ull;
-	if (LDS_SCENE) run_unit(&sl, p, tb, lds + threadIdx.x, i, pix, smp, seq0, pixelPos);
-	else run_unit(&sg, p, tb, lds + threadIdx.x, i, pix, smp, seq0, pixelPos);
+	if (LDS_SCENE) run_unit<TYPE>(&sl, p, tb, lds + threadIdx.x, i, pix, smp, seq0, pixelPos);
+	else run_unit<TYPE>(&sg, p, tb, lds + threadIdx.x, i, pix, smp, seq0, pixelPos);
 }
 
 // The own-pixel part of a batch of whole pixels [pix0, pix0 + n_pix): estimate = the pixel's units' contributions added one
@@ -690,7 +690,15 @@ __global__ void __launch_bounds__(256) k_bidir_replay(const unsigned long long* 
 	const uint32_t target = (uint32_t)(k >> 40);
 	if (i > 0 && (uint32_t)(key_sorted[i - 1] >> 40) == target) return;
 	float r = frame3[3 * (size_t)target], g = frame3[3 * (size_t)target + 1], b = frame3[3 * (size_t)target + 2];
+	// a setRGB wipes everything before it: start at the run's LAST set (LightTracing: the pixels that see the light collect
+	// hundreds of thousands of events, nearly all of them sets; this first scan has no dependent arithmetic)
+	uint32_t start = i;
 	for (uint32_t j = i; j < n_ev; j++) {
+		const unsigned long long kj = key_sorted[j];
+		if (kj == ~0ull || (uint32_t)(kj >> 40) != target) break;
+		if (ev_val[idx_sorted[j]].w == 0.f) start = j;
+	}
+	for (uint32_t j = start; j < n_ev; j++) {
 		const unsigned long long kj = key_sorted[j];
 		if (kj == ~0ull || (uint32_t)(kj >> 40) != target) break;
 		const float4 v = ev_val[idx_sorted[j]];

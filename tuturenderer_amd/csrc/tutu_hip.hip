@@ -1005,8 +1005,16 @@ int bidir_params(TutuCtx* c, int type, const TutuCameraDesc* cam, int spp, uint3
 
 int bidir_launch(TutuCtx* c, hipStream_t s, const BidirParams& p) {
 	const dim3 grid((p.n_units + 255) / 256);
-	if (c->lds_scene) hipLaunchKernelGGL(k_bidir<true>, grid, dim3(256), c->trace_lds_bytes, s, p);
-	else hipLaunchKernelGGL(k_bidir<false>, grid, dim3(256), c->trace_lds_bytes, s, p);
+	const unsigned lds = c->trace_lds_bytes;
+	if (c->lds_scene) {
+		if (p.type == 1) k_bidir<1, true><<<grid, dim3(256), lds, s>>>(p);
+		else if (p.type == 2) k_bidir<2, true><<<grid, dim3(256), lds, s>>>(p);
+		else k_bidir<3, true><<<grid, dim3(256), lds, s>>>(p);
+	} else {
+		if (p.type == 1) k_bidir<1, false><<<grid, dim3(256), lds, s>>>(p);
+		else if (p.type == 2) k_bidir<2, false><<<grid, dim3(256), lds, s>>>(p);
+		else k_bidir<3, false><<<grid, dim3(256), lds, s>>>(p);
+	}
 	HIP_TRY(hipGetLastError());
 	return TUTU_OK;
 }
