@@ -306,7 +306,90 @@ __global__ void __launch_bounds__(256) k_shade(PassParams pp) {
 		chunk_step = (gridDim.x * blockDim.x) >> 6;
 	}
 
-	for (; chunk < total_chunks; chunk += chunk_step) {
+	// GROUP -- the generic kernel of a scene that mixes scattering classes.  A wave runs a material's branch if ANY of its
+	// lanes takes it: on the veach room the ungrouped kernel issues 3026 vector instructions per 64 vertices at 29 % of the
+	// lanes, where the one-class kernel of the Cornell box needs 1286 at 68 %.  So a block takes WINDOWS of 16 chunks
+	// (1024 list entries), sorts the window's entries by the class of their hit (counting sort in LDS, one atomic per wave
+	// and class) and its four waves then draw the window's sorted chunks from a counter: most chunks hold one class, and the
+	// few mixed or expensive ones go to whichever wave is free (a fixed deal would make the rare classes one wave's -- one
+	// SIMD's -- burden and the block would wait for it at every barrier).  Nothing downstream depends on which lane shades
+	// which record: the random stream is keyed by pixel and sample, results are gathered per path (F[home]), a wave still
+	// compacts the survivors of whatever chunk it shaded into that chunk's own 64 output slots.
+	constexpr bool GROUP = MODE == SHADE_ANY;
+	constexpr uint32_t WCH = 16;  // chunks per window
+	__shared__ uint16_t g_src[GROUP ? WCH * 64 : 1];
+	__shared__ uint32_t g_cnt[GROUP ? 8 : 1];
+	__shared__ uint32_t g_next[1];
+	uint32_t win = blockIdx.x, win_chunks = 0;
+	bool have_win = false;
+
+	for (;;) {
+		if (GROUP) {
+			bool got = false;
+			while (!got) {
+				if (have_win) {
+					uint32_t k = 0;
+					if (lane == 0) k = atomicAdd(&g_next[0], 1u);
+					k = (uint32_t)__builtin_amdgcn_readfirstlane((int)k);
+					if (k < win_chunks) {
+						chunk = win * WCH + k;
+						got = true;
+						break;
+					}
+					__syncthreads();  // every wave has drawn past the window's end: g_src may be overwritten
+					have_win = false;
+					win += gridDim.x;
+				}
+				if (win * WCH >= total_chunks) break;
+				// ---- sort the window's entries by class
+				const uint32_t e0 = win * WCH * 64u;
+				const uint32_t n_ent = min(WCH * 64u, n_in - e0);
+				if (threadIdx.x < 8) g_cnt[threadIdx.x] = 0u;
+				if (threadIdx.x == 0) g_next[0] = 0u;
+				__syncthreads();
+				uint32_t ecls[WCH / 4], erank[WCH / 4];
+#pragma unroll
+				for (uint32_t q = 0; q < WCH / 4; q++) {
+					const uint32_t e = threadIdx.x + 256u * q;
+					const uint32_t c = e < n_ent ? (uint32_t)(pp.hitK[e0 + e] & 7) : 8u;  // 8: no entry
+					ecls[q] = c;
+					erank[q] = 0;
+					unsigned long long todo = __ballot(c < 8u);
+					while (todo != 0ull) {  // one LDS atomic per wave and class present
+						const int lead = __ffsll((long long)todo) - 1;
+						const uint32_t cl = (uint32_t)__builtin_amdgcn_readlane((int)c, lead);
+						const unsigned long long same = __ballot(c == cl);
+						uint32_t base = 0;
+						if (lane == lead) base = atomicAdd(&g_cnt[cl], (uint32_t)__popcll(same));
+						base = (uint32_t)__builtin_amdgcn_readlane((int)base, lead);
+						if (c == cl) erank[q] = base + (uint32_t)__popcll(same & lt_mask);
+						todo &= ~same;
+					}
+				}
+				__syncthreads();
+				uint32_t cbase[8], run = 0;
+#pragma unroll
+				for (uint32_t c = 0; c < 8; c++) {
+					cbase[c] = run;
+					run += g_cnt[c];
+				}
+#pragma unroll
+				for (uint32_t q = 0; q < WCH / 4; q++)
+					if (ecls[q] < 8u) {
+						uint32_t b0 = 0;
+#pragma unroll
+						for (uint32_t c = 0; c < 8; c++)
+							if (ecls[q] == c) b0 = cbase[c];
+						g_src[b0 + erank[q]] = (uint16_t)(threadIdx.x + 256u * q);
+					}
+				__syncthreads();
+				win_chunks = (n_ent + 63u) >> 6;
+				have_win = true;
+			}
+			if (!got) break;
+		} else if (chunk >= total_chunks) {
+			break;
+		}
 		bool act;
 		int chunk_class = 0;  // class of the hit (per lane)
 		uint32_t idx = 0;     // work item (FIRST only)
@@ -316,8 +399,15 @@ __global__ void __launch_bounds__(256) k_shade(PassParams pp) {
 			idx = blockIdx.x * blockDim.x + threadIdx.x;
 			act = idx < (uint32_t)pp.npix;
 		} else {
-			j = chunk * 64u + lane;
-			act = j < n_in;
+			if (GROUP) {
+				const uint32_t e = (chunk - win * WCH) * 64u + lane;  // position in the sorted window
+				const uint32_t e0 = win * WCH * 64u;
+				act = e < min(WCH * 64u, n_in - e0);
+				j = e0 + (act ? (uint32_t)g_src[e] : 0u);
+			} else {
+				j = chunk * 64u + lane;
+				act = j < n_in;
+			}
 			if (act) {
 				slot_in = pp.list[j];
 				chunk_class = pp.hitK[j] & 7;
@@ -633,6 +723,7 @@ __global__ void __launch_bounds__(256) k_shade(PassParams pp) {
 		pp.out.key[out0 + lane] = (uint8_t)key_r;
 		pp.out.V[out0 + lane] = (uint8_t)TUTU_V_BLOCKED;
 		__builtin_amdgcn_wave_barrier();  // the next chunk's staging writes stay behind these reads
+		if (!GROUP) chunk += chunk_step;
 	}
 }
 

@@ -696,7 +696,8 @@ int tutu_hip_create(const TutuSceneDesc* scene, int device, TutuCtx** out) {
 	{
 		const size_t ml = c->hs.mats.size() * sizeof(GpuMaterial) + c->hs.lights.size() * sizeof(GpuLight);
 		const size_t tr = c->hs.tri_shade.size() * sizeof(GpuTriShade);
-		if (ml <= 16 * 1024 && tr <= 16 * 1024 - ml) {
+		const int tab_max = getenv("TUTU_SHADE_TAB_MAX") ? atoi(getenv("TUTU_SHADE_TAB_MAX")) : 2;  // experiments: keep tables out of LDS
+		if (tab_max >= 2 && ml <= 16 * 1024 && tr <= 16 * 1024 - ml) {
 			c->shade_tab = 2;
 			c->shade_lds_bytes = (unsigned)(ml + tr);
 		} else if (ml <= 16 * 1024) {
