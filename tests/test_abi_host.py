@@ -52,6 +52,23 @@ def test_camera_frame_and_bvh_match_reference(tr, name):
     assert info["depth"] <= 30
 
 
+@pytest.mark.parametrize("name", SCENES)
+def test_camera_raster_matches_the_restatement(tr, port, name):
+    """tutu_camera_raster (Camera::initialize's world2Raster and scalars, what the other integrators read) == the CPU
+    restatement's, bit for bit -- which equals the reference's own Camera (tests/test_oracle_vs_reference.py)"""
+    from oracle.gen_golden import golden_scenes
+
+    mk, _ = golden_scenes()[name]
+    sc = mk()
+    cr = tr.camera_raster(sc)
+    mine = np.array(list(cr.world2raster) + [cr.imagePlaneDist, cr.filmPlaneAreaInv, cr.lensAreaInv] + list(cr.fwdDir), np.float32)
+    S = port.scene(sc)
+    want = S.camera_raster()
+    S.close()
+    assert bit_equal(mine, want)
+    assert cr.width == sc["width"] and cr.height == sc["height"] and list(cr.position) == [np.float32(x) for x in sc["eye"]]
+
+
 def test_bvh_edge_cases(tr):
     b, leaf, info = tr.bvh_build_preorder(np.zeros((0, 9), np.float32))
     assert len(leaf) == 0 and info["n_inner"] == 0
@@ -98,9 +115,9 @@ def test_committed_bench_line_keeps_the_contract():
 
     from conftest import ROOT
 
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_line.json")))
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_line_c2.json")))
     assert files, "no committed bench line"
-    d = json.load(open(files[-1]))
+    d = json.loads(open(files[-1]).read().strip().splitlines()[-1])
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
               "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert k in d, k
@@ -113,6 +130,10 @@ def test_committed_bench_line_keeps_the_contract():
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
     assert abs(r["achieved"] - r["algorithmic_bytes_per_launch"] / (r["avg_launch_ms"] * 1e-3) / 1e9) < 1e-6 * r["achieved"]
+    # every kernel has its own entry with its bound; the exclusive (one pass in flight) figures are the top-level ones
+    assert set(r["per_kernel"]) == {"k_trace_closest", "k_trace_any", "k_shade"} and r["kernel"] in r["per_kernel"]
+    assert abs(r["per_kernel"][r["kernel"]]["frac"] - r["frac"]) < 1e-12 and "exclusive_kernel_ms_per_step" in r
+    assert r["lds_scene"] is True and r["kernel"] == "k_shade" and r["per_kernel"]["k_trace_closest"]["bound"] == "valu"
     c = d["cpu_baseline"]
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in c, k

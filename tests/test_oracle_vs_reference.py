@@ -40,9 +40,17 @@ def test_live_other_integrators(reference, port):
 
     sc = scenes.veach_room(32, 24, small_light=True)
     R, P = reference.scene(sc), port.scene(sc)
+    # the camera the three integrators read: the reference's own Camera after initialize() (world2Raster, Camera.hpp:29-41)
+    assert R.camera_raster().tobytes() == P.camera_raster().tobytes()
     for itype in (1, 2, 3):
         a = R.render_integrator(itype, 3, pc.KEY0, 900 + itype)
         b = P.render_integrator(itype, 3, pc.KEY0, 900 + itype)
         assert a.tobytes() == b.tobytes(), itype
     R.close()
     P.close()
+    for mk in (lambda: scenes.cornell_box(96, 64), lambda: scenes.cornell_box(33, 57), lambda: scenes.veach_room(120, 90)):
+        sc = mk()
+        R, P = reference.scene(sc), port.scene(sc)
+        assert R.camera_raster().tobytes() == P.camera_raster().tobytes()
+        R.close()
+        P.close()
