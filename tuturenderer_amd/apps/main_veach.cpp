@@ -1,6 +1,7 @@
-// Scene program: the Veach-BDPT room rendered with the PathTracing integrator (BASELINE config 5) -- the
-// statements of the reference's src/main_veach_bdpt.cpp:14-107 against tuturenderer_amd/host/tutu_renderer.hpp.
-// usage: main_veach <config.txt> [spp] [model dir]      (the config must say `integrator path`)
+// Scene program: the Veach-BDPT room -- the statements of the reference's src/main_veach_bdpt.cpp:14-107 against
+// tuturenderer_amd/host/tutu_renderer.hpp.  With `integrator path` in the config it is BASELINE config 5; `integrator bdpt`
+// (what the reference runs it with), `light` and `naivept` select the device versions of those integrators.
+// usage: main_veach <config.txt> [spp] [model dir]
 // The reference asks for "veach_slight.obj" while the file is veach_sLight.obj, so on a case-sensitive file system
 // the small light is silently skipped (src/main_veach_bdpt.cpp:49); the same file name is asked for here.
 #include <chrono>

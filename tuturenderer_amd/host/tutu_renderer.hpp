@@ -618,7 +618,7 @@ public:
 	PPMGenerator* g = nullptr;
 };
 
-// IIntegrator for `integrator path`: the whole of PathTracing::integrate (PathTracing.hpp:352-516) as one call
+// IIntegrator for all four `integrator` keywords: PathTracing::integrate (PathTracing.hpp:352-516) -- or LightTracing / NaivePT / BDPT -- as one call
 // into the GPU library -- the same binding file a maintainer adds to the reference itself.
 #define TUTU_BINDING_KNOBS  // TUTU_SEED0 / TUTU_SEED1 / TUTU_SPP_PER_PASS are declared at the top of this header
 inline int TUTU_GPUS = 0;
