@@ -77,10 +77,6 @@ struct BVert {  // bdpt::eyePathVert / lightPathVert (BDPT.hpp:32-48) -- and the
 	float light_pdf;  // getLightPdf of the vertex (1 / (n_lights * area) on an emitter, else 0)
 	float fwdPdf, revPdf, G;
 	bool isDelta;
-	// where the hit is, for textureModify (applied by the callers at the points the reference applies it)
-	int tri;
-	float b1, b2;
-	bool is_sphere;
 };
 
 TUTU_DEV int world_to_pixel(const DevCam& c, V3 p) {  // Camera::worldPos2PixelIndex + raster2pxlIndex, Camera.hpp:52-79
@@ -145,6 +141,10 @@ struct BdCtx {
 	unsigned long long seq0;
 	uint32_t unit_slot;
 	V3 own;
+	// where the LAST hit is, for textureModify (the callers apply it to that hit's vertex, at the points the reference does)
+	int h_tri;
+	float h_b1, h_b2;
+	bool h_sphere;
 
 	TUTU_DEV void emit(int op, int index, V3 v) {
 		if (index < 0 || index >= p->cam.width * p->cam.height) return;  // Texture::setRGB / addRGB bounds test
@@ -172,12 +172,12 @@ struct BdCtx {
 		const int mat_id = __float_as_int(s3.x);
 		v.light_pdf = s3.z;
 		v.pos = o + t * d;
-		v.tri = tri;
-		v.b1 = b1;
-		v.b2 = b2;
-		v.is_sphere = false;
+		h_tri = tri;
+		h_b1 = b1;
+		h_b2 = b2;
+		h_sphere = false;
 		if (__float_as_int(s3.w) & TUTU_CLS_SPHERE) {
-			v.is_sphere = true;
+			h_sphere = true;
 			v.Ng = normalized(v.pos - n0);
 			v.Ns = v.Ng;
 		} else {
@@ -188,7 +188,7 @@ struct BdCtx {
 		return true;
 	}
 	TUTU_DEV void textures(BVert& v) {  // textureModify on the vertex's own copy of the material (IIntegrator.hpp:89-127)
-		if (p->sc.has_tex) texture_modify(p->sc, v.tri, v.b1, v.b2, v.is_sphere, v.Ng, v.m, v.Ns);
+		if (p->sc.has_tex) texture_modify(p->sc, h_tri, h_b1, h_b2, h_sphere, v.Ng, v.m, v.Ns);
 	}
 	TUTU_DEV bool blocked(V3 orig, V3 target) { return bd_blocked(ss, &p->sc, orig, target, stack); }
 	// sampleLight (IIntegrator.hpp:173-192) as a path vertex
@@ -332,42 +332,41 @@ __device__ __noinline__ float bdpt_mis(BdCtx<S>* cp, const BVert* ep, const BVer
 			pdf_tEndRev = bd_pdf(&tEnd.m, t2prev, -s2t, tEnd.Ns, eta, tEnd.m.eta) / fabsf(dot(t2prev, tEnd.Ng));
 		}
 	}
-	float toLight[2 * TUTU_BIDIR_MAXLEN + 4], toEye[2 * TUTU_BIDIR_MAXLEN + 4];
-	bool delta[2 * TUTU_BIDIR_MAXLEN + 4];
-	for (int i = 0; i < 2 * TUTU_BIDIR_MAXLEN + 4; i++) {
-		toLight[i] = 0.f;
-		toEye[i] = 0.f;
-		delta[i] = false;
-	}
+	// The reference fills an array of misNode {carry_towardLight, carry_towardEye, isDelta} per strategy (BDPT.hpp:150-196) and
+	// then walks it.  Here entry i is computed where it is read -- the same products of the same operands -- because the arrays
+	// would live in private memory, and with 28 strategies per unit their traffic was most of what this kernel moved.
+	// Entries: [0, Sn - 1) light-path interior, Sn - 1 the light path's end, Sn the eye path's end, (Sn, k] eye-path interior
+	// (entry k - ti = eye vertex ti).
 	const int k = Sn + Tn - 1;
-	for (int i = 0; i < Sn - 1; ++i) {
-		toLight[i] = (i == 0) ? lp[0].revPdf : lp[i].revPdf * lp[i].G;
-		toEye[i] = lp[i].fwdPdf * lp[i + 1].G;
-		delta[i] = lp[i].isDelta;
-	}
-	if (Sn > 0) {
-		toLight[Sn - 1] = (Sn == 1) ? pdf_sEndRev : pdf_sEndRev * lp[Sn - 1].G;
-		toEye[Sn - 1] = pdf_sEndFwd * G_connect;
-		delta[Sn - 1] = lp[Sn - 1].isDelta;
-	}
-	for (int ti = 0; ti < Tn - 1; ++ti) {
-		toEye[k - ti] = (ti == 0) ? ep[ti].revPdf : ep[ti].revPdf * ep[ti].G;
-		toLight[k - ti] = ep[ti].fwdPdf * ep[ti + 1].G;
-		delta[k - ti] = ep[ti].isDelta;
-	}
-	toEye[k - (Tn - 1)] = (Tn == 1) ? pdf_tEndRev : pdf_tEndRev * ep[Tn - 1].G;
-	toLight[k - (Tn - 1)] = (Sn == 0) ? pdf_tEndFwd : pdf_tEndFwd * G_connect;
-	delta[k - (Tn - 1)] = ep[Tn - 1].isDelta;
+	auto toLight = [&](int i) -> float {
+		if (i < Sn - 1) return (i == 0) ? lp[0].revPdf : lp[i].revPdf * lp[i].G;
+		if (i == Sn - 1) return (Sn == 1) ? pdf_sEndRev : pdf_sEndRev * lp[Sn - 1].G;
+		if (i == Sn) return (Sn == 0) ? pdf_tEndFwd : pdf_tEndFwd * G_connect;
+		const int ti = k - i;
+		return ep[ti].fwdPdf * ep[ti + 1].G;
+	};
+	auto toEye = [&](int i) -> float {
+		if (i < Sn - 1) return lp[i].fwdPdf * lp[i + 1].G;
+		if (i == Sn - 1) return pdf_sEndFwd * G_connect;
+		if (i == Sn) return (Tn == 1) ? pdf_tEndRev : pdf_tEndRev * ep[Tn - 1].G;
+		const int ti = k - i;
+		return (ti == 0) ? ep[0].revPdf : ep[ti].revPdf * ep[ti].G;
+	};
+	auto delta = [&](int i) -> bool {
+		if (i <= Sn - 1) return lp[i].isDelta;
+		if (i == Sn) return ep[Tn - 1].isDelta;
+		return ep[k - i].isDelta;
+	};
 
 	float p_i_plus_1 = 1.0f;
 	float denominator = 1.0f;
 	for (int i = Sn; i < k; ++i) {
 		if (i == 0) {
-			p_i_plus_1 *= toLight[0] / toLight[1];
-			if (delta[1]) continue;
+			p_i_plus_1 *= toLight(0) / toLight(1);
+			if (delta(1)) continue;
 		} else {
-			p_i_plus_1 *= toEye[i - 1] / toLight[i + 1];
-			if (delta[i] || delta[i + 1]) continue;
+			p_i_plus_1 *= toEye(i - 1) / toLight(i + 1);
+			if (delta(i) || delta(i + 1)) continue;
 		}
 		denominator += p_i_plus_1 * p_i_plus_1;
 	}
@@ -375,11 +374,11 @@ __device__ __noinline__ float bdpt_mis(BdCtx<S>* cp, const BVert* ep, const BVer
 	for (int i = Sn; i > 0; --i) {
 		if (i == (k + 1)) {
 		} else if (i == 1) {
-			p_i_minus_1 *= toLight[1] / toLight[0];
-			if (delta[0]) continue;
+			p_i_minus_1 *= toLight(1) / toLight(0);
+			if (delta(0)) continue;
 		} else {
-			p_i_minus_1 *= toLight[i] / toEye[i - 2];
-			if (delta[i - 1] || delta[i - 2]) continue;
+			p_i_minus_1 *= toLight(i) / toEye(i - 2);
+			if (delta(i - 1) || delta(i - 2)) continue;
 		}
 		denominator += p_i_minus_1 * p_i_minus_1;
 	}
