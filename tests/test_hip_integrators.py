@@ -138,6 +138,26 @@ def test_sphere_scene_units_and_frame(tr, port, iname):
     assert (rel > 1e-3).mean() < 3e-2 and l2[rel <= 1e-3].mean() < 1e-3
 
 
+@pytest.mark.parametrize("name", CASES + ["spheres"])
+def test_light_tracing_wavefront_is_the_unit_kernel_frame(tr, name, monkeypatch):
+    """tutu_hip_render_integrator renders LightTracing as a wavefront (generation / connection stages around the path tracer's
+    list and traversal kernels); TUTU_LT_UNIT_KERNEL selects the one-lane-per-unit kernel that tutu_hip_integrator_samples
+    uses.  Same arithmetic, same events, same replay: the same frame, bit for bit."""
+    from tuturenderer_amd import scenes
+
+    sc = scenes.cornell_spheres(64, 48) if name == "spheres" else integrator_cases()[name][0]()
+    monkeypatch.delenv("TUTU_LT_UNIT_KERNEL", raising=False)
+    with tr.Context(sc) as ctx:
+        a = ctx.render_integrator("light", 6, pc.KEY0, 88)
+        ctx.set_option("bidir_units", 500)
+        a_small = ctx.render_integrator("light", 6, pc.KEY0, 88)
+    monkeypatch.setenv("TUTU_LT_UNIT_KERNEL", "1")
+    with tr.Context(sc) as ctx:
+        b = ctx.render_integrator("light", 6, pc.KEY0, 88)
+    monkeypatch.delenv("TUTU_LT_UNIT_KERNEL", raising=False)
+    assert bit_equal(a, b) and bit_equal(a, a_small) and np.nanmean(a) > 0.01
+
+
 def test_larger_frame_batches_and_argument_checks(tr, port):
     from tuturenderer_amd import scenes
 

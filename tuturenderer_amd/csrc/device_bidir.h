@@ -48,6 +48,12 @@ struct BidirParams {
 	                              // scaling) | w = -1 when the primary ray missed, else the number of contributions
 	float4* own_list;             // [n_units][TUTU_BIDIR_MAX_OWN] the contributions one by one (BDPT frames: the pixel's estimate is
 	                              // ONE running sum over all its samples' contributions, and float addition is not associative); may be null
+	// LightTracing as a wavefront (k_lt_*): the unit's rays go through the path tracer's record set and traversal kernels
+	Records rec;
+	const uint32_t* list;         // list 0 of the generation stage: the units that shot a ray
+	const uint32_t* n_list;
+	const float4* hitC;           // closest hits per list position
+	uint32_t n_pad;               // record slots the generation stage initialises (multiple of TUTU_LIST_TILE)
 	int ev_stride;                // event slots per unit: 2 for LightTracing, TUTU_BIDIR_MAX_EVENTS for BDPT, 1 (unused) for NaivePT
 	unsigned long long* ev_key;   // [n_units][ev_stride]: target pixel << 40 | sequence number; ~0 = none
 	float4* ev_val;               // rgb | op (0 set, 1 add)
@@ -166,6 +172,10 @@ struct BdCtx {
 		int tri;
 		bd_closest(ss, &p->sc, o, d, stack, &t, &b1, &b2, &tri);
 		if (tri < 0) return false;
+		resolve(o, d, t, b1, b2, tri, v, with_textures);
+		return true;
+	}
+	TUTU_DEV void resolve(V3 o, V3 d, float t, float b1, float b2, int tri, BVert& v, bool with_textures) {
 		const float4 s0 = tb.tri(tri, 0), s1 = tb.tri(tri, 1), s2 = tb.tri(tri, 2), s3 = tb.tri(tri, 3);
 		const V3 n0 = mk(s0.x, s0.y, s0.z), n1 = mk(s0.w, s1.x, s1.y), n2 = mk(s1.z, s1.w, s2.x);
 		v.Ng = mk(s2.y, s2.z, s2.w);
@@ -185,7 +195,6 @@ struct BdCtx {
 		}
 		v.m = load_mat(tb, mat_id);
 		if (with_textures) textures(v);
-		return true;
 	}
 	TUTU_DEV void textures(BVert& v) {  // textureModify on the vertex's own copy of the material (IIntegrator.hpp:89-127)
 		if (p->sc.has_tex) texture_modify(p->sc, h_tri, h_b1, h_b2, h_sphere, v.Ng, v.m, v.Ns);
@@ -587,6 +596,139 @@ TUTU_DEV bool bdpt_unit(BdCtx<S>& c, V3 pixelPos) {
 	return true;
 }
 
+// ---------------------------------------------------------------------------------------------- LightTracing as a wavefront
+// lt_unit above, cut at its rays (the frame path of tutu_hip_render_integrator; k_bidir<1> stays the per-unit entry point):
+//   k_lt_gen      light point + direction -> the unit's record: extension ray (A, B), shadow request light -> camera (A, S),
+//                 and what the later stages need (D: the setRGB value | its pixel, E: throughput, G: light point, H: emission)
+//   [lists, closest-hit and any-hit traversal: the path tracer's own kernels, persistent waves with refill]
+//   k_lt_connect  event 0 (the setRGB, if the first shadow ray got through); the hit vertex, its BSDF towards the camera, the
+//                 second shadow request (A, S; P: the addRGB value | its pixel)
+//   [list, any-hit traversal]
+//   k_lt_emit     event 1 (the addRGB, if the second shadow ray got through)
+// Same arithmetic in the same order as lt_unit; the random stream of a unit continues at draw 5 in the second stage
+// (sampleLight takes three numbers, sampleLightDir two).
+TUTU_DEV ShadeTabs bd_global_tabs(const SceneDev& sc) {
+	ShadeTabs tb;
+	tb.mats = sc.mats;
+	tb.lights = sc.lights;
+	tb.tris = sc.tri_shade;
+	tb.tri_si = 4;
+	tb.tri_sk = 1;
+	tb.stage = nullptr;
+	return tb;
+}
+
+__global__ void __launch_bounds__(256) k_lt_gen(BidirParams p) {
+	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= p.n_pad) return;
+	p.rec.V[i] = (uint8_t)TUTU_V_BLOCKED;
+	if (i >= p.n_units) {
+		p.rec.key[i] = 0;
+		return;
+	}
+	p.ev_key[2 * (size_t)i + 0] = ~0ull;
+	p.ev_key[2 * (size_t)i + 1] = ~0ull;
+	uint8_t key = 0;
+	if (p.sc.n_lights > 0) {
+		const uint32_t pix = p.first_pix + i / (uint32_t)p.spp, smp = i % (uint32_t)p.spp;
+		const ShadeTabs tb = bd_global_tabs(p.sc);
+		Rng rng;
+		rng.init(pix, smp, 0, p.key0, p.key1);
+		const LightSample ls = sample_light(tb, p.sc.n_lights, rng);
+		const float pickpdf = ls.pdf;
+		float dirPdf;
+		V3 wi;
+		if (bd_sample_light_dir(ls.N, dirPdf, wi, rng)) {
+			wi = normalized(wi);
+			V3 orig = ls.pos;
+			bd_offset(orig, ls.N, false);
+			const int index = world_to_pixel(p.cam, ls.pos);
+			const V3 setv = ls.emission * bd_We(ls.pos, p.cam) * p.spp_inv;  // setRGB, not add [sic] LightTracing.hpp:118
+			const V3 tp0 = mk1(1 / pickpdf);
+			const float wi_n_cos = fabsf(dot(wi, ls.N));
+			const V3 tp = tp0 * wi_n_cos / dirPdf;
+			const V3 camPos = ld3(p.cam.position);
+			p.rec.A[i] = make_float4(orig.x, orig.y, orig.z, 0.f);
+			p.rec.B[i] = make_float4(wi.x, wi.y, wi.z, 0.f);
+			p.rec.S[i] = make_float4(camPos.x, camPos.y, camPos.z, 0.f);
+			p.rec.D[i] = make_float4(setv.x, setv.y, setv.z, __int_as_float(index));
+			p.rec.E[i] = make_float4(tp.x, tp.y, tp.z, 0.f);
+			p.rec.G[i] = make_float4(ls.pos.x, ls.pos.y, ls.pos.z, 0.f);
+			p.rec.H[i] = make_float4(ls.emission.x, ls.emission.y, ls.emission.z, 0.f);
+			key = (uint8_t)(TUTU_KEY_NEXT | TUTU_KEY_SHADOW);
+		}
+	}
+	p.rec.key[i] = key;
+}
+
+TUTU_DEV void lt_event(const BidirParams& p, uint32_t unit, uint32_t k, int op, int index, V3 v) {
+	if (index < 0 || index >= p.cam.width * p.cam.height) return;  // Texture::setRGB / addRGB bounds test
+	const uint32_t pix = p.first_pix + unit / (uint32_t)p.spp, smp = unit % (uint32_t)p.spp;
+	const unsigned long long seq = ((unsigned long long)pix * (unsigned long long)p.spp + smp) * 16ull + k;
+	p.ev_key[2 * (size_t)unit + k] = ((unsigned long long)(uint32_t)index << 40) | seq;
+	p.ev_val[2 * (size_t)unit + k] = make_float4(v.x, v.y, v.z, (float)op);
+}
+
+__global__ void __launch_bounds__(256) k_lt_connect(BidirParams p) {
+	const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+	if (j >= *p.n_list) return;
+	const uint32_t slot = p.list[j];  // = the unit
+	const float4 D = p.rec.D[slot];
+	if (p.rec.V[slot] == TUTU_V_ADD) lt_event(p, slot, 0, 0, __float_as_int(D.w), mk(D.x, D.y, D.z));
+	const float4 C = p.hitC[j];
+	const int tri = __float_as_int(C.w);
+	uint8_t key = 0;
+	if (tri >= 0) {
+		const float4 A = p.rec.A[slot], B = p.rec.B[slot], E = p.rec.E[slot], G4 = p.rec.G[slot], H = p.rec.H[slot];
+		const V3 o = mk(A.x, A.y, A.z), wi = mk(B.x, B.y, B.z);
+		const uint32_t pix = p.first_pix + slot / (uint32_t)p.spp, smp = slot % (uint32_t)p.spp;
+		BdCtx<SceneGlobal> c;
+		c.ss = nullptr;
+		c.p = &p;
+		c.tb = bd_global_tabs(p.sc);
+		c.stack = nullptr;
+		c.rng.init(pix, smp, 5, p.key0, p.key1);
+		BVert lp1;
+		c.resolve(o, wi, C.x, C.y, C.z, tri, lp1, true);
+		lp1.throughput = mk(E.x, E.y, E.z);
+		{
+			const V3 wo = -wi;
+			V3 wi2;
+			bool ok, TIR;
+			bd_sample(&lp1.m, wo, lp1.Ns, &wi2, p.sc.eta, &c.rng, &ok, &TIR);  // (writes the vertex material's alpha, which the BxDF below reads)
+		}
+		const V3 camPos = ld3(p.cam.position), camFwd = ld3(p.cam.fwdDir);
+		const V3 lightPos = mk(G4.x, G4.y, G4.z);
+		const float pdfCam = 1.f;
+		const float G = bd_Geo(camPos, camFwd, lp1.pos, lp1.Ng);
+		const V3 l = mk(H.x, H.y, H.z);
+		const V3 wo = normalized(lightPos - lp1.pos);
+		const V3 wic = normalized(camPos - lp1.pos);
+		const V3 bsdf = bd_bxdf(&lp1.m, wic, wo, lp1.Ng, lp1.Ns, 1.f, true, false);
+		const float we = bd_We(lp1.pos, p.cam);
+		const V3 res = pdfCam * l * bsdf * lp1.throughput * G * we;
+		V3 o2 = lp1.pos;
+		const bool rayInside = dot(lp1.Ns, wo) < 0;
+		bd_offset(o2, lp1.Ns, rayInside);
+		const int index = world_to_pixel(p.cam, lp1.pos);
+		const V3 addv = res * p.spp_inv;
+		p.rec.A[slot] = make_float4(o2.x, o2.y, o2.z, 0.f);  // (S still holds the camera position)
+		p.rec.P[slot] = make_float4(addv.x, addv.y, addv.z, __int_as_float(index));
+		key = (uint8_t)TUTU_KEY_SHADOW;
+	}
+	p.rec.V[slot] = (uint8_t)TUTU_V_BLOCKED;
+	p.rec.key[slot] = key;
+}
+
+__global__ void __launch_bounds__(256) k_lt_emit(BidirParams p) {
+	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= p.n_units) return;
+	if ((p.rec.key[i] & TUTU_KEY_SHADOW) && p.rec.V[i] == TUTU_V_ADD) {
+		const float4 P = p.rec.P[i];
+		lt_event(p, i, 1, 1, __float_as_int(P.w), mk(P.x, P.y, P.z));
+	}
+}
+
 // ---------------------------------------------------------------------------------------------- kernels
 template <int TYPE, typename S>
 TUTU_DEV void run_unit(const S* ss, const BidirParams& p, const ShadeTabs& tb, int* stack, uint32_t i, uint32_t pix, uint32_t smp,
@@ -680,8 +822,29 @@ __global__ void __launch_bounds__(256) k_bidir_own(const float4* own, const floa
 
 // events sorted by key (target pixel, then sequence; idx = where the event's value is): the first event of every target
 // replays its target's run in order
+// last_set[target] = 1 + the position (in sorted order) of the target's LAST setRGB of this batch, 0 = none.  LightTracing
+// sends a setRGB per unit to the few pixels that see the light: runs of thousands of events of which only the tail after the
+// last set matters, and one lane walking such a run through two dependent loads per event was 83 % of a LightTracing frame.
+__global__ void __launch_bounds__(256) k_bidir_mark(const unsigned long long* key_sorted, const uint32_t* idx_sorted, const float4* ev_val, uint32_t n_ev,
+                                                    uint32_t* last_set) {
+	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	const int lane = __lane_id();
+	const unsigned long long k = i < n_ev ? key_sorted[i] : ~0ull;
+	const uint32_t target = (uint32_t)(k >> 40);
+	const bool is_set = k != ~0ull && ev_val[idx_sorted[i]].w == 0.f;
+	// the events of a target are consecutive (sorted): one atomic per target and wave, from the wave's last set of that target
+	const uint32_t next_target = (uint32_t)__shfl_down((int)target, 1);
+	const unsigned long long m_set = __ballot(is_set);
+	const unsigned long long m_end = __ballot(lane == 63 || next_target != target);  // last lane of its target's stretch in this wave
+	if (is_set) {
+		const int e = lane + __ffsll((long long)(m_end >> lane)) - 1;                        // where this lane's stretch ends
+		const unsigned long long later = e > lane ? (m_set >> (lane + 1)) & ((e - lane) >= 64 ? ~0ull : ((1ull << (e - lane)) - 1ull)) : 0ull;
+		if (later == 0ull) atomicMax(&last_set[target], i + 1u);
+	}
+}
+
 __global__ void __launch_bounds__(256) k_bidir_replay(const unsigned long long* key_sorted, const uint32_t* idx_sorted, const float4* ev_val,
-                                                      uint32_t n_ev, float* frame3) {
+                                                      uint32_t n_ev, const uint32_t* last_set, float* frame3) {
 	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
 	if (i >= n_ev) return;
 	const unsigned long long k = key_sorted[i];
@@ -689,14 +852,9 @@ __global__ void __launch_bounds__(256) k_bidir_replay(const unsigned long long* 
 	const uint32_t target = (uint32_t)(k >> 40);
 	if (i > 0 && (uint32_t)(key_sorted[i - 1] >> 40) == target) return;
 	float r = frame3[3 * (size_t)target], g = frame3[3 * (size_t)target + 1], b = frame3[3 * (size_t)target + 2];
-	// a setRGB wipes everything before it: start at the run's LAST set (LightTracing: the pixels that see the light collect
-	// hundreds of thousands of events, nearly all of them sets; this first scan has no dependent arithmetic)
-	uint32_t start = i;
-	for (uint32_t j = i; j < n_ev; j++) {
-		const unsigned long long kj = key_sorted[j];
-		if (kj == ~0ull || (uint32_t)(kj >> 40) != target) break;
-		if (ev_val[idx_sorted[j]].w == 0.f) start = j;
-	}
+	// a setRGB wipes everything before it: start at the run's LAST set (k_bidir_mark)
+	const uint32_t ls = last_set[target];
+	const uint32_t start = ls ? ls - 1u : i;
 	for (uint32_t j = start; j < n_ev; j++) {
 		const unsigned long long kj = key_sorted[j];
 		if (kj == ~0ull || (uint32_t)(kj >> 40) != target) break;

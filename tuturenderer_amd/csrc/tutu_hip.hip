@@ -130,7 +130,7 @@ struct TutuCtx {
 	struct Bidir {
 		DevBuf<float4> own, own_list, ev_val;
 		DevBuf<unsigned long long> ev_key, ev_key_sorted;
-		DevBuf<uint32_t> idx, idx_sorted;
+		DevBuf<uint32_t> idx, idx_sorted, last_set;
 		DevBuf<uint8_t> sort_tmp;
 		DevBuf<float> frame;
 		hipEvent_t t0 = nullptr, t1 = nullptr;
@@ -768,7 +768,7 @@ int tutu_hip_destroy(TutuCtx* c) {
 	c->totals.release(); c->pixels.release(); c->u32a.release(); c->u32b.release();
 	c->out_stage.release();
 	c->bd.own.release(); c->bd.own_list.release(); c->bd.ev_val.release(); c->bd.ev_key.release(); c->bd.ev_key_sorted.release();
-	c->bd.idx.release(); c->bd.idx_sorted.release(); c->bd.sort_tmp.release(); c->bd.frame.release();
+	c->bd.idx.release(); c->bd.idx_sorted.release(); c->bd.sort_tmp.release(); c->bd.frame.release(); c->bd.last_set.release();
 	if (c->bd.t0) (void)hipEventDestroy(c->bd.t0);
 	if (c->bd.t1) (void)hipEventDestroy(c->bd.t1);
 	if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -1020,6 +1020,56 @@ int bidir_launch(TutuCtx* c, hipStream_t s, const BidirParams& p) {
 	return TUTU_OK;
 }
 
+// LightTracing as a wavefront (device_bidir.h: k_lt_gen / k_lt_connect / k_lt_emit around the path tracer's list and
+// traversal kernels), one batch of units; leaves the batch's events in p.ev_key / p.ev_val like k_bidir<1> does
+int lt_wavefront_batch(TutuCtx* c, hipStream_t s, BidirParams p) {
+	WorkSet& w = c->ws[0];
+	const uint32_t n_pad = (p.n_units + TUTU_LIST_TILE - 1) / TUTU_LIST_TILE * TUTU_LIST_TILE;
+	int rc = ensure_set(w, n_pad);
+	if (rc != TUTU_OK) return rc;
+	c->ev_used = 0;
+	p.rec = records_of(w, 0);
+	p.n_pad = n_pad;
+	p.list = w.lists.p;
+	p.hitC = w.hitC.p;
+	uint32_t* meta0 = w.list_meta.p;                     // lists of the generation stage
+	uint32_t* meta1 = w.list_meta.p + TUTU_META_STRIDE;  // list of the second shadow requests
+	p.n_list = meta0;
+	k_lt_gen<<<dim3(n_pad / 256), dim3(256), 0, s>>>(p);
+	HIP_TRY(hipGetLastError());
+	if ((rc = build_lists(c, w, s, p.rec.key, n_pad, nullptr, n_pad, meta0, nullptr, nullptr)) != TUTU_OK) return rc;
+	TraceParams tp;
+	tp.sc = c->sc;
+	tp.rec = p.rec;
+	tp.list = w.lists.p;
+	tp.n_ptr = meta0 + 0;
+	tp.hitC = w.hitC.p;
+	tp.hitK = w.hitK.p;
+	tp.F = w.F.p;
+	tp.tri_class = c->d_tri_class.p;
+	tp.stack_entries = c->stack_entries;
+	tp.refill_min = c->knobs.refill_min;
+	tp.inner_steps = c->knobs.inner_steps;
+	tp.any_near_first = c->knobs.any_near_first;
+	tp.part = nullptr;
+	const int grid = persistent_grid(p.n_units, c->n_cu, c->trace_blocks_per_cu);
+	launch_trace<false>(c, s, grid, tp);
+	tp.list = w.lists.p + w.cap;
+	tp.n_ptr = meta0 + 1;
+	launch_trace<true>(c, s, grid, tp);
+	HIP_TRY(hipGetLastError());
+	k_lt_connect<<<dim3((p.n_units + 255) / 256), dim3(256), 0, s>>>(p);
+	HIP_TRY(hipGetLastError());
+	if ((rc = build_lists(c, w, s, p.rec.key, n_pad, nullptr, n_pad, meta1, nullptr, nullptr)) != TUTU_OK) return rc;
+	tp.list = w.lists.p + w.cap;
+	tp.n_ptr = meta1 + 1;
+	launch_trace<true>(c, s, grid, tp);
+	k_lt_emit<<<dim3((p.n_units + 255) / 256), dim3(256), 0, s>>>(p);
+	HIP_TRY(hipGetLastError());
+	c->ev_used = 0;
+	return TUTU_OK;
+}
+
 int bidir_check(TutuCtx* c, int type, const TutuCameraDesc* cam, int spp) {
 	if (!c || !cam) return TUTU_E_INVALID;
 	if (type != TUTU_INTEGRATOR_LIGHT && type != TUTU_INTEGRATOR_NAIVEPT && type != TUTU_INTEGRATOR_BDPT) return TUTU_E_INVALID;
@@ -1059,6 +1109,7 @@ int tutu_hip_render_integrator(TutuCtx* c, int32_t type, const TutuCameraDesc* c
 	if ((rc = b.idx.ensure(max_ev)) != TUTU_OK) return rc;
 	if ((rc = b.idx_sorted.ensure(max_ev)) != TUTU_OK) return rc;
 	if ((rc = b.frame.ensure(3 * (size_t)npix)) != TUTU_OK) return rc;
+	if ((rc = b.last_set.ensure(npix)) != TUTU_OK) return rc;
 	size_t tmp_bytes = 0;
 	HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, b.ev_key.p, b.ev_key_sorted.p, b.idx.p, b.idx_sorted.p, (int)max_ev, 0, 64, s));
 	if ((rc = b.sort_tmp.ensure(tmp_bytes)) != TUTU_OK) return rc;
@@ -1073,11 +1124,14 @@ int tutu_hip_render_integrator(TutuCtx* c, int32_t type, const TutuCameraDesc* c
 	p.own_list = type == TUTU_INTEGRATOR_BDPT ? b.own_list.p : nullptr;
 	p.ev_key = b.ev_key.p;
 	p.ev_val = b.ev_val.p;
+	const bool lt_wavefront = type == TUTU_INTEGRATOR_LIGHT && !getenv("TUTU_LT_UNIT_KERNEL");
 	for (uint32_t pix0 = 0; pix0 < npix; pix0 += pix_per_batch) {
 		const uint32_t np = std::min(pix_per_batch, npix - pix0);
 		p.n_units = np * (uint32_t)spp;
 		p.first_pix = pix0;
-		if ((rc = bidir_launch(c, s, p)) != TUTU_OK) return rc;
+		if (lt_wavefront) {
+			if ((rc = lt_wavefront_batch(c, s, p)) != TUTU_OK) return rc;
+		} else if ((rc = bidir_launch(c, s, p)) != TUTU_OK) return rc;
 		size_t n_ev = (size_t)p.n_units * (size_t)p.ev_stride;
 		if (type != TUTU_INTEGRATOR_LIGHT) {
 			hipLaunchKernelGGL(k_bidir_own, dim3((np + 255) / 256), dim3(256), 0, s, b.own.p, p.own_list, type, spp, p.spp_inv, pix0, np, b.ev_key.p + n_ev,
@@ -1085,8 +1139,11 @@ int tutu_hip_render_integrator(TutuCtx* c, int32_t type, const TutuCameraDesc* c
 			n_ev += np;
 		}
 		HIP_TRY(hipcub::DeviceRadixSort::SortPairs(b.sort_tmp.p, tmp_bytes, b.ev_key.p, b.ev_key_sorted.p, b.idx.p, b.idx_sorted.p, (int)n_ev, 0, 64, s));
+		HIP_TRY(hipMemsetAsync(b.last_set.p, 0, sizeof(uint32_t) * (size_t)npix, s));
+		hipLaunchKernelGGL(k_bidir_mark, dim3((unsigned)((n_ev + 255) / 256)), dim3(256), 0, s, b.ev_key_sorted.p, b.idx_sorted.p, b.ev_val.p, (uint32_t)n_ev,
+		                   b.last_set.p);
 		hipLaunchKernelGGL(k_bidir_replay, dim3((unsigned)((n_ev + 255) / 256)), dim3(256), 0, s, b.ev_key_sorted.p, b.idx_sorted.p, b.ev_val.p, (uint32_t)n_ev,
-		                   b.frame.p);
+		                   b.last_set.p, b.frame.p);
 		HIP_TRY(hipGetLastError());
 	}
 	HIP_TRY(hipEventRecord(b.t1, s));
