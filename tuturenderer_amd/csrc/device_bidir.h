@@ -72,7 +72,7 @@ __device__ __noinline__ V3 bd_bxdf(const Mat* m, V3 wi, V3 wo, V3 Ng, V3 Ns, flo
 	// Material::BxDF's `adjoint` (Material.hpp:62-73): the sidedness test is symmetric in wi / wo, then they change places
 	return adjoint ? BxDF(*m, wo, wi, Ng, Ns, eta_scene, TIR) : BxDF(*m, wi, wo, Ng, Ns, eta_scene, TIR);
 }
-__device__ __noinline__ float bd_pdf(const Mat* m, V3 wi, V3 wo, V3 N, float eta_i, float eta_t) { return mat_pdf(*m, wi, wo, N, eta_i, eta_t); }
+TUTU_DEV float bd_pdf(const Mat* m, V3 wi, V3 wo, V3 N, float eta_i, float eta_t) { return mat_pdf(*m, wi, wo, N, eta_i, eta_t); }
 __device__ __noinline__ void bd_sample(Mat* m, V3 wo, V3 N, V3* wi, float eta_i, Rng* rng, bool* ok, bool* special) {
 	sampleDirection(*m, wo, N, *wi, eta_i, *rng, *ok, *special);
 }
@@ -295,7 +295,7 @@ TUTU_DEV bool naive_unit(BdCtx<S>& c, V3 pixelPos) {
 // ---------------------------------------------------------------------------------------------- BDPT
 // BDPT::MISweight, BDPT.hpp:70-230
 template <typename S>
-__device__ __noinline__ float bdpt_mis(BdCtx<S>* cp, const BVert* ep, const BVert* lp, int Sn, int Tn) {
+TUTU_DEV float bdpt_mis(BdCtx<S>* cp, const BVert* ep, const BVert* lp, int Sn, int Tn) {
 	BdCtx<S>& c = *cp;
 	const DevCam& cam = c.p->cam;
 	const float eta = c.p->sc.eta;
