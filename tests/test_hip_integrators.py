@@ -158,26 +158,6 @@ def test_light_tracing_wavefront_is_the_unit_kernel_frame(tr, name, monkeypatch)
     assert bit_equal(a, b) and bit_equal(a, a_small) and np.nanmean(a) > 0.01
 
 
-@pytest.mark.parametrize("name", CASES + ["spheres"])
-def test_bdpt_two_kernels_is_the_unit_kernel_frame(tr, name, monkeypatch):
-    """tutu_hip_render_integrator renders BDPT with two kernels (the walks, then one lane per (unit, strategy) reading the paths
-    from memory); TUTU_BDPT_UNIT_KERNEL selects the all-in-one-lane kernel that tutu_hip_integrator_samples uses.  Same
-    strategy code on the same vertices, contributions and splats applied in the same order: the same frame, bit for bit."""
-    from tuturenderer_amd import scenes
-
-    sc = scenes.cornell_spheres(64, 48) if name == "spheres" else integrator_cases()[name][0]()
-    monkeypatch.delenv("TUTU_BDPT_UNIT_KERNEL", raising=False)
-    with tr.Context(sc) as ctx:
-        a = ctx.render_integrator("bdpt", 5, pc.KEY0, 89)
-        ctx.set_option("bidir_units", 700)
-        a_small = ctx.render_integrator("bdpt", 5, pc.KEY0, 89)
-    monkeypatch.setenv("TUTU_BDPT_UNIT_KERNEL", "1")
-    with tr.Context(sc) as ctx:
-        b = ctx.render_integrator("bdpt", 5, pc.KEY0, 89)
-    monkeypatch.delenv("TUTU_BDPT_UNIT_KERNEL", raising=False)
-    assert bit_equal(a, b) and bit_equal(a, a_small) and np.nanmean(a) > 0.01
-
-
 def test_larger_frame_batches_and_argument_checks(tr, port):
     from tuturenderer_amd import scenes
 

@@ -48,12 +48,6 @@ struct BidirParams {
 	                              // scaling) | w = -1 when the primary ray missed, else the number of contributions
 	float4* own_list;             // [n_units][TUTU_BIDIR_MAX_OWN] the contributions one by one (BDPT frames: the pixel's estimate is
 	                              // ONE running sum over all its samples' contributions, and float addition is not associative); may be null
-	// BDPT in two kernels (k_bidir<3> in walk-only mode, then k_bdpt_connect): the unit's path vertices and what the strategies
-	// need besides them, in memory.  vert: [field][vertex][unit] (TUTU_BD_VFIELDS x TUTU_BD_VERTS x n_units floats; vertex
-	// 0..7 = eye path, 8..14 = light path); umeta: [unit] = we | ne + 16 * nl | type of the first hit | alive ; umeta2: its diffuse
-	float* vert;
-	float4* umeta;
-	float4* umeta2;
 	// LightTracing as a wavefront (k_lt_*): the unit's rays go through the path tracer's record set and traversal kernels
 	Records rec;
 	const uint32_t* list;         // list 0 of the generation stage: the units that shot a ray
@@ -90,54 +84,6 @@ struct BVert {  // bdpt::eyePathVert / lightPathVert (BDPT.hpp:32-48) -- and the
 	float fwdPdf, revPdf, G;
 	bool isDelta;
 };
-
-#define TUTU_BD_VFIELDS 29
-#define TUTU_BD_VERTS 15  // 8 eye-path + 7 light-path vertices
-
-// the two paths of a unit as the strategy code reads them: E(i) / L(i) = eye / light vertex i.  Returned by value: the loads
-// of the fields a caller does not use are dead and removed.
-struct PathsPriv {
-	const BVert* ep;
-	const BVert* lp;
-	TUTU_DEV BVert E(int i) const { return ep[i]; }
-	TUTU_DEV BVert L(int i) const { return lp[i]; }
-};
-struct PathsGlobal {
-	const float* vert;
-	uint32_t n_units, u;
-	TUTU_DEV float f(int field, int vi) const { return vert[((size_t)field * TUTU_BD_VERTS + vi) * n_units + u]; }
-	TUTU_DEV BVert load(int vi) const {
-		BVert v;
-		v.throughput = mk(f(0, vi), f(1, vi), f(2, vi));
-		v.pos = mk(f(3, vi), f(4, vi), f(5, vi));
-		v.Ng = mk(f(6, vi), f(7, vi), f(8, vi));
-		v.Ns = mk(f(9, vi), f(10, vi), f(11, vi));
-		v.m.diffuse = mk(f(12, vi), f(13, vi), f(14, vi));
-		v.m.emission = mk(f(15, vi), f(16, vi), f(17, vi));
-		v.m.type = __float_as_int(f(18, vi));
-		v.m.has_emission = __float_as_int(f(19, vi));
-		v.m.alpha = f(20, vi);
-		v.m.eta = f(21, vi);
-		v.m.roughness = f(22, vi);
-		v.m.metallic = f(23, vi);
-		v.light_pdf = f(24, vi);
-		v.fwdPdf = f(25, vi);
-		v.revPdf = f(26, vi);
-		v.G = f(27, vi);
-		v.isDelta = f(28, vi) != 0.f;
-		return v;
-	}
-	TUTU_DEV BVert E(int i) const { return load(i); }
-	TUTU_DEV BVert L(int i) const { return load(8 + i); }
-};
-TUTU_DEV void bd_store_vert(float* vert, uint32_t n_units, uint32_t u, int vi, const BVert& v) {
-	const float w[TUTU_BD_VFIELDS] = {v.throughput.x, v.throughput.y, v.throughput.z, v.pos.x, v.pos.y, v.pos.z, v.Ng.x, v.Ng.y, v.Ng.z, v.Ns.x, v.Ns.y, v.Ns.z,
-	                                  v.m.diffuse.x, v.m.diffuse.y, v.m.diffuse.z, v.m.emission.x, v.m.emission.y, v.m.emission.z, __int_as_float(v.m.type),
-	                                  __int_as_float(v.m.has_emission), v.m.alpha, v.m.eta, v.m.roughness, v.m.metallic, v.light_pdf, v.fwdPdf, v.revPdf, v.G,
-	                                  v.isDelta ? 1.f : 0.f};
-#pragma unroll
-	for (int k = 0; k < TUTU_BD_VFIELDS; k++) vert[((size_t)k * TUTU_BD_VERTS + vi) * n_units + u] = w[k];
-}
 
 TUTU_DEV int world_to_pixel(const DevCam& c, V3 p) {  // Camera::worldPos2PixelIndex + raster2pxlIndex, Camera.hpp:52-79
 	const float* e = c.w2r;
@@ -216,7 +162,7 @@ struct BdCtx {
 	}
 	TUTU_DEV void add_own(V3 v) {  // estimate = estimate + v
 		own = own + v;
-		if (p->own_list && n_own < TUTU_BIDIR_MAX_OWN) p->own_list[(size_t)unit_slot * TUTU_BIDIR_MAX_OWN + n_own] = make_float4(v.x, v.y, v.z, 1.f);
+		if (p->own_list && n_own < TUTU_BIDIR_MAX_OWN) p->own_list[(size_t)unit_slot * TUTU_BIDIR_MAX_OWN + n_own] = make_float4(v.x, v.y, v.z, 0.f);
 		n_own++;
 	}
 	// BVHStrategy::UpdateInter + what Triangle::intersect / Sphere::intersect put into the Intersection; textureModify where the
@@ -348,16 +294,16 @@ TUTU_DEV bool naive_unit(BdCtx<S>& c, V3 pixelPos) {
 
 // ---------------------------------------------------------------------------------------------- BDPT
 // BDPT::MISweight, BDPT.hpp:70-230
-template <typename S, typename P>
-TUTU_DEV float bdpt_mis(BdCtx<S>* cp, const P& pa, int Sn, int Tn) {
+template <typename S>
+TUTU_DEV float bdpt_mis(BdCtx<S>* cp, const BVert* ep, const BVert* lp, int Sn, int Tn) {
 	BdCtx<S>& c = *cp;
 	const DevCam& cam = c.p->cam;
 	const float eta = c.p->sc.eta;
 	if (Sn + Tn == 2) return 1;
 	float pdf_tEndFwd = 0, pdf_tEndRev = 0, pdf_sEndFwd = 0, pdf_sEndRev = 0, G_connect = 0;
 	if (Sn == 0) {
-		const BVert lightPrev = pa.E(Tn - 2);
-		const BVert lightvert = pa.E(Tn - 1);
+		const BVert& lightPrev = ep[Tn - 2];
+		const BVert& lightvert = ep[Tn - 1];
 		const V3 wo = normalized(lightPrev.pos - lightvert.pos);
 		const float cs = fabsf(dot(lightvert.Ng, wo));
 		float dirpdf = cs / TUTU_PI;
@@ -365,8 +311,8 @@ TUTU_DEV float bdpt_mis(BdCtx<S>* cp, const P& pa, int Sn, int Tn) {
 		pdf_tEndFwd = lightvert.light_pdf;  // getLightPdf
 		pdf_tEndRev = dirpdf;
 	} else {
-		const BVert sEnd = pa.L(Sn - 1);
-		const BVert tEnd = pa.E(Tn - 1);
+		const BVert& sEnd = lp[Sn - 1];
+		const BVert& tEnd = ep[Tn - 1];
 		G_connect = bd_Geo(sEnd.pos, sEnd.Ng, tEnd.pos, tEnd.Ng);
 		if (Tn == 1) {
 			const V3 cam2sEnd = normalized(sEnd.pos - tEnd.pos);
@@ -374,7 +320,7 @@ TUTU_DEV float bdpt_mis(BdCtx<S>* cp, const P& pa, int Sn, int Tn) {
 			const float d = cam.imagePlaneDist / camcos;
 			pdf_tEndFwd = (cam.filmPlaneAreaInv * d * d / camcos) / camcos;
 			pdf_tEndRev = cam.lensAreaInv;
-			const V3 s2prev = normalized(pa.L(Sn - 2).pos - sEnd.pos);
+			const V3 s2prev = normalized(lp[Sn - 2].pos - sEnd.pos);
 			pdf_sEndFwd = bd_pdf(&sEnd.m, -cam2sEnd, s2prev, sEnd.Ns, eta, sEnd.m.eta) / fabsf(dot(-cam2sEnd, sEnd.Ng));
 			pdf_sEndRev = bd_pdf(&sEnd.m, s2prev, -cam2sEnd, sEnd.Ns, eta, sEnd.m.eta) / fabsf(dot(s2prev, sEnd.Ng));
 		} else if (Sn == 1) {
@@ -382,13 +328,13 @@ TUTU_DEV float bdpt_mis(BdCtx<S>* cp, const P& pa, int Sn, int Tn) {
 			const float cs = dot(sEnd.Ng, light2tEnd);
 			pdf_sEndFwd = cs / TUTU_PI / cs;
 			pdf_sEndRev = sEnd.revPdf;
-			const V3 t2prev = normalized(pa.E(Tn - 2).pos - tEnd.pos);
+			const V3 t2prev = normalized(ep[Tn - 2].pos - tEnd.pos);
 			pdf_tEndFwd = bd_pdf(&tEnd.m, -light2tEnd, t2prev, tEnd.Ns, eta, tEnd.m.eta) / fabsf(dot(-light2tEnd, tEnd.Ng));
 			pdf_tEndRev = bd_pdf(&tEnd.m, t2prev, -light2tEnd, tEnd.Ns, eta, tEnd.m.eta) / fabsf(dot(t2prev, tEnd.Ng));
 		} else {
 			const V3 s2t = normalized(tEnd.pos - sEnd.pos);
-			const V3 s2prev = normalized(pa.L(Sn - 2).pos - sEnd.pos);
-			const V3 t2prev = normalized(pa.E(Tn - 2).pos - tEnd.pos);
+			const V3 s2prev = normalized(lp[Sn - 2].pos - sEnd.pos);
+			const V3 t2prev = normalized(ep[Tn - 2].pos - tEnd.pos);
 			pdf_sEndFwd = bd_pdf(&sEnd.m, s2t, s2prev, sEnd.Ns, eta, sEnd.m.eta) / fabsf(dot(s2t, sEnd.Ng));
 			pdf_sEndRev = bd_pdf(&sEnd.m, s2prev, s2t, sEnd.Ns, eta, sEnd.m.eta) / fabsf(dot(s2prev, sEnd.Ng));
 			pdf_tEndFwd = bd_pdf(&tEnd.m, -s2t, t2prev, tEnd.Ns, eta, tEnd.m.eta) / fabsf(dot(-s2t, tEnd.Ng));
@@ -402,23 +348,23 @@ TUTU_DEV float bdpt_mis(BdCtx<S>* cp, const P& pa, int Sn, int Tn) {
 	// (entry k - ti = eye vertex ti).
 	const int k = Sn + Tn - 1;
 	auto toLight = [&](int i) -> float {
-		if (i < Sn - 1) return (i == 0) ? pa.L(0).revPdf : pa.L(i).revPdf * pa.L(i).G;
-		if (i == Sn - 1) return (Sn == 1) ? pdf_sEndRev : pdf_sEndRev * pa.L(Sn - 1).G;
+		if (i < Sn - 1) return (i == 0) ? lp[0].revPdf : lp[i].revPdf * lp[i].G;
+		if (i == Sn - 1) return (Sn == 1) ? pdf_sEndRev : pdf_sEndRev * lp[Sn - 1].G;
 		if (i == Sn) return (Sn == 0) ? pdf_tEndFwd : pdf_tEndFwd * G_connect;
 		const int ti = k - i;
-		return pa.E(ti).fwdPdf * pa.E(ti + 1).G;
+		return ep[ti].fwdPdf * ep[ti + 1].G;
 	};
 	auto toEye = [&](int i) -> float {
-		if (i < Sn - 1) return pa.L(i).fwdPdf * pa.L(i + 1).G;
+		if (i < Sn - 1) return lp[i].fwdPdf * lp[i + 1].G;
 		if (i == Sn - 1) return pdf_sEndFwd * G_connect;
-		if (i == Sn) return (Tn == 1) ? pdf_tEndRev : pdf_tEndRev * pa.E(Tn - 1).G;
+		if (i == Sn) return (Tn == 1) ? pdf_tEndRev : pdf_tEndRev * ep[Tn - 1].G;
 		const int ti = k - i;
-		return (ti == 0) ? pa.E(0).revPdf : pa.E(ti).revPdf * pa.E(ti).G;
+		return (ti == 0) ? ep[0].revPdf : ep[ti].revPdf * ep[ti].G;
 	};
 	auto delta = [&](int i) -> bool {
-		if (i <= Sn - 1) return pa.L(i).isDelta;
-		if (i == Sn) return pa.E(Tn - 1).isDelta;
-		return pa.E(k - i).isDelta;
+		if (i <= Sn - 1) return lp[i].isDelta;
+		if (i == Sn) return ep[Tn - 1].isDelta;
+		return ep[k - i].isDelta;
 	};
 
 	float p_i_plus_1 = 1.0f;
@@ -499,94 +445,6 @@ __device__ __noinline__ void bdpt_walk(BdCtx<S>* cp, BVert* v, int* n_io, int ma
 	*n_io = n;
 }
 
-// One (s, t) strategy of sub_render_bdpt's double loop (BDPT.hpp:700-880): the contribution of connecting light vertex s - 1
-// to eye vertex t - 1, MIS-weighted, to the unit's own pixel (add_own) or, for t = 1, to the pixel the light vertex projects
-// to (emit).  pa = the two paths (PathsPriv in the unit kernel, PathsGlobal in k_bdpt_connect).
-template <typename S, typename P>
-TUTU_DEV void bdpt_strategy(BdCtx<S>& c, const P& pa, int ne, int nl, int pathLength, int Sn, float we, int first_type, V3 first_diffuse) {
-	const DevCam& cam = c.p->cam;
-	const float eta = c.p->sc.eta;
-	const V3 eyePos = ld3(cam.position), camFwd = ld3(cam.fwdDir);
-	const int Tn = pathLength + 1 - Sn;
-	if (Tn <= 0 || Tn > ne || Sn > nl) return;
-	if (Sn == 0) {
-		if (first_type == TUTU_UNLIT) {
-			c.add_own(first_diffuse);
-			return;
-		}
-		const BVert e = pa.E(Tn - 1);
-		if (!e.m.has_emission) return;
-		const V3 contrib = we * e.throughput * e.m.emission;
-		if (norm2(contrib) == 0) return;
-		if (isnan(contrib.x)) return;
-		const float misw = bdpt_mis(&c, pa, Sn, Tn);
-		c.add_own(misw * contrib);
-		return;
-	}
-	if (Tn == 1) {
-		const BVert lv = pa.L(Sn - 1);
-		if (lv.m.has_emission) return;
-		const V3 l = pa.L(0).m.emission;
-		V3 orig = lv.pos;
-		const V3 wic = normalized(eyePos - orig);
-		bool rayInside;
-		V3 bsdf;
-		if (Sn == 1) {
-			bsdf = mk1(1.f);
-			rayInside = false;
-		} else {
-			const V3 wo = normalized(pa.L(Sn - 2).pos - lv.pos);
-			rayInside = dot(wic, lv.Ng) < 0;  // Ng here (the single-thread variant tests Ns) BDPT.hpp:740
-			bsdf = bd_bxdf(&lv.m, wic, wo, lv.Ng, lv.Ns, eta, true, false);
-		}
-		const float G = bd_Geo(eyePos, camFwd, lv.pos, lv.Ng);
-		const float wel = bd_We(lv.pos, cam);
-		const V3 contrib = l * bsdf * lv.throughput * G * wel * c.p->spp_inv;
-		if (norm2(contrib) == 0) return;
-		if (isnan(contrib.x)) return;
-		const float misw = bdpt_mis(&c, pa, Sn, Tn);
-		bd_offset(orig, lv.Ns, rayInside);
-		if (!c.blocked(orig, eyePos) && dot(wic, camFwd) < 0) {
-			const int index = world_to_pixel(cam, lv.pos);
-			c.emit(1, index, misw * contrib);
-		}
-		return;
-	}
-	const BVert lv = pa.L(Sn - 1);
-	const V3 l = pa.L(0).m.emission;
-	const BVert e = pa.E(Tn - 1);
-	if (e.m.has_emission) return;
-	const V3 connectDir = normalized(e.pos - lv.pos);
-	const V3 e_wo = normalized(pa.E(Tn - 2).pos - e.pos);
-	const V3 evBSDF = bd_bxdf(&e.m, -connectDir, e_wo, e.Ng, e.Ns, eta, false, false);
-	V3 lvBSDF;
-	V3 l_wo = mk1(0.f);
-	if (Sn == 1) {
-		if (dot(connectDir, lv.Ns) >= 0) lvBSDF = mk1(1.f);
-		else lvBSDF = mk1(0.f);
-	} else {
-		l_wo = normalized(pa.L(Sn - 2).pos - lv.pos);
-		lvBSDF = bd_bxdf(&lv.m, connectDir, l_wo, lv.Ng, lv.Ns, eta, true, false);
-	}
-	V3 eOrig = e.pos;
-	bool rayInside = dot(e_wo, e.Ns) < 0;
-	bd_offset(eOrig, e.Ns, rayInside);
-	V3 lorig = lv.pos;
-	if (Sn == 1) {
-		bd_offset(lorig, lv.Ns, false);
-	} else {
-		rayInside = dot(l_wo, lv.Ns) < 0;
-		bd_offset(lorig, lv.Ns, rayInside);
-	}
-	if (c.blocked(eOrig, lorig)) return;
-	const float G = bd_Geo(e.pos, e.Ng, lv.pos, lv.Ng);
-	const V3 contrib = we * e.throughput * evBSDF * G * lv.throughput * lvBSDF * l;
-	if (norm2(contrib) == 0) return;
-	if (isnan(contrib.x)) return;
-	const float misw = bdpt_mis(&c, pa, Sn, Tn);
-	c.add_own(misw * contrib);
-}
-
 template <typename S>
 TUTU_DEV bool bdpt_unit(BdCtx<S>& c, V3 pixelPos) {
 	const DevCam& cam = c.p->cam;
@@ -652,19 +510,89 @@ TUTU_DEV bool bdpt_unit(BdCtx<S>& c, V3 pixelPos) {
 		}
 	}
 	const float we = bd_We(pixelPos, cam);
-	if (c.p->vert) {
-		// walk-only mode: the paths go to memory, k_bdpt_connect runs the strategies -- one lane per (unit, strategy)
-		const uint32_t u = c.unit_slot, nu = c.p->n_units;
-		for (int i = 0; i < ne; i++) bd_store_vert(c.p->vert, nu, u, i, ep[i]);
-		for (int i = 0; i < nl; i++) bd_store_vert(c.p->vert, nu, u, 8 + i, lp[i]);
-		c.p->umeta[u] = make_float4(we, __int_as_float(ne + 16 * nl), __int_as_float(first_type), 1.f);
-		c.p->umeta2[u] = make_float4(first_diffuse.x, first_diffuse.y, first_diffuse.z, 0.f);
-		return true;
-	}
 	if (ne < 2) return true;
-	const PathsPriv pa{ep, lp};
-	for (int pathLength = 1; pathLength <= TUTU_BIDIR_MAXLEN; pathLength++)
-		for (int Sn = 0; Sn < pathLength + 1; Sn++) bdpt_strategy(c, pa, ne, nl, pathLength, Sn, we, first_type, first_diffuse);
+	for (int pathLength = 1; pathLength <= TUTU_BIDIR_MAXLEN; pathLength++) {
+		for (int Sn = 0; Sn < pathLength + 1; Sn++) {
+			const int Tn = pathLength + 1 - Sn;
+			if (Tn <= 0 || Tn > ne || Sn > nl) continue;
+			if (Sn == 0) {
+				if (first_type == TUTU_UNLIT) {
+					c.add_own(first_diffuse);
+					continue;
+				}
+				const BVert& e = ep[Tn - 1];
+				if (!e.m.has_emission) continue;
+				const V3 contrib = we * e.throughput * e.m.emission;
+				if (norm2(contrib) == 0) continue;
+				if (isnan(contrib.x)) continue;
+				const float misw = bdpt_mis(&c, ep, lp, Sn, Tn);
+				c.add_own(misw * contrib);
+				continue;
+			}
+			if (Tn == 1) {
+				const BVert& lv = lp[Sn - 1];
+				if (lv.m.has_emission) continue;
+				const V3 l = lp[0].m.emission;
+				V3 orig = lv.pos;
+				const V3 wic = normalized(eyePos - orig);
+				bool rayInside;
+				V3 bsdf;
+				if (Sn == 1) {
+					bsdf = mk1(1.f);
+					rayInside = false;
+				} else {
+					const V3 wo = normalized(lp[Sn - 2].pos - lv.pos);
+					rayInside = dot(wic, lv.Ng) < 0;  // Ng here (the single-thread variant tests Ns) BDPT.hpp:740
+					bsdf = bd_bxdf(&lv.m, wic, wo, lv.Ng, lv.Ns, eta, true, false);
+				}
+				const float G = bd_Geo(eyePos, camFwd, lv.pos, lv.Ng);
+				const float wel = bd_We(lv.pos, cam);
+				const V3 contrib = l * bsdf * lv.throughput * G * wel * c.p->spp_inv;
+				if (norm2(contrib) == 0) continue;
+				if (isnan(contrib.x)) continue;
+				const float misw = bdpt_mis(&c, ep, lp, Sn, Tn);
+				bd_offset(orig, lv.Ns, rayInside);
+				if (!c.blocked(orig, eyePos) && dot(wic, camFwd) < 0) {
+					const int index = world_to_pixel(cam, lv.pos);
+					c.emit(1, index, misw * contrib);
+				}
+				continue;
+			}
+			const BVert& lv = lp[Sn - 1];
+			const V3 l = lp[0].m.emission;
+			const BVert& e = ep[Tn - 1];
+			if (e.m.has_emission) continue;
+			const V3 connectDir = normalized(e.pos - lv.pos);
+			const V3 e_wo = normalized(ep[Tn - 2].pos - e.pos);
+			const V3 evBSDF = bd_bxdf(&e.m, -connectDir, e_wo, e.Ng, e.Ns, eta, false, false);
+			V3 lvBSDF;
+			V3 l_wo = mk1(0.f);
+			if (Sn == 1) {
+				if (dot(connectDir, lv.Ns) >= 0) lvBSDF = mk1(1.f);
+				else lvBSDF = mk1(0.f);
+			} else {
+				l_wo = normalized(lp[Sn - 2].pos - lv.pos);
+				lvBSDF = bd_bxdf(&lv.m, connectDir, l_wo, lv.Ng, lv.Ns, eta, true, false);
+			}
+			V3 eOrig = e.pos;
+			bool rayInside = dot(e_wo, e.Ns) < 0;
+			bd_offset(eOrig, e.Ns, rayInside);
+			V3 lorig = lv.pos;
+			if (Sn == 1) {
+				bd_offset(lorig, lv.Ns, false);
+			} else {
+				rayInside = dot(l_wo, lv.Ns) < 0;
+				bd_offset(lorig, lv.Ns, rayInside);
+			}
+			if (c.blocked(eOrig, lorig)) continue;
+			const float G = bd_Geo(e.pos, e.Ng, lv.pos, lv.Ng);
+			const V3 contrib = we * e.throughput * evBSDF * G * lv.throughput * lvBSDF * l;
+			if (norm2(contrib) == 0) continue;
+			if (isnan(contrib.x)) continue;
+			const float misw = bdpt_mis(&c, ep, lp, Sn, Tn);
+			c.add_own(misw * contrib);
+		}
+	}
 	return true;
 }
 
@@ -861,74 +789,6 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))
 	const unsigned long long seq0 = ((unsigned long long)pix * (unsigned long long)p.spp + smp) * 16ull;
 	if (LDS_SCENE) run_unit<TYPE>(&sl, p, tb, lds + threadIdx.x, i, pix, smp, seq0, pixelPos);
 	else run_unit<TYPE>(&sg, p, tb, lds + threadIdx.x, i, pix, smp, seq0, pixelPos);
-}
-
-// BDPT's strategies, one lane per (unit, strategy): blockIdx.y = the strategy's place in sub_render_bdpt's double loop (path
-// length 1..7, s = 0..length: 35 of them), the unit's paths read from memory (k_bidir<3> in walk-only mode wrote them).  All
-// lanes of a wave run the same strategy on neighbouring units.  A strategy with t >= 2 owns slot length * (length - 1) / 2 + s
-// of the unit's contribution list (value | 1 = there is one), a t = 1 strategy event slot length - 1: the replay and
-// k_bidir_own_slots see them in the order the unit kernel produces them.
-template <bool LDS_SCENE>
-__global__ void __launch_bounds__(256) k_bdpt_connect(BidirParams p) {
-	extern __shared__ int lds[];
-	SceneLds sl;
-	SceneGlobal sg;
-	if (LDS_SCENE) sl = stage_scene_lds(p.sc, lds, p.stack_entries);
-	else {
-		sg.nodes = p.sc.nodes;
-		sg.tris = p.sc.tri_isect;
-	}
-	const uint32_t u = blockIdx.x * blockDim.x + threadIdx.x;
-	if (u >= p.n_units) return;
-	int q = (int)blockIdx.y, L = 1;
-	while (q > L) {
-		q -= L + 1;
-		L++;
-	}
-	const int Sn = q;  // 0..L
-	const bool own_slot = Sn <= L - 1;  // t >= 2
-	const size_t oslot = (size_t)u * TUTU_BIDIR_MAX_OWN + (size_t)(L * (L - 1) / 2 + Sn);
-	if (own_slot) p.own_list[oslot] = make_float4(0.f, 0.f, 0.f, 0.f);
-	if (p.own[u].w < 0.f) return;  // the primary ray missed
-	const float4 m1 = p.umeta[u], m2 = p.umeta2[u];
-	const int nn = __float_as_int(m1.y), ne = nn & 15, nl = nn >> 4;
-	if (ne < 2) return;
-	const uint32_t pix = p.first_pix + u / (uint32_t)p.spp, smp = u % (uint32_t)p.spp;
-	const PathsGlobal pa{p.vert, p.n_units, u};
-	if (LDS_SCENE) {
-		BdCtx<SceneLds> c;
-		c.ss = &sl; c.p = &p; c.tb = bd_global_tabs(p.sc); c.stack = lds + threadIdx.x;
-		c.n_ev = (uint32_t)(L - 1); c.n_own = (uint32_t)(L * (L - 1) / 2 + Sn); c.unit_slot = u; c.own = mk1(0.f);
-		c.seq0 = ((unsigned long long)pix * (unsigned long long)p.spp + smp) * 16ull;
-		bdpt_strategy(c, pa, ne, nl, L, Sn, m1.x, __float_as_int(m1.z), mk(m2.x, m2.y, m2.z));
-	} else {
-		BdCtx<SceneGlobal> c;
-		c.ss = &sg; c.p = &p; c.tb = bd_global_tabs(p.sc); c.stack = lds + threadIdx.x;
-		c.n_ev = (uint32_t)(L - 1); c.n_own = (uint32_t)(L * (L - 1) / 2 + Sn); c.unit_slot = u; c.own = mk1(0.f);
-		c.seq0 = ((unsigned long long)pix * (unsigned long long)p.spp + smp) * 16ull;
-		bdpt_strategy(c, pa, ne, nl, L, Sn, m1.x, __float_as_int(m1.z), mk(m2.x, m2.y, m2.z));
-	}
-}
-
-// k_bidir_own for the two-kernel BDPT: a unit's contributions sit in fixed slots (w = 1 where there is one)
-__global__ void __launch_bounds__(256) k_bidir_own_slots(const float4* own, const float4* own_list, int spp, float spp_inv, uint32_t pix0, uint32_t n_pix,
-                                                         unsigned long long* ev_key, float4* ev_val) {
-	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-	if (i >= n_pix) return;
-	float ex = 0.f, ey = 0.f, ez = 0.f;
-	for (int s = 0; s < spp; s++) {
-		const size_t u = (size_t)i * spp + s;
-		if (own[u].w < 0.f) break;  // sub_render_bdpt `break`s out of the pixel's sample loop (BDPT.hpp:690)
-		for (int k = 0; k < TUTU_BIDIR_MAX_OWN; k++) {
-			const float4 v = own_list[u * TUTU_BIDIR_MAX_OWN + k];
-			if (v.w != 0.f) {
-				ex = ex + v.x; ey = ey + v.y; ez = ez + v.z;
-			}
-		}
-	}
-	const uint32_t pix = pix0 + i;
-	ev_key[i] = ((unsigned long long)pix << 40) | (((unsigned long long)pix * (unsigned long long)spp + (unsigned long long)(spp - 1)) * 16ull + 15ull);
-	ev_val[i] = make_float4(ex * spp_inv, ey * spp_inv, ez * spp_inv, 1.f);
 }
 
 // The own-pixel part of a batch of whole pixels [pix0, pix0 + n_pix): estimate = the pixel's units' contributions added one

@@ -128,8 +128,7 @@ struct TutuCtx {
 	DevBuf<float> out_stage;
 	// the other integrators (device_bidir.h): per-unit results, frame-buffer events and their sorted order
 	struct Bidir {
-		DevBuf<float4> own, own_list, ev_val, umeta, umeta2;
-		DevBuf<float> vert;
+		DevBuf<float4> own, own_list, ev_val;
 		DevBuf<unsigned long long> ev_key, ev_key_sorted;
 		DevBuf<uint32_t> idx, idx_sorted, last_set;
 		DevBuf<uint8_t> sort_tmp;
@@ -770,7 +769,6 @@ int tutu_hip_destroy(TutuCtx* c) {
 	c->out_stage.release();
 	c->bd.own.release(); c->bd.own_list.release(); c->bd.ev_val.release(); c->bd.ev_key.release(); c->bd.ev_key_sorted.release();
 	c->bd.idx.release(); c->bd.idx_sorted.release(); c->bd.sort_tmp.release(); c->bd.frame.release(); c->bd.last_set.release();
-	c->bd.vert.release(); c->bd.umeta.release(); c->bd.umeta2.release();
 	if (c->bd.t0) (void)hipEventDestroy(c->bd.t0);
 	if (c->bd.t1) (void)hipEventDestroy(c->bd.t1);
 	if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -1003,9 +1001,6 @@ int bidir_params(TutuCtx* c, int type, const TutuCameraDesc* cam, int spp, uint3
 	p->smp_list = nullptr;
 	p->first_pix = 0;
 	p->own_list = nullptr;
-	p->vert = nullptr;
-	p->umeta = nullptr;
-	p->umeta2 = nullptr;
 	return TUTU_OK;
 }
 
@@ -1108,13 +1103,6 @@ int tutu_hip_render_integrator(TutuCtx* c, int32_t type, const TutuCameraDesc* c
 	TutuCtx::Bidir& b = c->bd;
 	if ((rc = b.own.ensure(max_units)) != TUTU_OK) return rc;
 	if (type == TUTU_INTEGRATOR_BDPT && (rc = b.own_list.ensure(max_units * TUTU_BIDIR_MAX_OWN)) != TUTU_OK) return rc;
-	// BDPT: walks and strategies in two kernels (device_bidir.h: k_bdpt_connect); TUTU_BDPT_UNIT_KERNEL = everything in one lane
-	const bool bdpt_split = type == TUTU_INTEGRATOR_BDPT && !getenv("TUTU_BDPT_UNIT_KERNEL");
-	if (bdpt_split) {
-		if ((rc = b.vert.ensure(max_units * (size_t)(TUTU_BD_VFIELDS * TUTU_BD_VERTS))) != TUTU_OK) return rc;
-		if ((rc = b.umeta.ensure(max_units)) != TUTU_OK) return rc;
-		if ((rc = b.umeta2.ensure(max_units)) != TUTU_OK) return rc;
-	}
 	if ((rc = b.ev_val.ensure(max_ev)) != TUTU_OK) return rc;
 	if ((rc = b.ev_key.ensure(max_ev)) != TUTU_OK) return rc;
 	if ((rc = b.ev_key_sorted.ensure(max_ev)) != TUTU_OK) return rc;
@@ -1143,24 +1131,9 @@ int tutu_hip_render_integrator(TutuCtx* c, int32_t type, const TutuCameraDesc* c
 		p.first_pix = pix0;
 		if (lt_wavefront) {
 			if ((rc = lt_wavefront_batch(c, s, p)) != TUTU_OK) return rc;
-		} else {
-			if (bdpt_split) {
-				p.vert = b.vert.p;
-				p.umeta = b.umeta.p;
-				p.umeta2 = b.umeta2.p;
-			}
-			if ((rc = bidir_launch(c, s, p)) != TUTU_OK) return rc;
-		}
+		} else if ((rc = bidir_launch(c, s, p)) != TUTU_OK) return rc;
 		size_t n_ev = (size_t)p.n_units * (size_t)p.ev_stride;
-		if (bdpt_split) {
-			const dim3 grid((p.n_units + 255) / 256, 35);
-			if (c->lds_scene) k_bdpt_connect<true><<<grid, dim3(256), c->trace_lds_bytes, s>>>(p);
-			else k_bdpt_connect<false><<<grid, dim3(256), c->trace_lds_bytes, s>>>(p);
-			hipLaunchKernelGGL(k_bidir_own_slots, dim3((np + 255) / 256), dim3(256), 0, s, b.own.p, p.own_list, spp, p.spp_inv, pix0, np, b.ev_key.p + n_ev,
-			                   b.ev_val.p + n_ev);
-			HIP_TRY(hipGetLastError());
-			n_ev += np;
-		} else if (type != TUTU_INTEGRATOR_LIGHT) {
+		if (type != TUTU_INTEGRATOR_LIGHT) {
 			hipLaunchKernelGGL(k_bidir_own, dim3((np + 255) / 256), dim3(256), 0, s, b.own.p, p.own_list, type, spp, p.spp_inv, pix0, np, b.ev_key.p + n_ev,
 			                   b.ev_val.p + n_ev);
 			n_ev += np;
