@@ -279,6 +279,9 @@ def main():
                     "measured_on": "one extra step with ONE pass in flight (kernels run one at a time)" if excl is not None else
                                    "the timed region (N > 1 or --no-extras: launches of several passes overlap, durations include shared time)",
                     "lds_scene": lds_scene,
+                    "launch_geometry_note": "the exclusive step runs every kernel with all the blocks that fit a CU; in the overlapped timed "
+                                            "region the one-class shade kernel is launched with ONE block per CU (knob shade_bpc = 0: it leaves "
+                                            "the CU's LDS to the traversal blocks of the other passes; 65 % slower alone, frame 3-4 % faster)",
                     "measured_per_ray": {"N_closest": n_c, "T_closest": t_c, "N_shadow": n_s, "T_shadow": t_s},
                     "traversal": {
                         "closest_Grays_per_s": src["k_trace_closest"]["units"] / max(src["k_trace_closest"]["ms"], 1e-9) / 1e6,

@@ -329,7 +329,7 @@ int tutu_hip_quantise(TutuCtx* ctx, uint32_t n, const float* values, int32_t* le
  *           launch's duration includes the time it shares the device with others.
  * The remaining knobs take their start values from TUTU_* environment variables ONCE, at tutu_hip_create, where a
  * value outside its range fails the create with TUTU_E_INVALID (it never reaches a kernel):
- *   "sets_default" TUTU_SETS [1,4] | "one_set" TUTU_ONE_SET {0,1} | "shade_bpc" TUTU_SHADE_BPC [1,16] |
+ *   "sets_default" TUTU_SETS [1,4] | "one_set" TUTU_ONE_SET {0,1} | "shade_bpc" TUTU_SHADE_BPC [0,16] (0 = one per CU for the one-class kernel while passes overlap, else all that fit) |
  *   "trace_bpc" TUTU_TRACE_BPC [0,8] (0 = from the LDS footprint) | "refill_min" TUTU_REFILL_MIN [1,64] |
  *   "inner_steps" TUTU_INNER_STEPS [1,64] | "any_near_first" TUTU_ANY_NEAR_FIRST {0,1} |
  *   "util_stats" TUTU_UTIL_STATS {0,1} | "bidir_units" TUTU_BIDIR_UNITS [64, 2^24] ((pixel, sample) units per batch of

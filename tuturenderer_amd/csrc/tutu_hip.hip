@@ -93,7 +93,7 @@ struct TutuCtx {
 	struct Knobs {
 		int sets = 4;             // TUTU_SETS           passes in flight                         [1, 4]
 		int one_set = 0;          // TUTU_ONE_SET        profiling aid: one work set              {0, 1}
-		int shade_bpc = 8;        // TUTU_SHADE_BPC      shade blocks per CU (persistent grid)    [1, 16]
+		int shade_bpc = 0;        // TUTU_SHADE_BPC      shade blocks per CU (persistent grid), 0 = by kernel  [0, 16]
 		int trace_bpc = 0;        // TUTU_TRACE_BPC      traversal blocks per CU, 0 = by LDS use  [0, 8]
 		int refill_min = 16;      // TUTU_REFILL_MIN     idle lanes before a wave refills         [1, 64]
 		int inner_steps = TUTU_INNER_STEPS;  // TUTU_INNER_STEPS node visits per round            [1, 64]
@@ -151,7 +151,7 @@ struct KnobDesc {
 const KnobDesc kKnobs[] = {
     {"sets_default", "TUTU_SETS", &TutuCtx::Knobs::sets, 1, TUTU_MAX_SETS},
     {"one_set", "TUTU_ONE_SET", &TutuCtx::Knobs::one_set, 0, 1},
-    {"shade_bpc", "TUTU_SHADE_BPC", &TutuCtx::Knobs::shade_bpc, 1, 16},
+    {"shade_bpc", "TUTU_SHADE_BPC", &TutuCtx::Knobs::shade_bpc, 0, 16},
     {"trace_bpc", "TUTU_TRACE_BPC", &TutuCtx::Knobs::trace_bpc, 0, 8},
     {"refill_min", "TUTU_REFILL_MIN", &TutuCtx::Knobs::refill_min, 1, 64},
     {"inner_steps", "TUTU_INNER_STEPS", &TutuCtx::Knobs::inner_steps, 1, 64},
@@ -347,7 +347,7 @@ int launch_shade(TutuCtx* c, hipStream_t s, int mode, dim3 grid, const PassParam
 // Stage d: shade(d) reads record set (d-1)&1 through stage d-1's list of continuing records and writes set d&1,
 // compacted per 64-record chunk; lists; trace_closest; trace_any.  The slots in use shrink with every stage.
 int run_pass(TutuCtx* c, WorkSet& w, hipStream_t s, const TutuCameraFrame* cam, uint32_t key0, uint32_t key1, int npix, int s0, int nsamp,
-             const uint32_t* d_smp_list, uint32_t* n_trace_launches) {
+             const uint32_t* d_smp_list, uint32_t* n_trace_launches, bool overlapped = false) {
 	const uint32_t blocks_x = (uint32_t)((npix + 255) / 256);
 	const size_t region0 = (size_t)blocks_x * 256u * (size_t)nsamp;  // slots stage 0 may write: one 64-slot chunk per wave
 	const uint32_t n_pad = (uint32_t)((region0 + TUTU_LIST_TILE - 1) / TUTU_LIST_TILE * TUTU_LIST_TILE);
@@ -371,7 +371,14 @@ int run_pass(TutuCtx* c, WorkSet& w, hipStream_t s, const TutuCameraFrame* cam, 
 	pp.n_mats = (int)c->hs.mats.size();
 
 	const size_t npaths = (size_t)npix * (size_t)nsamp;
-	const int shade_grid = persistent_grid(npaths, c->n_cu, c->knobs.shade_bpc);  // persistent blocks: the table staging is paid once per block
+	// persistent blocks: the table staging is paid once per block.  How many per CU: the one-class shade kernel is bound by
+	// memory and holds 43.5 KB of LDS per block -- three of them fill a CU and keep the traversal blocks of the other streams'
+	// passes (12 KB each, bound by vector issue) out.  When passes overlap, ONE shade block per CU (65 % slower if it ran
+	// alone) makes the frame 3-4 % faster (Cornell box: 2010 -> 2092 Msamples/s); a pass that runs by itself (one work set:
+	// profiling, the exclusive step of bench.py, small calls) has nobody to leave room for and takes all the blocks that fit.
+	// The generic kernel of mixed scenes is itself bound by vector issue and always does (veach room: -2 % with one).
+	const int shade_bpc = c->knobs.shade_bpc > 0 ? c->knobs.shade_bpc : ((overlapped && c->shade_mode_all != SHADE_ANY) ? 1 : 8);
+	const int shade_grid = persistent_grid(npaths, c->n_cu, shade_bpc);
 	const int trace_grid = persistent_grid(npaths, c->n_cu, c->knobs.trace_bpc > 0 ? std::min(c->knobs.trace_bpc, c->trace_blocks_per_cu) : c->trace_blocks_per_cu);
 	int rc = TUTU_OK;
 	for (int d = 0; d <= TUTU_MAX_DEPTH + 1; d++) {
@@ -575,7 +582,7 @@ int render_impl(TutuCtx* c, const TutuCameraFrame* cam, const TutuRenderParams* 
 		TutuCtx::WorkSet& w = c->ws[k];
 		hipStream_t sk = streams[k];
 		const int ns = std::min(spp_pass, rp->spp - s0);
-		if ((rc = run_pass(c, w, sk, cam, rp->key0, rp->key1, npix, s0, ns, nullptr, &trace_launches)) != TUTU_OK) return rc;
+		if ((rc = run_pass(c, w, sk, cam, rp->key0, rp->key1, npix, s0, ns, nullptr, &trace_launches, n_sets > 1)) != TUTU_OK) return rc;
 		// samples are added to the estimate in sample order (PathTracing.hpp:507-513): pass i resolves after pass i-1
 		if (i > 0 && n_sets > 1) HIP_TRY(hipStreamWaitEvent(sk, c->ws[(k + n_sets - 1) % n_sets].ev_resolved, 0));
 		{
