@@ -10,9 +10,12 @@ FETCH_SIZE reports half the bytes of wide (16 B/lane) coalesced reads, so it is 
 from the bench line of the same run (g2.log): extension rays for k_trace_closest and k_shade, shadow rays for k_trace_any.
 
 Also per kernel, from the SQ counters of the same collection (totals over the same dispatches, one counter group per pass):
-  valu_issue_frac   = 4 * SQ_INSTS_VALU / (GRBM_GUI_ACTIVE / 8 * 256 CUs * 4 SIMDs): the share of the SIMDs' issue cycles
-                      taken by vector instructions (a wave64 VALU instruction occupies its 16-lane SIMD for 4 cycles;
-                      GRBM_GUI_ACTIVE is summed over the 8 XCDs) -- the roofline of a kernel that does not touch memory;
+  valu_per_simd_cycle = SQ_INSTS_VALU / (GRBM_GUI_ACTIVE / 8 * 256 CUs * 4 SIMDs): vector wave-instructions issued per SIMD
+                      and shader cycle (GRBM_GUI_ACTIVE is summed over the 8 XCDs);
+  valu_issue_frac   = valu_per_simd_cycle / ISSUE_PEAK, where ISSUE_PEAK is MEASURED, not assumed: the rate of independent
+                      `v_add_f32` at 8 waves per SIMD from profiles/issuebench (profiles/issue_peak.json, written by
+                      issuebench_summary.py) -- the roofline of a kernel that does not touch memory.  Round 2 assumed 1/4
+                      (4 cycles per wave64 instruction); the guide states 1/2 for >= 2 waves per SIMD;
   valu_lanes_active = SQ_THREAD_CYCLES_VALU / (64 * SQ_ACTIVE_INST_VALU): lanes switched on in an average vector instruction;
   salu_per_valu     = SQ_INSTS_SALU / SQ_INSTS_VALU."""
 import csv
@@ -39,7 +42,14 @@ def stage(name):
 def main(root, tag, cfg):
     val = defaultdict(lambda: defaultdict(float))
     disp = defaultdict(lambda: defaultdict(set))
-    for f in glob.glob(f"{root}/g*/**/*counter_collection.csv", recursive=True):
+    files = glob.glob(f"{root}/g*/**/*counter_collection.csv", recursive=True)
+    per_group = defaultdict(list)
+    for f in files:
+        per_group[os.path.relpath(f, root).split(os.sep)[0]].append(f)
+    dup = {g: fs for g, fs in per_group.items() if len(fs) > 1}
+    if dup:  # round 2: two collections in one directory were summed and every byte count doubled
+        raise SystemExit(f"refusing: more than one counter_collection.csv in {sorted(dup)} -- collect into an empty directory (run_pmc.sh does)")
+    for f in files:
         for row in csv.DictReader(open(f)):
             st = stage(row["Kernel_Name"])
             if st and row["Counter_Name"] in ("FETCH_SIZE", "WRITE_SIZE", "SQ_INSTS_VALU", "GRBM_GUI_ACTIVE", "SQ_THREAD_CYCLES_VALU",
@@ -50,6 +60,13 @@ def main(root, tag, cfg):
     pk = line["roofline"]["per_kernel"]
     units = {k: pk[k]["units_per_launch"] * pk[k]["launches"] for k in pk}
     samples = line["value"] * 1e6 * line["ms_per_step"] * 1e-3 * line["steps"]
+    here = os.path.dirname(os.path.abspath(__file__))
+    issue_peak = None
+    try:
+        issue_peak = float(json.load(open(os.path.join(here, "issue_peak.json")))["valu_per_simd_cycle_peak"])
+    except (OSError, ValueError, KeyError):
+        pass
+    knobs = line["config"].get("knobs", {})
     kernels, total = {}, 0.0
     for st in val:
         fetch = 2.0 * val[st]["FETCH_SIZE"] * 1024.0
@@ -62,7 +79,9 @@ def main(root, tag, cfg):
             e["hbm_bytes_per_unit"] = (fetch + write) / units[st]
         v = val[st]
         if v.get("GRBM_GUI_ACTIVE") and v.get("SQ_INSTS_VALU"):
-            e["valu_issue_frac"] = 4.0 * v["SQ_INSTS_VALU"] / (v["GRBM_GUI_ACTIVE"] / 8.0 * 256 * 4)
+            e["valu_per_simd_cycle"] = v["SQ_INSTS_VALU"] / (v["GRBM_GUI_ACTIVE"] / 8.0 * 256 * 4)
+            if issue_peak:
+                e["valu_issue_frac"] = e["valu_per_simd_cycle"] / issue_peak
             e["salu_per_valu"] = v.get("SQ_INSTS_SALU", 0.0) / v["SQ_INSTS_VALU"]
         if v.get("SQ_ACTIVE_INST_VALU") and v.get("SQ_THREAD_CYCLES_VALU"):
             e["valu_lanes_active"] = v["SQ_THREAD_CYCLES_VALU"] / (64.0 * v["SQ_ACTIVE_INST_VALU"])
@@ -74,7 +93,16 @@ def main(root, tag, cfg):
             out = {}
     except (OSError, ValueError):
         out = {}
-    out[cfg] = {"tag": tag, "config": cfg, "spp": line["config"]["workload"], "spp_per_pass": line["config"]["spp_per_pass"],
+    # sanity: no kernel can move more than the HBM peak (8 TB/s) -- the check that would have caught the doubled collection
+    for st, e in kernels.items():
+        ms = pk.get(st, {}).get("avg_launch_ms")
+        if ms and e.get("hbm_bytes_per_unit") and pk[st].get("units_per_launch"):
+            tbs = e["hbm_bytes_per_unit"] * pk[st]["units_per_launch"] / (ms * 1e-3) / 1e12
+            e["implied_TB_per_s"] = tbs
+            if tbs > 8.0:
+                raise SystemExit(f"refusing: {st} would move {tbs:.1f} TB/s, above the HBM peak -- the collection is inconsistent")
+    out[cfg] = {"tag": tag, "config": cfg, "sets": knobs.get("sets_default"), "shade_bpc": knobs.get("shade_bpc"),
+                "issue_peak_valu_per_simd_cycle": issue_peak, "spp": line["config"]["workload"], "spp_per_pass": line["config"]["spp_per_pass"],
                 "samples": samples, "hbm_bytes_per_sample": total / samples, "kernels": kernels,
                 "note": "FETCH_SIZE x2 (gfx950 wide-read correction) + WRITE_SIZE, KiB -> bytes; per unit = / the run's own ray counts"}
     json.dump(out, open(path, "w"), indent=1, sort_keys=True)

@@ -18,7 +18,11 @@ def short(name):
 def main(root):
     agg = defaultdict(lambda: defaultdict(float))
     calls = defaultdict(lambda: defaultdict(set))
-    for f in glob.glob(f"{root}/g*/**/*counter_collection.csv", recursive=True):
+    files = glob.glob(f"{root}/g*/**/*counter_collection.csv", recursive=True)
+    groups = [f[len(root):].lstrip("/").split("/")[0] for f in files]
+    if len(groups) != len(set(groups)):
+        raise SystemExit("refusing: more than one counter_collection.csv per counter group -- collect into an empty directory")
+    for f in files:
         for row in csv.DictReader(open(f)):
             k = short(row["Kernel_Name"])
             if not k:

@@ -9,7 +9,13 @@ SPP=${3:-76}
 SPASS=${4:-19}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/pmc_${TAG}_${CFG}
+# start from an EMPTY directory: a second collection into the same directory used to leave two runs' CSVs side by side
+# and make_traffic.py summed them (round 2: every byte count doubled)
+rm -rf $OUT
 mkdir -p $OUT
+# Launch geometry of the collection = the EXCLUSIVE step of bench.py (one pass in flight, every kernel with all the
+# blocks that fit): that is the step whose per-kernel times the SQ counters are multiplied with (pipeline.valu).
+export TUTU_SETS=${TUTU_SETS:-1}
 export TMPDIR=/tmp
 cd /tmp
 i=0

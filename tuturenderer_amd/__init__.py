@@ -301,7 +301,8 @@ class Context:
         _check(self.lib.tutu_hip_set_option(self.h, C.c_char_p(name.encode()), C.c_int(int(value))), "tutu_hip_set_option")
 
     OPTION_NAMES = ("sets", "sets_default", "one_set", "shade_bpc", "trace_bpc", "refill_min", "inner_steps", "any_near_first",
-                    "util_stats", "bidir_units", "sah_tree", "n_refs", "lds_scene", "shade_tab")
+                    "util_stats", "bidir_units", "sah_tree", "n_refs", "lds_scene", "shade_tab", "fast_depth", "stack_entries",
+                    "trace_blocks_per_cu", "trace_lds_bytes")
 
     def get_option(self, name):
         v = C.c_int(0)
@@ -310,7 +311,13 @@ class Context:
 
     def options(self):
         """effective value of every knob (what a benchmark line should echo)"""
-        return {k: self.get_option(k) for k in self.OPTION_NAMES}
+        out = {}
+        for k in self.OPTION_NAMES:
+            try:
+                out[k] = self.get_option(k)
+            except TutuError:  # an older build loaded through TUTU_HIP_LIB (same-box A/B runs, profiles/ab.sh)
+                out[k] = None
+        return out
 
     def info(self):
         b = BvhInfo()

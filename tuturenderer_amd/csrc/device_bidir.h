@@ -762,6 +762,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))
 	else {
 		sg.nodes = p.sc.nodes;
 		sg.tris = p.sc.tri_isect;
+		sg.lboxes = p.sc.leaf_boxes;
 	}
 	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
 	if (i >= p.n_units) return;

@@ -732,14 +732,29 @@ __global__ void __launch_bounds__(256) k_shade(PassParams pp) {
 //
 // Every wave owns a contiguous range of the work list.  A lane keeps one ray in flight; the wave alternates
 //   refill  -- idle lanes (found with __ballot, ranked with __popcll) take the next rays of the wave's range,
-//   inner   -- up to TUTU_INNER_STEPS node visits for the lanes that sit on an inner node,
-//   leaf    -- one triangle test for the lanes that sit on a leaf,
+//   inner   -- up to `inner_steps` node visits for the lanes that sit on an inner node,
+//   leaf    -- one triangle test for the lanes that hold a parked leaf,
 //   finish  -- lanes whose traversal ended write their result and become idle,
 // so a lane whose ray ends early is given new work instead of waiting for the slowest ray of its wave (the plain
 // one-ray-per-lane loop ran with ~26 % of its lanes active on the Cornell box).  The loop ends when the range is
 // exhausted and every lane is idle: an exit condition every wave reaches.
+//
+// Round 3: the node step is straight-line code.  (Round 2's nested if / else chain was compiled into six-deep
+// structurised regions: ~250 exec-mask scalars and ~100 v_mov around ~500 vector instructions.)
+//   * Only PLAIN rays (device_trace.h) enter the loop; they walk the SAH tree with slab_plain (min / max form, 11
+//     half-rate + 12 full-rate vector instructions per box instead of ~16 + 12).  A ray with a zero / non-finite component
+//     -- for which the reference's answer depends on every box IT tests -- is set aside at refill (its list position goes
+//     to the wave's part of `defer`) and traced after the main loop by the reference-shaped loops of device_trace.h on
+//     the reference's own tree: rare (axis-parallel directions), and kept out of the main loop's register budget.
+//   * The per-lane stack has a sentinel entry (TUTU_TRAV_DONE) at its bottom: popping never tests for "empty", and
+//     the top entry can be requested at the START of the step, together with the node, whatever the outcome.
+//     Push = an unconditional store of the far child at the top slot (sp moves only if both children are hit).
+//     All decisions (near / far, one / both / none, park the leaf, pop) are selects on those values.
+//   * The closest-hit pruning limit lives in a register and changes only when a hit is accepted.
+//   * The reference's leaf boxes (candidate validation) and the class table are part of the LDS scene copy.
 #define TUTU_INNER_STEPS 4
 #define TUTU_TRAV_IDLE (INT_MIN + 1)
+#define TUTU_STACK_SENTINELS 1
 
 struct TraceParams {
 	SceneDev sc;
@@ -750,7 +765,7 @@ struct TraceParams {
 	uint8_t* hitK;          // closest-hit: material class of the hit, per list position
 	float4* F;              // any-hit: final radiance per home slot (TUTU_KEY_FINAL requests)
 	const uint8_t* tri_class;  // per triangle (leaf order): class of its material
-	int stack_entries;
+	int stack_entries;      // per-lane LDS stack entries, sentinels included
 	// work counters, per block: [block][0] nodes entered, [1] leaf tests (SURVEY.md 8(d)'s N and T, measured on the tree
 	// that is actually walked), [2] / [3] wave-level inner-node / leaf steps.  Plain read-modify-write by one thread per
 	// block and counter; each work set has its own array.
@@ -758,7 +773,11 @@ struct TraceParams {
 	int refill_min;  // idle lanes a wave waits for before it fetches new rays (1 = refill at once)
 	int inner_steps;  // node visits between two leaf / finish / refill rounds
 	int any_near_first;  // any-hit: descend into the nearer child first
+	uint32_t* defer;     // >= *n_ptr entries: list positions of the rays that are not plain, per wave range (below)
 };
+
+// leaf references are negative and above the two markers: (unsigned)ref > 0x80000001
+TUTU_DEV bool ref_is_leaf(int ref) { return (uint32_t)ref > (uint32_t)TUTU_TRAV_IDLE; }
 
 template <typename S, bool ANY, bool SPH>
 TUTU_DEV void trace_persistent(const S& ss, const TraceParams& tp, int* stack, const uint8_t* tri_class) {
@@ -771,17 +790,21 @@ TUTU_DEV void trace_persistent(const S& ss, const TraceParams& tp, int* stack, c
 	const uint32_t per = (n + n_waves - 1) / n_waves;
 	const uint32_t begin = min(n, wave * per), end = min(n, begin + per);
 	uint32_t next = begin;
+	const float inf = __builtin_inff();
+
+	stack[0] = TUTU_TRAV_DONE;  // the sentinel: a pop below the lane's first entry ends the walk
+	int* top = stack + TUTU_STACK_SENTINELS * 256;  // next free entry of this lane
 
 	int cur = TUTU_TRAV_IDLE;
 	int pend = TUTU_TRAV_IDLE;  // parked leaf (TUTU_TRAV_IDLE = none)
-	int sp = 0;
 	uint32_t slot = 0;  // closest-hit: the ray's list position (where its hit goes); any-hit: the request's record slot
 	RayPre r = make_ray(mk1(0.f), mk1(1.f));
 	float best_t = FLT_MAX, best_u = 0.f, best_v = 0.f;
 	int best_tri = -1;
-	bool validate = false;  // this lane walks the SAH tree: candidates are checked against the reference's leaf box
+	float lim = FLT_MAX;  // pruning limit: closest-hit best_t * slack (FLT_MAX before the first hit); any-hit dis * slack
 	uint32_t n_nodes = 0, n_leaves = 0;  // work counters of this lane
 	uint32_t w_node_steps = 0, w_leaf_steps = 0;  // wave-uniform: how often each phase ran
+	uint32_t n_def = 0;  // wave-uniform: rays set aside for the exact walk
 	// any-hit only
 	float dis = 0.f;
 	float4 Lpre = make_float4(0.f, 0.f, 0.f, 0.f);  // TUTU_KEY_FINAL requests: the path's radiance | home slot and the
@@ -794,13 +817,17 @@ TUTU_DEV void trace_persistent(const S& ss, const TraceParams& tp, int* stack, c
 		const unsigned long long idle = __ballot(cur == TUTU_TRAV_IDLE);
 		if (idle != 0ull && next < end && (__popcll(idle) >= tp.refill_min || __ballot(cur != TUTU_TRAV_IDLE && cur != TUTU_TRAV_DONE) == 0ull)) {
 			const uint32_t i = next + (uint32_t)__popcll(idle & lt_mask);
+			bool exact = false;
 			if (cur == TUTU_TRAV_IDLE && i < end) {
 				slot = tp.list[i];
+				V3 so, lo = mk1(0.f);
 				if (!ANY) {
 					const float4 A = tp.rec.A[slot], B = tp.rec.B[slot];
 					slot = i;
-					r = make_ray(mk(A.x, A.y, A.z), mk(B.x, B.y, B.z));
+					so = mk(A.x, A.y, A.z);
+					r = make_ray(so, mk(B.x, B.y, B.z));
 					best_t = FLT_MAX; best_u = 0.f; best_v = 0.f; best_tri = -1;
+					lim = FLT_MAX;
 				} else {
 					fl = tp.rec.key[slot];
 					const float4 e0 = (fl & TUTU_KEY_ALT) ? tp.rec.S2[slot] : tp.rec.A[slot];
@@ -810,20 +837,35 @@ TUTU_DEV void trace_persistent(const S& ss, const TraceParams& tp, int* stack, c
 						const float4 e2 = tp.rec.P[slot];
 						contrib = mk(e2.x, e2.y, e2.z);
 					}
-					const V3 so = mk(e0.x, e0.y, e0.z), lo = mk(e1.x, e1.y, e1.z);
+					so = mk(e0.x, e0.y, e0.z);
+					lo = mk(e1.x, e1.y, e1.z);
 					// isShadowRayBlocked, IIntegrator.hpp:135-137
 					const V3 raydir = normalized(lo - so);
 					dis = norm(lo - so);
 					r = make_ray(so, raydir);
+					lim = dis * TUTU_PRUNE_SLACK;
 					blocked = false;
 				}
-				sp = 0;
-				float te;
-				validate = sc.has_fast && ray_is_plain(r);
-				if (sc.root_ref == INT_MIN ||
-				    !slab(r, sc.root_min[0], sc.root_min[1], sc.root_min[2], sc.root_max[0], sc.root_max[1], sc.root_max[2], te))
-					cur = TUTU_TRAV_DONE;
-				else cur = validate ? sc.root_ref : sc.root_ref_exact;
+				top = stack + TUTU_STACK_SENTINELS * 256;
+				pend = TUTU_TRAV_IDLE;
+				cur = TUTU_TRAV_DONE;
+				if (sc.root_ref != INT_MIN) {
+					if (!ray_is_plain(r)) {
+						exact = true;  // the reference's own tree with the reference's own slab: after the main loop
+						cur = TUTU_TRAV_IDLE;
+					} else {
+						float te;
+						if (slab_plain(r, sc.root_min[0], sc.root_min[1], sc.root_min[2], sc.root_max[0], sc.root_max[1], sc.root_max[2], inf, te)) {
+							if (sc.root_ref >= 0) cur = sc.root_ref;
+							else pend = sc.root_ref;  // a scene of one object: the root is a leaf
+						}
+					}
+				}
+			}
+			const unsigned long long em = __ballot(exact);
+			if (em != 0ull) {
+				if (exact) tp.defer[begin + n_def + (uint32_t)__popcll(em & lt_mask)] = i;
+				n_def += (uint32_t)__popcll(em);
 			}
 			next += (uint32_t)__popcll(idle);
 		}
@@ -837,67 +879,61 @@ TUTU_DEV void trace_persistent(const S& ss, const TraceParams& tp, int* stack, c
 			w_node_steps++;
 			if (cur >= 0) {
 				n_nodes++;
-				float lim;
-				if (ANY) lim = dis * TUTU_PRUNE_SLACK;
-				else lim = best_tri >= 0 ? best_t * TUTU_PRUNE_SLACK : FLT_MAX;
-				const ChildTest ct = test_children(ss, cur, r, lim);
-				if (ct.hl && ct.hr) {
-					const bool right_first = (!ANY || tp.any_near_first) && ct.tr < ct.tl;
-					stack[sp * 256] = right_first ? ct.left : ct.right;
-					sp++;
-					cur = right_first ? ct.right : ct.left;
-				} else if (ct.hl) {
-					cur = ct.left;
-				} else if (ct.hr) {
-					cur = ct.right;
-				} else if (sp == 0) {
-					cur = TUTU_TRAV_DONE;
-				} else {
-					sp--;
-					cur = stack[sp * 256];
-				}
-				if (cur < 0 && cur > TUTU_TRAV_IDLE && pend == TUTU_TRAV_IDLE) {  // park the leaf, go on
-					pend = cur;
-					if (sp == 0) cur = TUTU_TRAV_DONE;
-					else {
-						sp--;
-						cur = stack[sp * 256];
-					}
-				}
+				const int p1 = top[-256];  // the top entry, requested with the node
+				float4 a, b, c, e;
+				ss.node(cur, a, b, c, e);
+				float tl, tr;
+				const bool hl = slab_plain(r, a.x, a.y, a.z, a.w, b.x, b.y, lim, tl);
+				const bool hr = slab_plain(r, b.z, b.w, c.x, c.y, c.z, c.w, lim, tr);
+				const int left = __float_as_int(e.x), right = __float_as_int(e.y);
+				const bool right_first = (!ANY || tp.any_near_first) && tr < tl;
+				const bool take_left = hl && !(hr && right_first);
+				const int first = take_left ? left : right;   // the child to enter if any is hit
+				const int other = take_left ? right : left;   // the child to postpone if both are hit
+				const bool both = hl && hr, none = !(hl || hr);
+				*top = other;  // a push only if `both` (else the slot stays free: the store is harmless)
+				// what the lane moves to: a child, or the top entry of its stack.  A child that is a leaf is parked and the
+				// walk goes on with the entry below it: the far child just pushed, or the top entry.  (A POPPED leaf is not
+				// parked: the entry below it is not at hand; the lane sits on it until the leaf step.)
+				const int below = both ? other : p1;
+				const bool park = !none && ref_is_leaf(first) && pend == TUTU_TRAV_IDLE;
+				pend = park ? first : pend;
+				cur = none ? p1 : (park ? below : first);
+				// both: +1 (push), minus the pop when the near child is parked; one: that pop; none: the pop
+				top += both ? (park ? 0 : 256) : ((none || park) ? -256 : 0);
 			}
 		}
 
 		// ---- leaf: the parked leaf, or the leaf the lane sits on
 		{
 			const bool has_pend = pend != TUTU_TRAV_IDLE;
-			const bool on_leaf = cur < 0 && cur > TUTU_TRAV_IDLE;
+			const bool on_leaf = ref_is_leaf(cur);
 			if (__ballot(has_pend || on_leaf) != 0ull) w_leaf_steps++;
 			if (has_pend || on_leaf) {
 				n_leaves++;
+				const int p1 = top[-256];
 				int ti;
 				float t, u, v;
 				const bool h = leaf_test<SPH>(ss, has_pend ? ~pend : ~cur, r, ti, t, u, v);
-				if (ANY) {
-					if (h && t < dis && !float_equal(t, dis) && (!validate || leaf_box_hit(sc, ti, r))) blocked = true;  // BVH.hpp:186
-				} else if (h && (t < best_t || (t == best_t && ti < best_tri)) && (!validate || leaf_box_hit(sc, ti, r))) {
-					best_t = t; best_u = u; best_v = v; best_tri = ti;
-				}
-				if (has_pend) {
-					pend = TUTU_TRAV_IDLE;
-					if (on_leaf) {  // the second leaf reached meanwhile moves into the parking slot
-						pend = cur;
-						if (sp == 0) cur = TUTU_TRAV_DONE;
+				bool cand;
+				if (ANY) cand = h && t < dis && !float_equal(t, dis);  // BVH.hpp:186
+				else cand = h && (t < best_t || (t == best_t && ti < best_tri));
+				if (cand) {  // validated against the reference's leaf box (BVH.hpp:150; device_trace.h)
+					float4 lo, hi;
+					ss.lbox(ti, lo, hi);
+					float te;
+					if (slab_plain(r, lo.x, lo.y, lo.z, hi.x, hi.y, hi.z, inf, te)) {
+						if (ANY) blocked = true;
 						else {
-							sp--;
-							cur = stack[sp * 256];
+							best_t = t; best_u = u; best_v = v; best_tri = ti;
+							lim = t * TUTU_PRUNE_SLACK;
 						}
 					}
-				} else if (sp == 0) {
-					cur = TUTU_TRAV_DONE;
-				} else {
-					sp--;
-					cur = stack[sp * 256];
 				}
+				// the leaf the lane sits on was either tested (nothing was parked) or moves into the parking slot
+				pend = (has_pend && on_leaf) ? cur : TUTU_TRAV_IDLE;
+				cur = on_leaf ? p1 : cur;
+				top -= on_leaf ? 256 : 0;
 				if (ANY && blocked) {
 					cur = TUTU_TRAV_DONE;
 					pend = TUTU_TRAV_IDLE;
@@ -921,6 +957,39 @@ TUTU_DEV void trace_persistent(const S& ss, const TraceParams& tp, int* stack, c
 				tp.rec.V[slot] = (uint8_t)((fl & TUTU_KEY_KILL) ? TUTU_V_KILLED : TUTU_V_ADD);
 			}
 			cur = TUTU_TRAV_IDLE;
+		}
+	}
+	// ---- the rays that are not plain: the reference's tree, the reference's slab, one ray per lane (device_trace.h)
+	if (n_def != 0u) {
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // the list positions were written by other lanes of this wave
+		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+		int* xstack = stack + TUTU_STACK_SENTINELS * 256;
+		for (uint32_t j = (uint32_t)lane; j < n_def; j += 64u) {
+			const uint32_t i = tp.defer[begin + j];
+			const uint32_t s = tp.list[i];
+			if (!ANY) {
+				const float4 A = tp.rec.A[s], B = tp.rec.B[s];
+				float t, u, v;
+				int tri;
+				trace_closest(ss, sc, mk(A.x, A.y, A.z), mk(B.x, B.y, B.z), xstack, 256, t, u, v, tri);
+				tp.hitC[i] = make_float4(t, u, v, __int_as_float(tri));
+				tp.hitK[i] = tri >= 0 ? tri_class[tri] : (uint8_t)TUTU_CLASS_MISS;
+			} else {
+				const uint32_t f = tp.rec.key[s];
+				const float4 e0 = (f & TUTU_KEY_ALT) ? tp.rec.S2[s] : tp.rec.A[s];
+				const float4 e1 = tp.rec.S[s];
+				const bool blk = trace_any(ss, sc, mk(e0.x, e0.y, e0.z), mk(e1.x, e1.y, e1.z), xstack, 256);
+				if (f & TUTU_KEY_FINAL) {
+					const float4 Lp = tp.rec.L[s], e2 = tp.rec.P[s];
+					float4 F = make_float4(Lp.x, Lp.y, Lp.z, 0.f);
+					if (!blk) {
+						F.x = F.x + e2.x; F.y = F.y + e2.y; F.z = F.z + e2.z;
+					}
+					tp.F[__float_as_uint(Lp.w)] = F;
+				} else if (!blk) {
+					tp.rec.V[s] = (uint8_t)((f & TUTU_KEY_KILL) ? TUTU_V_KILLED : TUTU_V_ADD);
+				}
+			}
 		}
 	}
 	// work counters: wave sum, then one plain add per block into this block's own slots (no global atomics: a counter word
@@ -949,11 +1018,11 @@ TUTU_DEV void trace_persistent(const S& ss, const TraceParams& tp, int* stack, c
 // LDS carve-up with the per-triangle class table appended to the staged scene
 // SPH: the scene has sphere leaves (the triangle-only instantiations do not contain the sphere test)
 template <bool LDS_SCENE, bool ANY, bool SPH>
-__global__ void __launch_bounds__(256) k_trace(TraceParams tp) {
+__global__ void __launch_bounds__(256, 8) k_trace(TraceParams tp) {
 	extern __shared__ int lds[];  // [stack entries][256 lanes] | optional scene copy | optional class table
 	if (LDS_SCENE) {
 		const SceneLds sl = stage_scene_lds(tp.sc, lds, tp.stack_entries);
-		uint8_t* cls = reinterpret_cast<uint8_t*>(const_cast<float4*>(sl.tris + 3 * tp.sc.n_tris));
+		uint8_t* cls = reinterpret_cast<uint8_t*>(sl.end());
 		if (!ANY) {
 			for (int i = threadIdx.x; i < tp.sc.n_tris; i += blockDim.x) cls[i] = tp.tri_class[i];
 			__syncthreads();
@@ -963,6 +1032,7 @@ __global__ void __launch_bounds__(256) k_trace(TraceParams tp) {
 		SceneGlobal sg;
 		sg.nodes = tp.sc.nodes;
 		sg.tris = tp.sc.tri_isect;
+		sg.lboxes = tp.sc.leaf_boxes;
 		trace_persistent<SceneGlobal, ANY, SPH>(sg, tp, lds + threadIdx.x, tp.tri_class);
 	}
 }
@@ -991,6 +1061,7 @@ __global__ void __launch_bounds__(256) k_primary(PrimaryParams p) {
 	else {
 		sg.nodes = p.sc.nodes;
 		sg.tris = p.sc.tri_isect;
+		sg.lboxes = p.sc.leaf_boxes;
 	}
 	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
 	if (i < (uint32_t)p.n) {

@@ -61,17 +61,22 @@ struct SceneDev {
 struct SceneGlobal {
 	const float4* nodes;
 	const float4* tris;
+	const float4* lboxes;  // the reference's leaf boxes, 2 x float4 per object
 	TUTU_DEV void node(int i, float4& a, float4& b, float4& c, float4& e) const {
 		a = nodes[4 * i + 0]; b = nodes[4 * i + 1]; c = nodes[4 * i + 2]; e = nodes[4 * i + 3];
 	}
 	TUTU_DEV void tri(int i, float4& q0, float4& q1, float4& q2) const {
 		q0 = tris[3 * i + 0]; q1 = tris[3 * i + 1]; q2 = tris[3 * i + 2];
 	}
+	TUTU_DEV void lbox(int i, float4& lo, float4& hi) const {
+		lo = lboxes[2 * i]; hi = lboxes[2 * i + 1];
+	}
 };
 
 struct SceneLds {
 	const float4* nodes;  // [4][nn]
 	const float4* tris;   // [3][nt]
+	const float4* lboxes; // [2][nt]
 	int nn, nt;
 	TUTU_DEV void node(int i, float4& a, float4& b, float4& c, float4& e) const {
 		a = nodes[i]; b = nodes[nn + i]; c = nodes[2 * nn + i]; e = nodes[3 * nn + i];
@@ -79,7 +84,13 @@ struct SceneLds {
 	TUTU_DEV void tri(int i, float4& q0, float4& q1, float4& q2) const {
 		q0 = tris[i]; q1 = tris[nt + i]; q2 = tris[2 * nt + i];
 	}
+	TUTU_DEV void lbox(int i, float4& lo, float4& hi) const {
+		lo = lboxes[i]; hi = lboxes[nt + i];
+	}
+	TUTU_DEV float4* end() const { return const_cast<float4*>(lboxes + 2 * nt); }  // first float4 behind the scene copy
 };
+// bytes of the scene copy (host side: sizes the dynamic LDS): nodes 64 B, intersection records 48 B, leaf boxes 32 B
+#define TUTU_LDS_SCENE_BYTES(n_inner, n_tris) ((size_t)(n_inner) * 64 + (size_t)(n_tris) * (48 + 32))
 
 // LDS carve-up of the traversal kernels: [stack ints: stack_entries x blockDim][scene copy, 16-B aligned]
 TUTU_DEV SceneLds stage_scene_lds(const SceneDev& sc, int* lds_base, int stack_entries) {
@@ -89,9 +100,12 @@ TUTU_DEV SceneLds stage_scene_lds(const SceneDev& sc, int* lds_base, int stack_e
 	s.nt = sc.n_tris;
 	s.nodes = dst;
 	s.tris = dst + 4 * sc.n_inner;
+	s.lboxes = dst + 4 * sc.n_inner + 3 * sc.n_tris;
 	for (int idx = threadIdx.x; idx < 4 * sc.n_inner; idx += blockDim.x) dst[(idx & 3) * sc.n_inner + (idx >> 2)] = sc.nodes[idx];
 	float4* td = dst + 4 * sc.n_inner;
 	for (int idx = threadIdx.x; idx < 3 * sc.n_tris; idx += blockDim.x) td[(idx % 3) * sc.n_tris + (idx / 3)] = sc.tri_isect[idx];
+	float4* bd = td + 3 * sc.n_tris;
+	for (int idx = threadIdx.x; idx < 2 * sc.n_tris; idx += blockDim.x) bd[(idx & 1) * sc.n_tris + (idx >> 1)] = sc.leaf_boxes[idx];
 	__syncthreads();
 	return s;
 }
@@ -142,6 +156,29 @@ TUTU_DEV bool leaf_box_hit(const SceneDev& sc, int leaf, const RayPre& r) {
 	const float4 lo = sc.leaf_boxes[2 * leaf], hi = sc.leaf_boxes[2 * leaf + 1];
 	float te;
 	return slab(r, lo.x, lo.y, lo.z, hi.x, hi.y, hi.z, te);
+}
+
+// ---- the slab test of the WALKED tree, for plain rays only.
+// For a plain ray no slab product is a NaN, and (min - o) * inv, (max - o) * inv are ordered by the sign of inv (rounded
+// subtraction and multiplication are monotone), so the reference's swap-by-sign + `?:` chain (BoundBox.hpp:63-90) selects
+// exactly min / max of the two products: t_enter = max3(min..), t_exit = min3(max..) are the reference's values (up to the
+// sign of a zero, which no comparison sees).  Written with the raw instructions: fminf / fmaxf would add a canonicalising
+// `v_max x, x` per operand in IEEE mode.  On MI355X v_min / v_max / v_min3 / v_max3 / v_cndmask / v_cmp issue at half the
+// rate of v_sub / v_mul (profiles/issue_peak.json), so the swap (6 selects) + chain (4 compares + 4 selects) of slab()
+// is the expensive half of a box test; this form needs 6 min/max + 2 three-input ones.
+TUTU_DEV float raw_min(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+TUTU_DEV float raw_max(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+TUTU_DEV float raw_min3(float a, float b, float c) { float r; asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+TUTU_DEV float raw_max3(float a, float b, float c) { float r; asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+// accept iff t_enter <= t_exit && t_exit >= 0 (BoundBox.hpp:91) && t_enter <= lim (pruning; lim >= 0)
+//        iff max(t_enter, 0) <= min(t_exit, lim).   te = max(t_enter, 0): the entry distance the children are ordered by.
+TUTU_DEV bool slab_plain(const RayPre& r, float minx, float miny, float minz, float maxx, float maxy, float maxz, float lim, float& te) {
+	const float ax = (minx - r.o.x) * r.inv.x, bx = (maxx - r.o.x) * r.inv.x;
+	const float ay = (miny - r.o.y) * r.inv.y, by = (maxy - r.o.y) * r.inv.y;
+	const float az = (minz - r.o.z) * r.inv.z, bz = (maxz - r.o.z) * r.inv.z;
+	te = raw_max3(raw_min(ax, bx), raw_min(ay, by), raw_max(raw_min(az, bz), 0.f));
+	const float tx = raw_min3(raw_max(ax, bx), raw_max(ay, by), raw_min(raw_max(az, bz), lim));
+	return te <= tx;
 }
 
 // Triangle::intersect, Triangle.hpp:23-59 (E1, E2 and the normalised normal are hoisted to the host)

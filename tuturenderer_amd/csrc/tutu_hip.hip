@@ -115,6 +115,7 @@ struct TutuCtx {
 		DevBuf<float4> F;          // per home slot: finished radiance
 		DevBuf<uint32_t> lists;    // [2][cap]: continuing records, records with a shadow request
 		DevBuf<uint32_t> tile_counts, tile_offsets;
+		DevBuf<uint32_t> defer;    // traversal kernels: list positions of the rays set aside for the exact walk (device_shade.h)
 		DevBuf<uint32_t> list_meta;   // per depth: list counts [2]
 		DevBuf<unsigned long long> part;  // [2 kinds][TUTU_PART_BLOCKS][2] traversal work counters
 		hipEvent_t ev_resolved = nullptr;
@@ -220,6 +221,7 @@ int ensure_set(WorkSet& w, size_t want_slots) {
 		if ((rc = w.hitK.ensure(cap)) != TUTU_OK) return rc;
 		if ((rc = w.F.ensure(cap)) != TUTU_OK) return rc;
 		if ((rc = w.lists.ensure(2 * cap)) != TUTU_OK) return rc;
+		if ((rc = w.defer.ensure(cap)) != TUTU_OK) return rc;
 		if ((rc = w.tile_counts.ensure(2 * (cap / TUTU_LIST_TILE))) != TUTU_OK) return rc;
 		if ((rc = w.tile_offsets.ensure(2 * (cap / TUTU_LIST_TILE))) != TUTU_OK) return rc;
 		w.cap = cap;
@@ -415,6 +417,7 @@ int run_pass(TutuCtx* c, WorkSet& w, hipStream_t s, const TutuCameraFrame* cam, 
 		tp.inner_steps = c->knobs.inner_steps;
 		tp.any_near_first = c->knobs.any_near_first;
 		tp.part = w.part.p;
+		tp.defer = w.defer.p;
 		TIMED(EV_TRACE_CLOSEST, launch_trace<false>(c, s, trace_grid, tp));
 		(*n_trace_launches)++;
 		tp.list = w.lists.p + w.cap;
@@ -735,9 +738,11 @@ int tutu_hip_create(const TutuSceneDesc* scene, int device, TutuCtx** out) {
 	}
 	// per-lane traversal stack: at most one push per inner node on a root-to-leaf path.  When nodes + triangles are
 	// small enough, every block also keeps a copy of them in LDS (160 KB per CU).
-	c->stack_entries = (int)c->hs.depth + 1;
+	// A leaf at depth D has D inner ancestors, each with at most one entry outstanding: D entries, + the sentinel entry at
+	// the bottom of the persistent kernels' stacks (device_shade.h).
+	c->stack_entries = (int)c->hs.depth + TUTU_STACK_SENTINELS;
 	const size_t stack_bytes = (size_t)c->stack_entries * 256 * sizeof(int);
-	const size_t scene_bytes = c->hs.nodes.size() * sizeof(GpuNode) + c->hs.tri_isect.size() * sizeof(GpuTriIsect) +
+	const size_t scene_bytes = TUTU_LDS_SCENE_BYTES(c->hs.nodes.size(), c->hs.tri_isect.size()) +
 	                           ((c->hs.tri_class.size() + 15) / 16) * 16;  // + class table
 	c->lds_scene = scene_bytes > 0 && scene_bytes <= 24 * 1024;
 	c->trace_lds_bytes = (unsigned)(stack_bytes + (c->lds_scene ? scene_bytes : 0));
@@ -766,7 +771,7 @@ int tutu_hip_destroy(TutuCtx* c) {
 			w.verdict[k2].release();
 		}
 		w.hitC.release(); w.hitK.release(); w.F.release(); w.lists.release(); w.tile_counts.release(); w.tile_offsets.release();
-		w.list_meta.release(); w.part.release();
+		w.list_meta.release(); w.part.release(); w.defer.release();
 		if (w.ev_resolved) (void)hipEventDestroy(w.ev_resolved);
 	}
 	if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
@@ -816,6 +821,22 @@ int tutu_hip_get_option(TutuCtx* c, const char* name, int* value) {
 	}
 	if (strcmp(name, "lds_scene") == 0) {
 		*value = c->lds_scene ? 1 : 0;
+		return TUTU_OK;
+	}
+	if (strcmp(name, "fast_depth") == 0) {  // depth of the walked (SAH) tree; the reference tree's is TutuBvhInfo::depth
+		*value = (int)c->hs.fast_depth;
+		return TUTU_OK;
+	}
+	if (strcmp(name, "stack_entries") == 0) {
+		*value = c->stack_entries;
+		return TUTU_OK;
+	}
+	if (strcmp(name, "trace_blocks_per_cu") == 0) {
+		*value = c->trace_blocks_per_cu;
+		return TUTU_OK;
+	}
+	if (strcmp(name, "trace_lds_bytes") == 0) {
+		*value = (int)c->trace_lds_bytes;
 		return TUTU_OK;
 	}
 	if (strcmp(name, "shade_tab") == 0) {
@@ -1060,6 +1081,7 @@ int lt_wavefront_batch(TutuCtx* c, hipStream_t s, BidirParams p) {
 	tp.inner_steps = c->knobs.inner_steps;
 	tp.any_near_first = c->knobs.any_near_first;
 	tp.part = nullptr;
+	tp.defer = w.defer.p;
 	const int grid = persistent_grid(p.n_units, c->n_cu, c->trace_blocks_per_cu);
 	launch_trace<false>(c, s, grid, tp);
 	tp.list = w.lists.p + w.cap;
@@ -1335,6 +1357,7 @@ __global__ void k_test_fn(FnArgs a) {
 	case TUTU_FN_TRI: {  // Triangle::intersect on a GpuTriIsect record (in[0], 12 floats) + vertex normals (in[1], 9 floats), o, d
 		SceneGlobal sg;
 		sg.nodes = nullptr;
+		sg.lboxes = nullptr;
 		sg.tris = reinterpret_cast<const float4*>(a.in[0]);
 		const RayPre r = make_ray(ld3(a.in[2] + i3), ld3(a.in[3] + i3));
 		float t = 0.f, u = 0.f, v = 0.f;
@@ -1459,6 +1482,7 @@ static int run_trace_kernel(TutuCtx* c, uint32_t n, bool any) {
 	tp.tri_class = c->d_tri_class.p;
 	tp.stack_entries = c->stack_entries;
 	tp.part = nullptr;
+	tp.defer = w.defer.p;
 	tp.refill_min = 1;
 	tp.inner_steps = TUTU_INNER_STEPS;
 	tp.any_near_first = 1;
