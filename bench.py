@@ -127,7 +127,9 @@ def main():
     ap.add_argument("--dump", type=str, default="")
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL, the measured configuration) or gloo (rehearsal of the N>1 path)")
     ap.add_argument("--same-device", action="store_true", help="rehearsal only: every rank uses cuda:0 (needs --backend gloo)")
-    ap.add_argument("--emulate-shard", type=int, default=0, help="analysis only: render just shard 0 of an N-way tile split (no collective)")
+    ap.add_argument("--emulate-shard", type=int, default=0, help="analysis only: render just ONE shard of an N-way tile split (no collective)")
+    ap.add_argument("--shard", type=int, default=0, help="with --emulate-shard N: which shard; -1 = every shard in turn on this one GPU, "
+                                                         "printing the per-shard times (tile balance as data) instead of the bench line")
     args = ap.parse_args()
 
     # before anything touches the GPU: the host driver only supports dmabuf IPC (RCCL / tensor sharing across processes)
@@ -166,8 +168,40 @@ def main():
     mine = fg.mine
     if args.emulate_shard > 1:
         from tuturenderer_amd.dist import tile_pixel_lists
-        mine = tile_pixel_lists(W, H, args.emulate_shard)[0]
+        shard_lists = tile_pixel_lists(W, H, args.emulate_shard)
+        mine = shard_lists[max(args.shard, 0) % args.emulate_shard]
     torch.cuda.synchronize()  # the library renders on its own stream: torch's allocation fills must have landed
+
+    if args.emulate_shard > 1 and args.shard < 0:
+        # Tile balance as data: every shard of the N-way split rendered alone, one after the other, on this one GPU.
+        # It says how evenly the round-robin tiles split the WORK (max / mean is what an N-GPU frame would wait for);
+        # it says nothing about the gather or about N devices, and is not a scaling measurement.
+        rows = []
+        for k, lst in enumerate(shard_lists):
+            for _ in range(max(args.warmup, 1)):
+                fg.render(ctx, spp, KEY0, key1, pixels=lst, max_paths=args.max_paths, spp_per_pass=args.spp_per_pass)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                fg.render(ctx, spp, KEY0, key1, pixels=lst, max_paths=args.max_paths, spp_per_pass=args.spp_per_pass)
+            torch.cuda.synchronize()
+            rows.append({"shard": k, "pixels": int(len(lst)), "ms": (time.perf_counter() - t0) / args.steps * 1e3,
+                         "rays": int(ctx.last_stats["closest_rays"] + ctx.last_stats["shadow_rays"])})
+        fg.render(ctx, spp, KEY0, key1, max_paths=args.max_paths, spp_per_pass=args.spp_per_pass)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            fg.render(ctx, spp, KEY0, key1, max_paths=args.max_paths, spp_per_pass=args.spp_per_pass)
+        torch.cuda.synchronize()
+        whole = (time.perf_counter() - t0) / args.steps * 1e3
+        ms = [r["ms"] for r in rows]
+        print(json.dumps({"metric": "shard balance (one GPU renders every shard of an N-way tile split in turn)", "config": cfg["name"], "id": args.config,
+                          "n_shards": args.emulate_shard, "spp": spp, "steps": args.steps, "whole_frame_ms": whole, "max_ms": max(ms), "min_ms": min(ms),
+                          "mean_ms": sum(ms) / len(ms), "max_over_mean": max(ms) / (sum(ms) / len(ms)),
+                          "sum_of_shards_over_whole_frame": sum(ms) / whole, "ideal_speedup_if_no_other_cost": whole / max(ms),
+                          "shards": rows}), flush=True)
+        ctx.close()
+        return
 
     def step():
         fg.render(ctx, spp, KEY0, key1, pixels=mine, max_paths=args.max_paths, spp_per_pass=args.spp_per_pass)
@@ -252,7 +286,8 @@ def main():
         prof = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(prof):
             tj = json.load(open(prof)).get(args.config)
-            if isinstance(tj, dict) and tj.get("spp_per_pass") == spp_per_pass:
+            # the collection must match this run's pass size AND the exclusive step's launch geometry (one pass in flight)
+            if isinstance(tj, dict) and tj.get("spp_per_pass") == spp_per_pass and tj.get("sets") == 1:
                 tk = tj["kernels"].get(dom)
                 if tk:
                     traffic = tk["hbm_bytes_per_unit"] * top["units_per_launch"]
@@ -263,11 +298,14 @@ def main():
                                     "frac": value * 1e6 * tj["hbm_bytes_per_sample"] / (HBM_PEAK_GBS * 1e9),
                                     "note": "measured HBM bytes per sample (all kernels, committed PMC collection) x this run's samples/s / 8 TB/s"}
         sq = {}
+        issue_peak = None
         if os.path.exists(prof):
             tj2 = json.load(open(prof)).get(args.config)
-            if isinstance(tj2, dict) and tj2.get("spp_per_pass") == spp_per_pass:
+            if isinstance(tj2, dict) and tj2.get("spp_per_pass") == spp_per_pass and tj2.get("sets") == 1:
                 for k, e in tj2["kernels"].items():
-                    sq[k] = {m: e[m] for m in ("valu_issue_frac", "valu_lanes_active", "salu_per_valu", "hbm_bytes_per_unit") if m in e}
+                    sq[k] = {m: e[m] for m in ("valu_per_simd_cycle", "valu_issue_frac", "valu_lanes_active", "salu_per_valu", "hbm_bytes_per_unit",
+                                               "l2_hit_rate", "wave_cycles_waiting") if m in e}
+                issue_peak = tj2.get("issue_peak_valu_per_simd_cycle")
         roofline = {"bound": "hbm", "kernel": dom, "dominant_by_time": by_time,
                     "kernel_note": ("scene in LDS: the traversal kernels are VALU-issue bound (per_kernel.*.pmc.valu_issue_frac), "
                                     "k_shade is the HBM-bound kernel") if lds_scene else "the kernel with the most exclusive time",
@@ -293,6 +331,15 @@ def main():
                         "note": "G rays/s of the kernel alone (exclusive step); lanes_active = share of a wave's 64 lanes with work in a step"},
                     "per_kernel": {k: dict(priced(src, k), algorithmic_bytes_per_unit=per_unit[k], hbm_bytes_per_unit=hbm_unit[k],
                                            bound=("valu" if (lds_scene and k != "k_shade") else "hbm"), pmc=sq.get(k)) for k in src}}
+        # what actually reaches HBM (memory-resident scenes: most node / triangle bytes are served by L2): the measured
+        # bytes per unit of the committed PMC collection x this run's units / this run's exclusive kernel time
+        if traffic is not None and sq.get(dom):
+            roofline["hbm_reaching"] = {"bytes_per_unit_measured": sq[dom].get("hbm_bytes_per_unit"), "l2_hit_rate": sq[dom].get("l2_hit_rate"),
+                                        "achieved": traffic / max(top["avg_launch_ms"] * 1e-3, 1e-12) / 1e9, "unit": "GB/s",
+                                        "frac": traffic / max(top["avg_launch_ms"] * 1e-3, 1e-12) / 1e9 / HBM_PEAK_GBS,
+                                        "note": "FETCH_SIZE x2 + WRITE_SIZE of the dominant kernel (fabric-side requests: HBM or Infinity Cache), per unit, x "
+                                                "units_per_launch / avg_launch_ms -- the bandwidth the kernel really draws beyond L2, next to the algorithmic "
+                                                "figure above"}
         if excl is not None:
             roofline["exclusive_step_ms"] = excl["ms_total"]
             roofline["exclusive_kernel_ms_per_step"] = {"k_trace_closest": excl["ms_trace_closest"], "k_trace_any": excl["ms_trace_any"],
@@ -312,8 +359,12 @@ def main():
             if all(k in sq and "valu_issue_frac" in sq[k] for k in names):
                 busy = sum(excl[f] * sq[k]["valu_issue_frac"] for k, f in names.items())
                 pipeline_valu = {"valu_busy_ms_per_step": busy, "frac": busy / (dt / args.steps * 1e3),
-                                 "note": "sum over kernels of exclusive ms x valu_issue_frac (PMC: 4 x SQ_INSTS_VALU / SIMD cycles), / ms_per_step: "
-                                         "the share of the chip's vector issue slots the overlapped frame uses"}
+                                 "issue_peak_valu_per_simd_cycle": issue_peak,
+                                 "note": "sum over kernels of exclusive ms x valu_issue_frac, / ms_per_step: the share of the chip's MEASURED vector "
+                                         "issue peak the overlapped frame uses.  valu_issue_frac = (SQ_INSTS_VALU / SIMD cycles, PMC at the exclusive "
+                                         "step's launch geometry) / issue peak; the peak is measured by profiles/issuebench (independent v_add_f32 at 8 "
+                                         "waves per SIMD: 0.40 wave-instructions per SIMD-cycle = 2.5 cycles per wave64 instruction, profiles/"
+                                         "issue_peak.json).  v_min/v_max/v_cndmask/v_cmp issue at 0.24: a kernel made of them saturates earlier"}
         rendered = max(npix * spp * args.steps, 1)
         seg_per_sample = tab["k_shade"]["units"] / rendered
         sh_per_sample = agg["shadow_rays"] / rendered
@@ -322,6 +373,14 @@ def main():
             "algorithmic_bytes_per_sample": seg_per_sample * (per_unit["k_trace_closest"] + per_unit["k_shade"]) + sh_per_sample * per_unit["k_trace_any"],
             "of_which_lds_served": (seg_per_sample * scene_bytes["k_trace_closest"] + sh_per_sample * scene_bytes["k_trace_any"]) if lds_scene else 0.0,
             "measured_hbm": pipeline_hbm, "valu": pipeline_valu}
+        # the picture the timed region left in HBM: mean and CRC-32 of the float frame (rank 0's assembled frame), so that a
+        # reader can see that the fast frame is the right frame (tests/test_hip_parity.py pins the same frame against the oracle)
+        import zlib
+        fr = fg.frame.detach().cpu().numpy().astype(np.float32, copy=False)
+        frame_check = {"mean": float(fr.mean(dtype=np.float64)), "mean_rgb": [float(x) for x in fr.reshape(-1, 3).mean(axis=0, dtype=np.float64)],
+                       "nan_pixels": int(np.isnan(fr).any(axis=-1).sum()) if fr.ndim > 1 else int(np.isnan(fr).sum()),
+                       "crc32": f"{zlib.crc32(np.ascontiguousarray(fr).tobytes()) & 0xFFFFFFFF:08x}",
+                       "note": "linear radiance, float32, as tutu_hip_render_device left it (shard runs: only this shard's pixels are set)"}
         line = {
             "metric": METRIC if args.config == "c2" else "Msamples/sec (rays traced/sec)",
             "value": value, "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -336,6 +395,7 @@ def main():
                        "timed": "tutu_hip_render_device: scene, BVH and work buffers resident in HBM, frame left in HBM (bench contract); "
                                 "see `drop_in` for the SURVEY 8d bracket (create + H2D + render + D2H + destroy)",
                        "knobs": options, "env": {k: v for k, v in os.environ.items() if k.startswith("TUTU_")}},
+            "frame": frame_check,
             "roofline": roofline,
         }
         if world == 1 and not args.no_extras:
@@ -353,6 +413,10 @@ def main():
             t0 = time.perf_counter()
             c2.close()
             t_d = time.perf_counter() - t0
+            line["survey_8d_bracket"] = {"value": W * H * spp / t_r2 / 1e6, "unit": "Msamples/s", "seconds": t_r2,
+                                         "note": "SURVEY.md 8d's metric bracket: host wall clock around tutu_hip_render on a persistent context -- render + "
+                                                 "frame D2H over PCIe into the caller's host buffer (scene already resident, as the reference's timer "
+                                                 "brackets render() only, src/main_cornellBox.cpp:75-79); `value` above leaves the frame in HBM"}
             line["drop_in"] = {"create_s": t_c2, "first_render_s": t_r1, "second_render_s": t_r2, "destroy_s": t_d,
                                "Msamples_per_s_cold": W * H * spp / (t_c2 + t_r1 + t_d) / 1e6, "Msamples_per_s_warm_host_frame": W * H * spp / t_r2 / 1e6,
                                "note": "tutu_hip_create + tutu_hip_render (host frame: PCIe D2H included) + tutu_hip_destroy; the first render also "

@@ -17,6 +17,7 @@ Also per kernel, from the SQ counters of the same collection (totals over the sa
                       issuebench_summary.py) -- the roofline of a kernel that does not touch memory.  Round 2 assumed 1/4
                       (4 cycles per wave64 instruction); the guide states 1/2 for >= 2 waves per SIMD;
   valu_lanes_active = SQ_THREAD_CYCLES_VALU / (64 * SQ_ACTIVE_INST_VALU): lanes switched on in an average vector instruction;
+  l2_hit_rate       = TCC_HIT_sum / (TCC_HIT_sum + TCC_MISS_sum);  wave_cycles_waiting = SQ_WAIT_ANY / SQ_WAVE_CYCLES;
   salu_per_valu     = SQ_INSTS_SALU / SQ_INSTS_VALU."""
 import csv
 import glob
@@ -53,7 +54,8 @@ def main(root, tag, cfg):
         for row in csv.DictReader(open(f)):
             st = stage(row["Kernel_Name"])
             if st and row["Counter_Name"] in ("FETCH_SIZE", "WRITE_SIZE", "SQ_INSTS_VALU", "GRBM_GUI_ACTIVE", "SQ_THREAD_CYCLES_VALU",
-                                              "SQ_ACTIVE_INST_VALU", "SQ_INSTS_SALU"):
+                                              "SQ_ACTIVE_INST_VALU", "SQ_INSTS_SALU", "TCC_HIT_sum", "TCC_MISS_sum", "SQ_WAIT_ANY",
+                                              "SQ_WAVE_CYCLES"):
                 val[st][row["Counter_Name"]] += float(row["Counter_Value"])
                 disp[st][row["Counter_Name"]].add(row["Dispatch_Id"])
     line = json.loads([x for x in open(f"{root}/g2.log") if x.startswith("{")][0])
@@ -83,6 +85,10 @@ def main(root, tag, cfg):
             if issue_peak:
                 e["valu_issue_frac"] = e["valu_per_simd_cycle"] / issue_peak
             e["salu_per_valu"] = v.get("SQ_INSTS_SALU", 0.0) / v["SQ_INSTS_VALU"]
+        if v.get("TCC_HIT_sum") or v.get("TCC_MISS_sum"):
+            e["l2_hit_rate"] = v.get("TCC_HIT_sum", 0.0) / (v.get("TCC_HIT_sum", 0.0) + v.get("TCC_MISS_sum", 0.0))
+        if v.get("SQ_WAVE_CYCLES"):
+            e["wave_cycles_waiting"] = v.get("SQ_WAIT_ANY", 0.0) / v["SQ_WAVE_CYCLES"]  # s_waitcnt / barrier
         if v.get("SQ_ACTIVE_INST_VALU") and v.get("SQ_THREAD_CYCLES_VALU"):
             e["valu_lanes_active"] = v["SQ_THREAD_CYCLES_VALU"] / (64.0 * v["SQ_ACTIVE_INST_VALU"])
         kernels[st] = e

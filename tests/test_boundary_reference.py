@@ -76,11 +76,22 @@ def test_binding_hands_over_the_same_scene_from_both_front_ends(built, tmp_path)
 
 
 @pytest.mark.gpu
+def test_reference_builds_travelled_to_the_gpu_box():
+    """GPU box guard: the reference-built checker binaries (oracle/_ref, git-ignored but NOT gpurun-ignored) must have come
+    along with the snapshot -- a push that drops them would otherwise silently shrink the suite to its skips"""
+    from oracle.pyoracle import available
+
+    missing = [b for b in ("ref_binding", "main_cornellBox_ref", "main_veach_ref", "libtutu_ref.so", "libtutu_ref_fast.so")
+               if not os.path.exists(os.path.join(REF_BIN, b))]
+    assert not missing, f"oracle/_ref is incomplete on this box: {missing}"
+    assert available("reference") and available("reference_fast")
+
+
+@pytest.mark.gpu
 def test_reference_front_end_renders_through_the_binding(built, tmp_path):
     """GPU: the reference's own front-end + HipPathTracing.hpp renders the Cornell box and writes, with the reference's own
     P3 writer, the same bytes as the bundled front-end does; a second integrate() of the same scene reuses the contexts"""
-    if not _have_ref_builds():
-        pytest.skip("oracle/_ref boundary builds missing")
+    assert _have_ref_builds(), "oracle/_ref boundary builds missing on the GPU box"
     cfg, specs, run = _cornell_files(tmp_path)
     ppm = {}
     for tag, exe in (("ref", os.path.join(REF_BIN, "ref_binding")), ("ours", os.path.join(ROOT, "oracle", "bundled_binding"))):
@@ -119,8 +130,7 @@ def test_reference_front_end_renders_through_the_binding(built, tmp_path):
 def test_reference_scene_programs_over_the_bundled_front_end(built, tmp_path):
     """GPU: src/main_cornellBox.cpp of the reference, compiled unchanged against host/tutu_renderer.hpp, end to end -- the same
     PPM as the bundled scene program apps/main_cornellBox (which restates it)"""
-    if not _have_ref_builds():
-        pytest.skip("oracle/_ref boundary builds missing")
+    assert _have_ref_builds(), "oracle/_ref boundary builds missing on the GPU box"
     cfg, specs, run = _cornell_files(tmp_path)
     out = {}
     for tag, exe in (("ref_main", os.path.join(REF_BIN, "main_cornellBox_ref")), ("app", os.path.join(APPS, "main_cornellBox"))):

@@ -3,8 +3,8 @@
 The reference splits image rows statically over 20 std::threads that share the framebuffer
 (PathTracing.hpp:393-429).  Here every rank renders its own pixel list (the RNG is keyed by global pixel index and
 sample index, so the image is bit-identical for any number of ranks) and the pieces are gathered to rank 0 with a
-single `torch.distributed.gather` -- RCCL over xGMI when the backend is "nccl", gloo in the CPU tests.  Payload:
-W*H*12 B per frame (7.7 MB at 800x800), each peer on its own link to the root.
+single grouped send/recv of exactly len(list) rows per rank -- RCCL over xGMI when the backend is "nccl", gloo in the
+CPU tests.  Payload: W*H*12 B per frame (7.7 MB at 800x800), each peer on its own link to the root.
 """
 import numpy as np
 
@@ -32,56 +32,75 @@ def tile_pixel_lists(W, H, n_ranks, tile=TILE):
 
 
 class FrameGather:
-    """Owns the per-rank output piece and, on rank 0, the assembled frame."""
+    """Owns the per-rank output piece and, on rank 0, the gathered pieces and the assembled frame.
+
+    One collective per frame, exact sizes: every rank r > 0 sends its len(list_r) rows to rank 0, rank 0 posts the matching
+    receives, all in ONE batch (`batch_isend_irecv`: ncclGroupStart ... ncclSend / ncclRecv ... ncclGroupEnd with backend
+    "nccl" = RCCL) straight into one contiguous (W*H, 3) buffer in rank order -- rank 0's own piece IS the
+    head of that buffer -- and ONE index_copy (one kernel) un-tiles it into the frame.
+
+    Ordering without host synchronisation: the library is handed torch's current stream (the ABI's `stream` argument),
+    so its kernels are ordered after the previous frame's send / un-tiling, which read `piece`, by stream order alone.
+    """
 
     def __init__(self, W, H, rank, world, device, tile=TILE, host_staging=False):
         import torch
 
         self.torch = torch
         self.W, self.H, self.rank, self.world = W, H, rank, world
-        self.host_staging = host_staging  # gloo rehearsal: the collective runs on CPU copies of the pieces
+        self.device = device
+        self.host_staging = host_staging  # gloo rehearsal on GPUs: the collective runs on CPU copies of the pieces
         self.lists = tile_pixel_lists(W, H, world, tile)
         self.mine = self.lists[rank]
-        n_max = max(len(l) for l in self.lists)
-        self.piece = torch.zeros((n_max, 3), dtype=torch.float32, device=device)  # equal size on every rank
-        self.frame = torch.zeros((H * W, 3), dtype=torch.float32, device=device) if rank == 0 else None
-        self.gather_list = [torch.zeros_like(self.piece) for _ in range(world)] if (world > 1 and rank == 0) else None
-        self.index = [torch.from_numpy(l.astype(np.int64)).to(device) for l in self.lists] if rank == 0 else None
-        # Ordering contract with tutu_hip_render_device (INTEGRATION.md): the library writes `piece` from ITS stream and
-        # returns when that write is complete; what it cannot see is torch-stream work that still READS `piece` (the
-        # gather / index_copy below are enqueued asynchronously).  `consumed` marks the end of that work; the next
-        # render waits for it on the host before the library touches `piece` again.
-        self.consumed = torch.cuda.Event() if device.type == "cuda" else None
+        self.sizes = [len(l) for l in self.lists]
+        self.offsets = [0]
+        for n in self.sizes:
+            self.offsets.append(self.offsets[-1] + n)
+        if rank == 0:
+            self.gathered = torch.zeros((W * H, 3), dtype=torch.float32, device=device)  # pieces back to back, rank order
+            self.piece = self.gathered[: self.sizes[0]]
+            self.frame = torch.zeros((H * W, 3), dtype=torch.float32, device=device)
+            self.index = torch.from_numpy(np.concatenate(self.lists).astype(np.int64)).to(device)  # row k of `gathered` -> pixel
+        else:
+            self.gathered = None
+            self.piece = torch.zeros((max(self.sizes[rank], 1), 3), dtype=torch.float32, device=device)[: self.sizes[rank]]
+            self.frame = None
+            self.index = None
 
     def render(self, ctx, spp, key0, key1, pixels=None, **kw):
-        """ctx.render_device into this rank's piece, ordered after the previous frame's consumers of `piece`"""
-        if self.consumed is not None:
-            self.consumed.synchronize()
-        return ctx.render_device(self.piece.data_ptr(), spp, key0, key1, pixels=self.mine if pixels is None else pixels, **kw)
+        """ctx.render_device into this rank's piece, on torch's current stream: ordered after the previous frame's consumers
+        of `piece` (send / un-tiling) by the stream itself -- no host wait between frames"""
+        stream = None
+        if self.device.type == "cuda":
+            stream = self.torch.cuda.current_stream(self.device).cuda_stream
+        return ctx.render_device(self.piece.data_ptr(), spp, key0, key1, pixels=self.mine if pixels is None else pixels,
+                                 stream=stream, **kw)
 
     def assemble(self):
-        """the collective (world > 1) + scatter of the pieces into the frame on rank 0"""
-        frame = self._assemble()
-        if self.consumed is not None:
-            self.consumed.record()
-        return frame
-
-    def _assemble(self):
+        """the collective (world > 1) + ONE un-tiling kernel on rank 0"""
         if self.world > 1:
             import torch.distributed as dist
 
             if self.host_staging:
                 piece = self.piece.cpu()
-                glist = [self.torch.zeros_like(piece) for _ in range(self.world)] if self.rank == 0 else None
-                dist.gather(piece, glist, dst=0)
                 if self.rank == 0:
-                    for r in range(self.world):
-                        self.frame.index_copy_(0, self.index[r], glist[r][: len(self.lists[r])].to(self.frame.device))
+                    host = self.torch.zeros((self.W * self.H, 3), dtype=self.torch.float32)
+                    host[: self.sizes[0]] = piece
+                    ops = [dist.P2POp(dist.irecv, host[self.offsets[r]: self.offsets[r + 1]], r) for r in range(1, self.world) if self.sizes[r]]
+                else:
+                    ops = [dist.P2POp(dist.isend, piece, 0)] if self.sizes[self.rank] else []
+                for w in (dist.batch_isend_irecv(ops) if ops else []):
+                    w.wait()
+                if self.rank == 0:
+                    self.gathered.copy_(host.to(self.device))
             else:
-                dist.gather(self.piece, self.gather_list, dst=0)
                 if self.rank == 0:
-                    for r in range(self.world):
-                        self.frame.index_copy_(0, self.index[r], self.gather_list[r][: len(self.lists[r])])
-        else:
-            self.frame.index_copy_(0, self.index[0], self.piece[: len(self.mine)])
+                    ops = [dist.P2POp(dist.irecv, self.gathered[self.offsets[r]: self.offsets[r + 1]], r) for r in range(1, self.world)
+                           if self.sizes[r]]
+                else:
+                    ops = [dist.P2POp(dist.isend, self.piece, 0)] if self.sizes[self.rank] else []
+                for w in (dist.batch_isend_irecv(ops) if ops else []):
+                    w.wait()  # nccl: orders the current stream after the transfer, no host block
+        if self.rank == 0:
+            self.frame.index_copy_(0, self.index, self.gathered)
         return self.frame
