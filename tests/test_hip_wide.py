@@ -1,0 +1,118 @@
+"""GPU (MI355X): the two optional forms of the persistent traversal kernels -- the four-wide quantised tree (default only
+for trees of >= 16 MB of binary nodes, e.g. the broom stand-in) and the two-tier stack (LDS + HBM, default only for very
+deep trees) -- forced onto the mesh scenes of the golden set: the same bits as the reference build's hits, whatever is walked.
+The knobs are read from the environment when the context is created (include/tutu_hip.h)."""
+import numpy as np
+import pytest
+
+from conftest import golden_path
+from helpers import bit_equal, count_diff
+from oracle import parity_cases as pc
+
+pytestmark = pytest.mark.gpu
+
+FORMS = {
+    "wide": {"TUTU_WIDE": "2"},
+    "wide_short_lds_stack": {"TUTU_WIDE": "2", "TUTU_WIDE_LDS_STACK": "6"},   # most pushes land in the HBM tier
+    "binary_two_tier_stack": {"TUTU_WIDE": "0", "TUTU_LDS_STACK_MAX": "6"},
+}
+
+
+@pytest.fixture(scope="module")
+def tr(built):
+    import tuturenderer_amd
+
+    tuturenderer_amd.load_library()
+    assert tuturenderer_amd.device_count() >= 1
+    return tuturenderer_amd
+
+
+def _scene(name):
+    from oracle.gen_golden import golden_scenes
+
+    mk, key1 = golden_scenes()[name]
+    return mk(), key1
+
+
+@pytest.mark.parametrize("form", sorted(FORMS))
+@pytest.mark.parametrize("name", ["veach_slight", "cornell_spheres"])
+def test_golden_rays_bit_exact_in_every_form(tr, port, monkeypatch, name, form):
+    for k, v in FORMS[form].items():
+        monkeypatch.setenv(k, v)
+    sc, _ = _scene(name)
+    z = np.load(golden_path(f"scene_{name}.npz"))
+    S = port.scene(sc)
+    O, D = pc.scene_rays(S)
+    with tr.Context(sc) as ctx:
+        opt = ctx.options()
+        if name == "veach_slight":  # (the sphere scene is small enough to live in LDS: it keeps the binary LDS kernel)
+            assert opt["lds_scene"] == 0
+            assert opt["wide_tree"] == (1 if form.startswith("wide") else 0)
+            assert opt["stack_entries_hbm"] > 0
+        hits = ctx.trace_closest(O, D)
+        h = hits["tri"] >= 0
+        assert bit_equal(h.astype(np.uint8), z["scene.hit"])
+        assert bit_equal(hits["tri"], z["scene.tri"])
+        assert bit_equal(np.where(h, hits["t"], 0).astype(np.float32), z["scene.t"])
+    S.close()
+
+
+@pytest.mark.parametrize("form", sorted(FORMS))
+def test_random_and_degenerate_rays_vs_oracle_in_every_form(tr, port, monkeypatch, form):
+    """veach room: 300 k random rays + 60 k rays with zero components / origins on box planes / far origins (not plain: they
+    must take the reference's tree) -- identical object and identical t bits, identical shadow answers"""
+    for k, v in FORMS[form].items():
+        monkeypatch.setenv(k, v)
+    sc, _ = _scene("veach_slight")
+    S = port.scene(sc)
+    r = pc._rng(777)
+    V = S.verts.reshape(-1, 3)
+    lo, hi = V.min(0), V.max(0)
+    n = 300_000
+    o = (lo + (hi - lo) * r.random((n, 3))).astype(np.float32)
+    d = pc.unit(r, n)
+    m = 60_000
+    o2 = (lo + (hi - lo) * r.random((m, 3))).astype(np.float32)
+    d2 = pc.unit(r, m)
+    kind = r.integers(0, 4, m)
+    axis = r.integers(0, 3, m)
+    for k in range(3):
+        d2[(kind == 0) & (axis == k), k] = 0.0
+    snap = (kind == 1)[:, None] & (r.random((m, 3)) < 0.5)
+    o2 = np.where(snap, V[r.integers(0, len(V), (m, 3)), np.arange(3)], o2).astype(np.float32)
+    far = kind == 2  # origins far outside the region the wide tree's margin was sized for
+    o2[far] = (o2[far] + np.float32(50.0) * (hi - lo) * np.sign(r.random((int(far.sum()), 3)) - 0.5)).astype(np.float32)
+    d2[far] = -np.sign(o2[far]) * np.abs(d2[far])  # pointing back at the scene
+    tiny = kind == 3  # a direction component below 2^-60: 1/d beyond the wide tree's scale range
+    d2[tiny, 0] = np.float32(1e-30)
+    O, D = np.concatenate([o, o2]), np.concatenate([d, d2]).astype(np.float32)
+    with tr.Context(sc) as ctx:
+        hits = ctx.trace_closest(O, D)
+        hit, t, tri, *_ = S.closest(O, D)
+        assert count_diff(hits["tri"], tri) == 0
+        assert count_diff(np.where(tri >= 0, hits["t"], 0), np.where(tri >= 0, t, 0)) == 0
+        assert (tri[n:] >= 0).mean() > 0.2  # the odd rays do hit things
+        # shadow queries between random points
+        a = (lo + (hi - lo) * r.random((100_000, 3))).astype(np.float32)
+        b = (lo + (hi - lo) * r.random((100_000, 3))).astype(np.float32)
+        assert bit_equal(np.asarray(ctx.trace_any(a, b)).astype(np.uint8), S.any_hit(a, b))
+    S.close()
+
+
+def test_frames_are_identical_in_every_form(tr, monkeypatch):
+    """bunny stand-in (82 k triangles, memory-resident), 96 x 96 x 8 spp: the binary walk, the wide walk and both two-tier
+    stacks render the same frame bit for bit"""
+    from tuturenderer_amd import scenes
+
+    frames = {}
+    for form, env in dict(FORMS, default={}).items():
+        for k in ("TUTU_WIDE", "TUTU_WIDE_LDS_STACK", "TUTU_LDS_STACK_MAX"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        with tr.Context(scenes.bunny_box(96, 96)) as ctx:
+            frames[form] = ctx.render(spp=8, key0=0x5EED0001, key1=3)
+    ref = frames.pop("default")
+    assert np.isfinite(ref).all() and ref.mean() > 0.01
+    for form, f in frames.items():
+        assert f.tobytes() == ref.tobytes(), form

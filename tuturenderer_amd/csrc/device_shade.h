@@ -751,6 +751,10 @@ __global__ void __launch_bounds__(256) k_shade(PassParams pp) {
 //     Push = an unconditional store of the far child at the top slot (sp moves only if both children are hit).
 //     All decisions (near / far, one / both / none, park the leaf, pop) are selects on those values.
 //   * The closest-hit pruning limit lives in a register and changes only when a hit is accepted.
+//   * DEEP: trees whose worst-case stack does not fit the LDS that 8 blocks per CU leave per block (20 KB) keep entries
+//     [0, stack_entries) in LDS and the rest -- reached by few rays -- in a per-lane column of `gstack` in HBM, so that
+//     the occupancy of the memory-resident scenes (latency-bound: 70 % of their wave-cycles wait for a node) no longer
+//     depends on the tree's depth (round 2: bunny stand-in 7 blocks per CU, broom stand-in 5).
 //   * The reference's leaf boxes (candidate validation) and the class table are part of the LDS scene copy.
 #define TUTU_INNER_STEPS 4
 #define TUTU_TRAV_IDLE (INT_MIN + 1)
@@ -765,7 +769,9 @@ struct TraceParams {
 	uint8_t* hitK;          // closest-hit: material class of the hit, per list position
 	float4* F;              // any-hit: final radiance per home slot (TUTU_KEY_FINAL requests)
 	const uint8_t* tri_class;  // per triangle (leaf order): class of its material
-	int stack_entries;      // per-lane LDS stack entries, sentinels included
+	int stack_entries;      // per-lane LDS stack entries, the sentinel included (the LDS tier of the stack)
+	int* gstack;            // DEEP kernels: entries >= stack_entries of every lane, [entry - stack_entries][global lane]
+
 	// work counters, per block: [block][0] nodes entered, [1] leaf tests (SURVEY.md 8(d)'s N and T, measured on the tree
 	// that is actually walked), [2] / [3] wave-level inner-node / leaf steps.  Plain read-modify-write by one thread per
 	// block and counter; each work set has its own array.
@@ -779,7 +785,14 @@ struct TraceParams {
 // leaf references are negative and above the two markers: (unsigned)ref > 0x80000001
 TUTU_DEV bool ref_is_leaf(int ref) { return (uint32_t)ref > (uint32_t)TUTU_TRAV_IDLE; }
 
-template <typename S, bool ANY, bool SPH>
+// pick child reference `slot` (0..3) of a wide node
+TUTU_DEV int wide_pick(uint32_t key, int c0, int c1, int c2, int c3) {
+	const uint32_t s = key & 3u;
+	return s == 0u ? c0 : (s == 1u ? c1 : (s == 2u ? c2 : c3));
+}
+#define TUTU_WIDE_MISS 0xFFFFFFFFu
+
+template <typename S, bool ANY, bool SPH, bool DEEP, bool WIDE>
 TUTU_DEV void trace_persistent(const S& ss, const TraceParams& tp, int* stack, const uint8_t* tri_class) {
 	const SceneDev& sc = tp.sc;
 	const int lane = __lane_id();
@@ -792,9 +805,37 @@ TUTU_DEV void trace_persistent(const S& ss, const TraceParams& tp, int* stack, c
 	uint32_t next = begin;
 	const float inf = __builtin_inff();
 
-	stack[0] = TUTU_TRAV_DONE;  // the sentinel: a pop below the lane's first entry ends the walk
-	int* top = stack + TUTU_STACK_SENTINELS * 256;  // next free entry of this lane
-
+	int sp = TUTU_STACK_SENTINELS;  // next free entry of this lane
+	const int K = tp.stack_entries;
+	const uint32_t gstride = gridDim.x * blockDim.x;
+	int* const gcol = DEEP ? tp.gstack + (blockIdx.x * blockDim.x + threadIdx.x) : nullptr;
+	// The common case -- no lane of the wave is near the end of the LDS tier -- is decided per WAVE and contains LDS
+	// accesses only.  (Written as a per-lane select of the two address spaces the compiler emits flat_load / flat_store
+	// for every access, which wait for both memory counters: +25 % on the veach room.)
+	// (the two tiers carry their address spaces in the pointer TYPES: with generic pointers the compiler merges the branches
+	// into one flat access of a selected address)
+	typedef __attribute__((address_space(3))) int lds_int;
+	typedef __attribute__((address_space(1))) int hbm_int;
+	lds_int* const lstack = (lds_int*)stack;
+	hbm_int* const gstack = (hbm_int*)gcol;
+	auto entry_read = [&](int e) -> int {  // entry e of this lane's stack
+		if (DEEP && __ballot(e >= K) != 0ull) {
+			int v = 0;
+			if (e < K) v = lstack[e * 256];
+			else v = gstack[(size_t)(e - K) * gstride];
+			return v;
+		}
+		return lstack[e * 256];
+	};
+	auto entry_write = [&](int e, int v) {
+		if (DEEP && __ballot(e >= K) != 0ull) {
+			if (e < K) lstack[e * 256] = v;
+			else gstack[(size_t)(e - K) * gstride] = v;
+			return;
+		}
+		lstack[e * 256] = v;
+	};
+	lstack[0] = TUTU_TRAV_DONE;  // the sentinel: a pop below the lane's first entry ends the walk
 	int cur = TUTU_TRAV_IDLE;
 	int pend = TUTU_TRAV_IDLE;  // parked leaf (TUTU_TRAV_IDLE = none)
 	uint32_t slot = 0;  // closest-hit: the ray's list position (where its hit goes); any-hit: the request's record slot
@@ -846,17 +887,18 @@ TUTU_DEV void trace_persistent(const S& ss, const TraceParams& tp, int* stack, c
 					lim = dis * TUTU_PRUNE_SLACK;
 					blocked = false;
 				}
-				top = stack + TUTU_STACK_SENTINELS * 256;
+				sp = TUTU_STACK_SENTINELS;
 				pend = TUTU_TRAV_IDLE;
 				cur = TUTU_TRAV_DONE;
 				if (sc.root_ref != INT_MIN) {
-					if (!ray_is_plain(r)) {
+					if (!ray_is_plain(r) || (WIDE && !ray_fits_wide(sc, r))) {
 						exact = true;  // the reference's own tree with the reference's own slab: after the main loop
 						cur = TUTU_TRAV_IDLE;
 					} else {
 						float te;
 						if (slab_plain(r, sc.root_min[0], sc.root_min[1], sc.root_min[2], sc.root_max[0], sc.root_max[1], sc.root_max[2], inf, te)) {
-							if (sc.root_ref >= 0) cur = sc.root_ref;
+							if (WIDE) cur = 0;  // the wide tree's root
+							else if (sc.root_ref >= 0) cur = sc.root_ref;
 							else pend = sc.root_ref;  // a scene of one object: the root is a leaf
 						}
 					}
@@ -877,9 +919,67 @@ TUTU_DEV void trace_persistent(const S& ss, const TraceParams& tp, int* stack, c
 		for (int k = 0; k < tp.inner_steps; k++) {
 			if (__ballot(cur >= 0) == 0ull) break;
 			w_node_steps++;
+			if (WIDE) {
+				if (cur >= 0) {
+					// ---- one node of the WIDE tree: four quantised child boxes in one 64-B fetch (host_scene.hpp: GpuWideNode).
+					// Plane q of axis a lies at t = fma(q, 2^e / d, (p - o) / d): conservative by the margin the host quantised
+					// with (host_scene.cpp: build_wide).  The hit children are ordered by entry distance with a five-comparator
+					// network on packed keys (distance bits | slot), the nearest is entered, the others go to the stack far to near.
+					n_nodes++;
+					const int p1 = entry_read(sp - 1);
+					const float4 n0 = sc.wnodes[4 * cur + 0], n1 = sc.wnodes[4 * cur + 1], n2 = sc.wnodes[4 * cur + 2], n3 = sc.wnodes[4 * cur + 3];
+					const uint32_t exps = __float_as_uint(n0.w);
+					const float sx = ldexpf(r.inv.x, (int)(exps & 0xFFu) - 128);
+					const float sy = ldexpf(r.inv.y, (int)((exps >> 8) & 0xFFu) - 128);
+					const float sz = ldexpf(r.inv.z, (int)((exps >> 16) & 0xFFu) - 128);
+					const float ox = (n0.x - r.o.x) * r.inv.x, oy = (n0.y - r.o.y) * r.inv.y, oz = (n0.z - r.o.z) * r.inv.z;
+					const uint32_t qlx = __float_as_uint(n2.x), qly = __float_as_uint(n2.y), qlz = __float_as_uint(n2.z);
+					const uint32_t qhx = __float_as_uint(n2.w), qhy = __float_as_uint(n3.x), qhz = __float_as_uint(n3.y);
+					uint32_t key[4];
+#pragma unroll
+					for (int c = 0; c < 4; c++) {
+						const float ax = fmaf((float)((qlx >> (8 * c)) & 0xFFu), sx, ox), bx = fmaf((float)((qhx >> (8 * c)) & 0xFFu), sx, ox);
+						const float ay = fmaf((float)((qly >> (8 * c)) & 0xFFu), sy, oy), by = fmaf((float)((qhy >> (8 * c)) & 0xFFu), sy, oy);
+						const float az = fmaf((float)((qlz >> (8 * c)) & 0xFFu), sz, oz), bz = fmaf((float)((qhz >> (8 * c)) & 0xFFu), sz, oz);
+						const float te = raw_max3(raw_min(ax, bx), raw_min(ay, by), raw_max(raw_min(az, bz), 0.f));
+						const float tx = raw_min3(raw_max(ax, bx), raw_max(ay, by), raw_min(raw_max(az, bz), lim));
+						key[c] = te <= tx ? ((__float_as_uint(te) & ~3u) | (uint32_t)c) : TUTU_WIDE_MISS;
+					}
+					{  // ascending: (0,1) (2,3) (0,2) (1,3) (1,2)
+						uint32_t a, b;
+						a = min(key[0], key[1]); b = max(key[0], key[1]); key[0] = a; key[1] = b;
+						a = min(key[2], key[3]); b = max(key[2], key[3]); key[2] = a; key[3] = b;
+						a = min(key[0], key[2]); b = max(key[0], key[2]); key[0] = a; key[2] = b;
+						a = min(key[1], key[3]); b = max(key[1], key[3]); key[1] = a; key[3] = b;
+						a = min(key[1], key[2]); b = max(key[1], key[2]); key[1] = a; key[2] = b;
+					}
+					const int c0 = __float_as_int(n1.x), c1 = __float_as_int(n1.y), c2 = __float_as_int(n1.z), c3 = __float_as_int(n1.w);
+					const int r0 = wide_pick(key[0], c0, c1, c2, c3), r1 = wide_pick(key[1], c0, c1, c2, c3);
+					const int r2 = wide_pick(key[2], c0, c1, c2, c3), r3 = wide_pick(key[3], c0, c1, c2, c3);
+					const bool none = key[0] == TUTU_WIDE_MISS;
+					const int v1 = key[1] != TUTU_WIDE_MISS ? 1 : 0, v2 = key[2] != TUTU_WIDE_MISS ? 1 : 0, v3 = key[3] != TUTU_WIDE_MISS ? 1 : 0;
+					// far to near, unconditionally: a store for a child that was not hit lands on the slot the next store (or a
+					// later push) overwrites -- the stack pointer only moves past the children that were hit
+					if (DEEP && __ballot(sp + 2 >= K) != 0ull) {
+						entry_write(sp, r3);
+						entry_write(sp + v3, r2);
+						entry_write(sp + v3 + v2, r1);
+					} else {
+						lstack[sp * 256] = r3;
+						lstack[(sp + v3) * 256] = r2;
+						lstack[(sp + v3 + v2) * 256] = r1;
+					}
+					const int below = v1 ? r1 : p1;  // what lies under the nearest child
+					const bool park = !none && ref_is_leaf(r0) && pend == TUTU_TRAV_IDLE;
+					pend = park ? r0 : pend;
+					cur = none ? p1 : (park ? below : r0);
+					sp += v1 + v2 + v3 - ((none || park) ? 1 : 0);
+				}
+				continue;
+			}
 			if (cur >= 0) {
 				n_nodes++;
-				const int p1 = top[-256];  // the top entry, requested with the node
+				const int p1 = entry_read(sp - 1);  // the top entry, requested with the node
 				float4 a, b, c, e;
 				ss.node(cur, a, b, c, e);
 				float tl, tr;
@@ -891,7 +991,7 @@ TUTU_DEV void trace_persistent(const S& ss, const TraceParams& tp, int* stack, c
 				const int first = take_left ? left : right;   // the child to enter if any is hit
 				const int other = take_left ? right : left;   // the child to postpone if both are hit
 				const bool both = hl && hr, none = !(hl || hr);
-				*top = other;  // a push only if `both` (else the slot stays free: the store is harmless)
+				entry_write(sp, other);  // a push only if `both` (else the slot stays free: the store is harmless)
 				// what the lane moves to: a child, or the top entry of its stack.  A child that is a leaf is parked and the
 				// walk goes on with the entry below it: the far child just pushed, or the top entry.  (A POPPED leaf is not
 				// parked: the entry below it is not at hand; the lane sits on it until the leaf step.)
@@ -900,7 +1000,7 @@ TUTU_DEV void trace_persistent(const S& ss, const TraceParams& tp, int* stack, c
 				pend = park ? first : pend;
 				cur = none ? p1 : (park ? below : first);
 				// both: +1 (push), minus the pop when the near child is parked; one: that pop; none: the pop
-				top += both ? (park ? 0 : 256) : ((none || park) ? -256 : 0);
+				sp += both ? (park ? 0 : 1) : ((none || park) ? -1 : 0);
 			}
 		}
 
@@ -911,7 +1011,7 @@ TUTU_DEV void trace_persistent(const S& ss, const TraceParams& tp, int* stack, c
 			if (__ballot(has_pend || on_leaf) != 0ull) w_leaf_steps++;
 			if (has_pend || on_leaf) {
 				n_leaves++;
-				const int p1 = top[-256];
+				const int p1 = entry_read(sp - 1);
 				int ti;
 				float t, u, v;
 				const bool h = leaf_test<SPH>(ss, has_pend ? ~pend : ~cur, r, ti, t, u, v);
@@ -933,7 +1033,7 @@ TUTU_DEV void trace_persistent(const S& ss, const TraceParams& tp, int* stack, c
 				// the leaf the lane sits on was either tested (nothing was parked) or moves into the parking slot
 				pend = (has_pend && on_leaf) ? cur : TUTU_TRAV_IDLE;
 				cur = on_leaf ? p1 : cur;
-				top -= on_leaf ? 256 : 0;
+				sp -= on_leaf ? 1 : 0;
 				if (ANY && blocked) {
 					cur = TUTU_TRAV_DONE;
 					pend = TUTU_TRAV_IDLE;
@@ -963,7 +1063,7 @@ TUTU_DEV void trace_persistent(const S& ss, const TraceParams& tp, int* stack, c
 	if (n_def != 0u) {
 		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // the list positions were written by other lanes of this wave
 		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-		int* xstack = stack + TUTU_STACK_SENTINELS * 256;
+		int* xstack = stack;  // (the reference's tree always fits the LDS tier: host, tutu_hip_create)
 		for (uint32_t j = (uint32_t)lane; j < n_def; j += 64u) {
 			const uint32_t i = tp.defer[begin + j];
 			const uint32_t s = tp.list[i];
@@ -1017,7 +1117,9 @@ TUTU_DEV void trace_persistent(const S& ss, const TraceParams& tp, int* stack, c
 
 // LDS carve-up with the per-triangle class table appended to the staged scene
 // SPH: the scene has sphere leaves (the triangle-only instantiations do not contain the sphere test)
-template <bool LDS_SCENE, bool ANY, bool SPH>
+// DEEP: the stack has a second tier in HBM (memory-resident scenes with deep trees)
+// WIDE: memory-resident scenes walk the four-wide quantised tree (always with the two-tier stack: a wide node can push three)
+template <bool LDS_SCENE, bool ANY, bool SPH, bool DEEP, bool WIDE>
 __global__ void __launch_bounds__(256, 8) k_trace(TraceParams tp) {
 	extern __shared__ int lds[];  // [stack entries][256 lanes] | optional scene copy | optional class table
 	if (LDS_SCENE) {
@@ -1027,13 +1129,13 @@ __global__ void __launch_bounds__(256, 8) k_trace(TraceParams tp) {
 			for (int i = threadIdx.x; i < tp.sc.n_tris; i += blockDim.x) cls[i] = tp.tri_class[i];
 			__syncthreads();
 		}
-		trace_persistent<SceneLds, ANY, SPH>(sl, tp, lds + threadIdx.x, cls);
+		trace_persistent<SceneLds, ANY, SPH, false, false>(sl, tp, lds + threadIdx.x, cls);
 	} else {
 		SceneGlobal sg;
 		sg.nodes = tp.sc.nodes;
 		sg.tris = tp.sc.tri_isect;
 		sg.lboxes = tp.sc.leaf_boxes;
-		trace_persistent<SceneGlobal, ANY, SPH>(sg, tp, lds + threadIdx.x, tp.tri_class);
+		trace_persistent<SceneGlobal, ANY, SPH, DEEP || WIDE, WIDE>(sg, tp, lds + threadIdx.x, tp.tri_class);
 	}
 }
 

@@ -56,6 +56,10 @@ struct SceneDev {
 	int root_ref_exact;
 	int has_fast;
 	const float4* leaf_boxes;  // 2 x float4 per leaf (leaf order): min xyz, max xyz
+	// the wide tree (GpuWideNode, host_scene.hpp), walked by the persistent kernels on memory-resident scenes
+	const float4* wnodes;      // 4 x float4 per node; node 0 = root
+	int has_wide;
+	float wide_lo[3], wide_hi[3];  // ray origins the quantisation margin was sized for
 };
 
 struct SceneGlobal {
@@ -150,6 +154,14 @@ TUTU_DEV bool ray_is_plain(const RayPre& r) {
 	const float inf = __builtin_inff();
 	return fabsf(r.inv.x) < inf && fabsf(r.inv.y) < inf && fabsf(r.inv.z) < inf && fabsf(r.o.x) < inf && fabsf(r.o.y) < inf &&
 	       fabsf(r.o.z) < inf && r.d.x != 0.f && r.d.y != 0.f && r.d.z != 0.f;
+}
+// ... and for the WIDE tree additionally: 2^-60 <= |1/d| <= 2^60 (the per-node scale 2^e / d stays a normal number) and an
+// origin inside the region the quantisation margin was sized for (host_scene.cpp: build_wide)
+TUTU_DEV bool ray_fits_wide(const SceneDev& sc, const RayPre& r) {
+	const float lo = 0x1p-60f, hi = 0x1p60f;
+	const float ax = fabsf(r.inv.x), ay = fabsf(r.inv.y), az = fabsf(r.inv.z);
+	return ax >= lo && ax <= hi && ay >= lo && ay <= hi && az >= lo && az <= hi && r.o.x >= sc.wide_lo[0] && r.o.x <= sc.wide_hi[0] &&
+	       r.o.y >= sc.wide_lo[1] && r.o.y <= sc.wide_hi[1] && r.o.z >= sc.wide_lo[2] && r.o.z <= sc.wide_hi[2];
 }
 // BVHAccel::getIntersection reaches a leaf's intersect() only through the slab test of the leaf node itself (BVH.hpp:150)
 TUTU_DEV bool leaf_box_hit(const SceneDev& sc, int leaf, const RayPre& r) {

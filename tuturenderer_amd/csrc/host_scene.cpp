@@ -3,6 +3,7 @@
 #include "host_scene.hpp"
 
 #include <algorithm>
+#include <array>
 #include <chrono>
 #include <climits>
 #include <cmath>
@@ -499,6 +500,140 @@ int build_reference_tree(uint32_t n_tris, const float* verts, std::vector<BuildN
 	return build_tree_of_boxes(tb, out, depth);
 }
 
+// ---- the wide tree (GpuWideNode, host_scene.hpp): the SAH tree collapsed to four children per node, boxes quantised.
+// Collapse: a node's child set starts as its two children; the inner child with the largest box area is replaced by ITS two
+// children until there are four or only leaves are left.
+// Quantisation margin.  The kernel evaluates a plane at real position X = p + q 2^e as  t_q = fma(q, s, b),  s = 2^e inv
+// (exact), b = fl(fl(p - o) inv); the reference evaluates the true plane x as  t_ref = fl(fl(x - o) inv).  With
+// |delta_i| <= 2^-24:  t_q = [inv (X - o) + inv (p - o) (d1 + d2)] (1 + d3),  t_ref = inv (x - o) (1 + d4 + d5), so the
+// quantised lower plane is entered no later than the true one (and the upper one left no earlier) whenever
+//     |x - X| >= 2^-22 (|p - o| + |X - o| + |x - o|).
+// Ray origins are restricted to the scene box grown by 3 extents on every side (other rays are not "plain" and walk the
+// reference's tree): every |. - o| <= 4.01 ext, so m = 6 * 2^-22 * 4.01 ext ~ 5.8e-6 ext covers it with a factor 2 to spare.
+// Exponents are clamped to [-60, 60] and plain rays have 2^-60 <= |inv| <= 2^60, so s is a normal number.
+namespace {
+double wide_area(const BuildNode& b) {
+	const double dx = (double)b.pmax[0] - b.pmin[0], dy = (double)b.pmax[1] - b.pmin[1], dz = (double)b.pmax[2] - b.pmin[2];
+	return dx * dy + dy * dz + dz * dx;
+}
+}  // namespace
+
+// t: build tree (pre-order, t[0] = root, must be an inner node); leaf_ref(bn) = the device reference of leaf bn
+template <typename LeafRef>
+static bool build_wide(const std::vector<BuildNode>& t, const LeafRef& leaf_ref, HostScene& hs) {
+	hs.wnodes.clear();
+	hs.has_wide = false;
+	if (t.empty() || !(t[0].left >= 0 || t[0].right >= 0)) return false;
+	double ext = 0;
+	for (int k = 0; k < 3; k++) {
+		if (!std::isfinite(t[0].pmin[k]) || !std::isfinite(t[0].pmax[k])) return false;
+		ext = std::max(ext, (double)t[0].pmax[k] - (double)t[0].pmin[k]);
+	}
+	double maxabs = 0;
+	for (int k = 0; k < 3; k++) maxabs = std::max(maxabs, std::max(std::fabs((double)t[0].pmin[k]), std::fabs((double)t[0].pmax[k])));
+	if (!(ext > 0) || ext > 0x1p60 || ext < 0x1p-40 || maxabs > 0x1p60) return false;  // coordinates the 8-bit frames cannot serve
+	for (int k = 0; k < 3; k++) {
+		hs.wide_origin_lo[k] = (float)((double)t[0].pmin[k] - 3.0 * ext);
+		hs.wide_origin_hi[k] = (float)((double)t[0].pmax[k] + 3.0 * ext);
+	}
+	const double m = 6.0 * 0x1p-22 * 4.01 * (ext + maxabs * 0x1p-20);
+	auto is_inner = [&](int32_t bn) { return t[bn].left >= 0 || t[bn].right >= 0; };
+	// breadth-first numbering: a wide node per collapsed group
+	struct Item { int32_t bn; int32_t id; uint32_t level; };
+	std::vector<Item> queue;
+	queue.push_back({0, 0, 1});
+	int32_t next_id = 1;
+	uint32_t max_level = 1;
+	std::vector<std::array<int32_t, 4>> kids;  // per wide node: build-node index of each child (-1 = unused)
+	for (size_t qi = 0; qi < queue.size(); qi++) {
+		const Item it = queue[qi];
+		max_level = std::max(max_level, it.level);
+		std::array<int32_t, 4> ch = {t[it.bn].left, t[it.bn].right, -1, -1};
+		int n = 2;
+		while (n < 4) {
+			int best = -1;
+			double best_area = -1;
+			for (int k = 0; k < n; k++)
+				if (is_inner(ch[k]) && wide_area(t[ch[k]]) > best_area) {
+					best_area = wide_area(t[ch[k]]);
+					best = k;
+				}
+			if (best < 0) break;
+			const int32_t bn = ch[best];
+			ch[best] = t[bn].left;
+			ch[n++] = t[bn].right;
+		}
+		kids.push_back(ch);
+		for (int k = 0; k < n; k++)
+			if (is_inner(ch[k])) queue.push_back({ch[k], next_id++, it.level + 1});
+	}
+	hs.wnodes.resize(queue.size());
+	// ids were handed out in queue order: the children of queue[qi] that are inner got consecutive ids
+	std::vector<int32_t> id_of(t.size(), -1);
+	for (const Item& it : queue) id_of[it.bn] = it.id;
+	for (size_t qi = 0; qi < queue.size(); qi++) {
+		const std::array<int32_t, 4>& ch = kids[qi];
+		GpuWideNode& w = hs.wnodes[queue[qi].id];
+		memset(&w, 0, sizeof(w));
+		int n = 0;
+		while (n < 4 && ch[n] >= 0) n++;
+		double lo[3], hi[3];
+		for (int a = 0; a < 3; a++) {
+			lo[a] = 1e300;
+			hi[a] = -1e300;
+			for (int k = 0; k < n; k++) {
+				lo[a] = std::min(lo[a], (double)t[ch[k]].pmin[a] - m);
+				hi[a] = std::max(hi[a], (double)t[ch[k]].pmax[a] + m);
+			}
+		}
+		int e[3];
+		for (int a = 0; a < 3; a++) {
+			float pf = (float)lo[a];
+			if ((double)pf > lo[a]) pf = std::nextafterf(pf, -INFINITY);  // round the frame's origin DOWN
+			w.p[a] = pf;
+			const double span = hi[a] - (double)pf;
+			int ea = (int)std::ceil(std::log2(std::max(span, 1e-300) / 255.0));
+			while (std::ldexp(255.0, ea) < span) ea++;
+			ea = std::max(-60, std::min(60, ea));
+			if (std::ldexp(255.0, ea) < span) return false;  // (cannot happen with the extent check above)
+			e[a] = ea;
+			for (int k = 0; k < 4; k++) {
+				uint32_t ql, qh;
+				if (k < n) {
+					const double l = ((double)t[ch[k]].pmin[a] - m - (double)pf), h = ((double)t[ch[k]].pmax[a] + m - (double)pf);
+					ql = (uint32_t)std::max(0.0, std::min(255.0, std::floor(std::ldexp(l, -ea))));
+					qh = (uint32_t)std::max(0.0, std::min(255.0, std::ceil(std::ldexp(h, -ea))));
+					// the guarantees the kernel's exactness argument rests on
+					if ((double)pf + std::ldexp((double)ql, ea) > (double)t[ch[k]].pmin[a] - m || (double)pf + std::ldexp((double)qh, ea) < (double)t[ch[k]].pmax[a] + m)
+						return false;
+				} else {
+					ql = qh = 255u;  // unused slot: a point at the frame's far corner
+				}
+				w.qlo[a] |= ql << (8 * k);
+				w.qhi[a] |= qh << (8 * k);
+			}
+		}
+		w.exps = (uint32_t)(e[0] + 128) | ((uint32_t)(e[1] + 128) << 8) | ((uint32_t)(e[2] + 128) << 16);
+		int32_t any_leaf = INT_MIN;
+		for (int k = 0; k < n; k++) {
+			w.child[k] = is_inner(ch[k]) ? id_of[ch[k]] : leaf_ref(ch[k]);
+			if (!is_inner(ch[k]) && any_leaf == INT_MIN) any_leaf = w.child[k];
+		}
+		if (n < 4) {
+			// an unused slot refers to a leaf of this node's own subtree: find one
+			int32_t bn = ch[0];
+			while (any_leaf == INT_MIN) {
+				if (is_inner(bn)) bn = t[bn].left;
+				else any_leaf = leaf_ref(bn);
+			}
+			for (int k = n; k < 4; k++) w.child[k] = any_leaf;
+		}
+	}
+	hs.wide_depth = max_level;
+	hs.has_wide = true;
+	return true;
+}
+
 int build_host_scene(const TutuSceneDesc* d, HostScene& hs) {
 	if (!d) return TUTU_E_INVALID;
 	// TUTU_BUILD_TIMING: the phases of the host build on stderr
@@ -695,6 +830,14 @@ int build_host_scene(const TutuSceneDesc* d, HostScene& hs) {
 			hs.has_fast_tree = true;
 			hs.depth = std::max(hs.depth, sah_depth);
 			hs.fast_depth = sah_depth;
+			lap("flatten the walked tree");
+			if (!getenv("TUTU_NO_WIDE")) {
+				build_wide(sah, [&](int32_t bn) -> int32_t {
+					const int32_t leaf = hs.leaf_of_orig[sah[bn].tri];
+					return obj_sph[sah[bn].tri] >= 0 ? ~(leaf | kSphereBit) : ~leaf;
+				}, hs);
+				lap("wide tree (collapse + quantise)");
+			}
 		}
 	}
 	hs.root_ref_exact = flatten(tree);

@@ -23,6 +23,25 @@ struct GpuNode {
 };
 static_assert(sizeof(GpuNode) == 64, "GpuNode must be 64 B");
 
+// One node of the WIDE tree the persistent traversal kernels walk on memory-resident scenes (round 3): four children,
+// their boxes quantised to 8 bits per plane in the node's own frame -- 64 B for four children where GpuNode spends 64 B on
+// two, so a ray fetches half the bytes in half the round trips.  Plane k of child c along axis a lies at
+//     p[a] + q * 2^e[a],  q = byte c of qlo[a] / qhi[a]
+// and the quantised box CONTAINS the child's true box with a margin that covers the rounding of the kernel's
+// fma(q, 2^e * inv, (p - o) * inv) against the reference's (x - o) * inv (host_scene.cpp: build_wide).  A wider box can
+// only let more candidates through; every candidate is still validated against the reference's leaf box.
+// child[c] >= 0: wide node index; < 0: leaf, ~object (device_trace.h).  Unused slots hold a point box at the node's
+// corner and the reference of one of the node's own leaves (harmless if ever hit: a leaf test is idempotent).
+struct GpuWideNode {
+	float p[3];
+	uint32_t exps;      // byte a: e[a] + 128
+	int32_t child[4];
+	uint32_t qlo[3];    // axis a: byte c = child c
+	uint32_t qhi[3];
+	uint32_t pad[2];
+};
+static_assert(sizeof(GpuWideNode) == 64, "GpuWideNode must be 64 B");
+
 // Triangle as the intersector reads it (48 B = 3 x dwordx4): v0, E1 = v1-v0, E2 = v2-v0, n = normalized(E1 x E2).
 // These are exactly the per-test temporaries of Triangle::intersect (Triangle.hpp:25-35), hoisted to the host;
 // the host computes them with the same fp32 operations, so the bits are the same.
@@ -103,6 +122,11 @@ struct HostScene {
 	uint32_t fast_depth = 0, ref_depth = 0;
 	uint32_t n_refs = 0;         // leaves of the walked tree (>= objects: sliver triangles get several references)
 	std::vector<float> leaf_boxes;  // [leaf][8]: min xyz pad, max xyz pad -- the reference's leaf boxes
+	// the wide tree (optional: memory-resident scenes whose coordinates allow the quantisation)
+	std::vector<GpuWideNode> wnodes;   // wnodes[0] is the root
+	bool has_wide = false;
+	uint32_t wide_depth = 0;           // levels of wide nodes on the longest root-to-leaf path
+	float wide_origin_lo[3], wide_origin_hi[3];  // ray origins for which the quantisation margin was sized (others are not "plain")
 	uint32_t depth;  // max over both trees: sizes the traversal stack
 	float eta;
 	float bkg[3];

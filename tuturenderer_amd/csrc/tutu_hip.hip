@@ -73,8 +73,11 @@ struct TutuCtx {
 	hipStream_t stream = nullptr;
 	int n_cu = 256;
 	// traversal kernels: dynamic LDS = per-lane stacks (+ a copy of the BVH when it fits)
-	int stack_entries = TUTU_STACK_DEPTH;
+	int stack_entries = TUTU_STACK_DEPTH;   // full-depth stack of the one-ray-per-lane walkers (k_primary, bidirectional kernels)
 	unsigned trace_lds_bytes = TUTU_STACK_DEPTH * 256 * sizeof(int);
+	int ktrace_entries = TUTU_STACK_DEPTH;  // k_trace: entries of the LDS tier of its stack ...
+	int ktrace_deep = 0;                    // ... and of the HBM tier (0: the whole stack is in LDS)
+	unsigned ktrace_lds_bytes = TUTU_STACK_DEPTH * 256 * sizeof(int);
 	bool lds_scene = false;
 	uint32_t type_mask = 0;  // MaterialType values present among the non-emissive materials
 	int shade_tab = 0;       // 0: shade tables in HBM, 1: materials+lights in LDS, 2: + per-triangle shading records
@@ -97,12 +100,17 @@ struct TutuCtx {
 		int trace_bpc = 0;        // TUTU_TRACE_BPC      traversal blocks per CU, 0 = by LDS use  [0, 8]
 		int refill_min = 16;      // TUTU_REFILL_MIN     idle lanes before a wave refills         [1, 64]
 		int inner_steps = TUTU_INNER_STEPS;  // TUTU_INNER_STEPS node visits per round            [1, 64]
+		int wide = 1;             // TUTU_WIDE           four-wide quantised tree: 0 never, 1 for big trees, 2 always  [0, 2]
+		int wide_min_mb = 16;     // TUTU_WIDE_MIN_MB    ... "big" = at least this many MB of binary nodes  [0, 65536]
+		int wide_inner_steps = 2; // TUTU_WIDE_INNER_STEPS node visits per round on the wide tree  [1, 64]
+		int lds_stack_max = 32;   // TUTU_LDS_STACK_MAX  k_trace, binary tree: entries of the LDS tier of a deep tree's stack, 0 = all in LDS  [0, 64]
+		int wide_lds_stack = 19;  // TUTU_WIDE_LDS_STACK k_trace, wide tree: entries of the LDS tier (19 KB: eight blocks per CU)  [4, 64]
 		int any_near_first = 1;   // TUTU_ANY_NEAR_FIRST any-hit: nearer child first              {0, 1}
 		int util_stats = 0;       // TUTU_UTIL_STATS     phase counters of the traversal kernels  {0, 1}
 		int bidir_units = 1 << 21;  // TUTU_BIDIR_UNITS  LightTracing / NaivePT / BDPT: (pixel, sample) units per batch  [64, 2^24]
 	} knobs;
 	int shade_mode_all = SHADE_ANY;  // the kernel of that launch: the scene's only scattering class, or SHADE_ANY
-	DevBuf<float4> d_tri_tex, d_texels, d_tex_desc, d_leaf_boxes;
+	DevBuf<float4> d_tri_tex, d_texels, d_tex_desc, d_leaf_boxes, d_wnodes;
 	DevBuf<uint8_t> d_tri_class;
 	// work buffers: up to four sets, so that consecutive passes run on their own streams and a memory-bound stage of
 	// one pass overlaps a compute-bound stage of another
@@ -115,6 +123,7 @@ struct TutuCtx {
 		DevBuf<float4> F;          // per home slot: finished radiance
 		DevBuf<uint32_t> lists;    // [2][cap]: continuing records, records with a shadow request
 		DevBuf<uint32_t> tile_counts, tile_offsets;
+		DevBuf<int> gstack;        // traversal kernels, deep trees: the HBM tier of the per-lane stacks [entry][lane of the grid]
 		DevBuf<uint32_t> defer;    // traversal kernels: list positions of the rays set aside for the exact walk (device_shade.h)
 		DevBuf<uint32_t> list_meta;   // per depth: list counts [2]
 		DevBuf<unsigned long long> part;  // [2 kinds][TUTU_PART_BLOCKS][2] traversal work counters
@@ -156,6 +165,11 @@ const KnobDesc kKnobs[] = {
     {"trace_bpc", "TUTU_TRACE_BPC", &TutuCtx::Knobs::trace_bpc, 0, 8},
     {"refill_min", "TUTU_REFILL_MIN", &TutuCtx::Knobs::refill_min, 1, 64},
     {"inner_steps", "TUTU_INNER_STEPS", &TutuCtx::Knobs::inner_steps, 1, 64},
+    {"lds_stack_max", "TUTU_LDS_STACK_MAX", &TutuCtx::Knobs::lds_stack_max, 0, 64},
+    {"wide_lds_stack", "TUTU_WIDE_LDS_STACK", &TutuCtx::Knobs::wide_lds_stack, 4, 64},
+    {"wide", "TUTU_WIDE", &TutuCtx::Knobs::wide, 0, 2},
+    {"wide_min_mb", "TUTU_WIDE_MIN_MB", &TutuCtx::Knobs::wide_min_mb, 0, 65536},
+    {"wide_inner_steps", "TUTU_WIDE_INNER_STEPS", &TutuCtx::Knobs::wide_inner_steps, 1, 64},
     {"any_near_first", "TUTU_ANY_NEAR_FIRST", &TutuCtx::Knobs::any_near_first, 0, 1},
     {"util_stats", "TUTU_UTIL_STATS", &TutuCtx::Knobs::util_stats, 0, 1},
     {"bidir_units", "TUTU_BIDIR_UNITS", &TutuCtx::Knobs::bidir_units, 64, 1 << 24},
@@ -234,8 +248,11 @@ int ensure_set(WorkSet& w, size_t want_slots) {
 
 int ensure_work(TutuCtx* c, size_t want_slots, size_t nitems, int n_sets) {
 	int rc;
-	for (int k = 0; k < n_sets; k++)
+	for (int k = 0; k < n_sets; k++) {
 		if ((rc = ensure_set(c->ws[k], want_slots)) != TUTU_OK) return rc;
+		// HBM tier of the traversal stacks (deep trees): one column per lane of the largest grid
+		if (c->ktrace_deep > 0 && (rc = c->ws[k].gstack.ensure((size_t)c->ktrace_deep * TUTU_PART_BLOCKS * 256)) != TUTU_OK) return rc;
+	}
 	if ((rc = c->prim_dir.ensure(nitems)) != TUTU_OK) return rc;
 	if ((rc = c->prim_hit.ensure(nitems)) != TUTU_OK) return rc;
 	if ((rc = c->accum.ensure(nitems)) != TUTU_OK) return rc;
@@ -275,14 +292,26 @@ int ev_end(TutuCtx* c, hipStream_t s, size_t idx) {
 // the traversal kernel for this scene: BVH in LDS or HBM, closest- or any-hit, with or without sphere leaves
 template <bool ANY>
 void launch_trace(TutuCtx* c, hipStream_t s, int grid, const TraceParams& tp) {
+	if (c->sc.has_wide) {  // memory-resident scene: the four-wide quantised tree, two-tier stack
+		dim3 g(grid), b(256);
+		if (c->has_spheres) k_trace<false, ANY, true, true, true><<<g, b, c->ktrace_lds_bytes, s>>>(tp);
+		else k_trace<false, ANY, false, true, true><<<g, b, c->ktrace_lds_bytes, s>>>(tp);
+		return;
+	}
+	if (c->ktrace_deep > 0) {  // memory-resident scene with a deep tree: second stack tier in HBM
+		dim3 g(grid), b(256);
+		if (c->has_spheres) k_trace<false, ANY, true, true, false><<<g, b, c->ktrace_lds_bytes, s>>>(tp);
+		else k_trace<false, ANY, false, true, false><<<g, b, c->ktrace_lds_bytes, s>>>(tp);
+		return;
+	}
 	const dim3 g((unsigned)grid), b(256);
-	const unsigned lds = c->trace_lds_bytes;
+	const unsigned lds = c->ktrace_lds_bytes;
 	if (c->has_spheres) {
-		if (c->lds_scene) k_trace<true, ANY, true><<<g, b, lds, s>>>(tp);
-		else k_trace<false, ANY, true><<<g, b, lds, s>>>(tp);
+		if (c->lds_scene) k_trace<true, ANY, true, false, false><<<g, b, lds, s>>>(tp);
+		else k_trace<false, ANY, true, false, false><<<g, b, lds, s>>>(tp);
 	} else {
-		if (c->lds_scene) k_trace<true, ANY, false><<<g, b, lds, s>>>(tp);
-		else k_trace<false, ANY, false><<<g, b, lds, s>>>(tp);
+		if (c->lds_scene) k_trace<true, ANY, false, false, false><<<g, b, lds, s>>>(tp);
+		else k_trace<false, ANY, false, false, false><<<g, b, lds, s>>>(tp);
 	}
 }
 
@@ -412,9 +441,10 @@ int run_pass(TutuCtx* c, WorkSet& w, hipStream_t s, const TutuCameraFrame* cam, 
 		tp.hitK = w.hitK.p;
 		tp.F = w.F.p;
 		tp.tri_class = c->d_tri_class.p;
-		tp.stack_entries = c->stack_entries;
+		tp.stack_entries = c->ktrace_entries;
+	tp.gstack = w.gstack.p;
 		tp.refill_min = c->knobs.refill_min;
-		tp.inner_steps = c->knobs.inner_steps;
+		tp.inner_steps = c->sc.has_wide ? c->knobs.wide_inner_steps : c->knobs.inner_steps;
 		tp.any_near_first = c->knobs.any_near_first;
 		tp.part = w.part.p;
 		tp.defer = w.defer.p;
@@ -673,6 +703,7 @@ int tutu_hip_create(const TutuSceneDesc* scene, int device, TutuCtx** out) {
 	if (!c->hs.tri_class.empty() && hipMemcpyAsync(c->d_tri_class.p, c->hs.tri_class.data(), c->hs.tri_class.size(), hipMemcpyHostToDevice, s) != hipSuccess)
 		return fail(TUTU_E_HIP);
 	if ((rc = upload(c->d_leaf_boxes, c->hs.leaf_boxes, s)) != TUTU_OK) return fail(rc);
+	if ((rc = upload(c->d_wnodes, c->hs.wnodes, s)) != TUTU_OK) return fail(rc);
 	c->textured = !c->hs.tri_tex.empty();
 	if (c->textured) {
 		if ((rc = upload(c->d_tri_tex, c->hs.tri_tex, s)) != TUTU_OK) return fail(rc);
@@ -689,6 +720,10 @@ int tutu_hip_create(const TutuSceneDesc* scene, int device, TutuCtx** out) {
 	sc.root_ref_exact = c->hs.root_ref_exact;
 	sc.has_fast = c->hs.has_fast_tree ? 1 : 0;
 	sc.leaf_boxes = c->d_leaf_boxes.p;
+	sc.wnodes = c->d_wnodes.p;
+	sc.has_wide = 0;  // decided below, with the traversal kernels' LDS budget
+	memcpy(sc.wide_lo, c->hs.wide_origin_lo, 12);
+	memcpy(sc.wide_hi, c->hs.wide_origin_hi, 12);
 	sc.has_tex = c->textured ? 1 : 0;
 	sc.has_spheres = c->has_spheres ? 1 : 0;
 	sc.nodes = c->d_nodes.p;
@@ -746,7 +781,42 @@ int tutu_hip_create(const TutuSceneDesc* scene, int device, TutuCtx** out) {
 	                           ((c->hs.tri_class.size() + 15) / 16) * 16;  // + class table
 	c->lds_scene = scene_bytes > 0 && scene_bytes <= 24 * 1024;
 	c->trace_lds_bytes = (unsigned)(stack_bytes + (c->lds_scene ? scene_bytes : 0));
-	c->trace_blocks_per_cu = (int)std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / std::max<size_t>(c->trace_lds_bytes, 1)));
+	// k_trace (persistent waves): 8 blocks per CU leave 20 KB of LDS per block.  A memory-resident scene whose worst-case
+	// stack is deeper keeps the first `ktrace_entries` entries in LDS and the rest in HBM (device_shade.h: DEEP) -- few rays
+	// ever reach them -- so that the tree's depth does not cost resident waves.  The reference's own tree (depth ceil(log2 n),
+	// walked by the one-ray-per-lane loops after the main loop) must fit the LDS tier.
+	c->ktrace_entries = c->stack_entries;
+	c->ktrace_deep = 0;
+	// The wide tree pays where the walked tree does not fit the L2s (4 MB per XCD): a ray then moves half the bytes in
+	// half the round trips (broom stand-in, 42 MB of binary nodes: +37 %).  On trees that do fit, the binary walk waits
+	// for L2 hits with 35-40 % of the vector issue slots in use and the wide node's decode + ordering (2.6 x the vector
+	// instructions per step for 0.55 x the steps) turns it issue-bound for no gain (bunny stand-in, veach room: -0..5 %).
+	// TUTU_WIDE: 0 never, 1 by size (>= TUTU_WIDE_MIN_MB of binary nodes), 2 always.
+	const size_t walked_mb = ((size_t)c->hs.n_fast_inner * sizeof(GpuNode)) >> 20;
+	sc.has_wide = (!c->lds_scene && c->hs.has_wide && (c->knobs.wide == 2 || (c->knobs.wide == 1 && walked_mb >= (size_t)c->knobs.wide_min_mb))) ? 1 : 0;
+	if (sc.has_wide) {
+		// a wide node pushes up to three children (+ two scratch slots above the top for the unconditional stores)
+		const int need = 3 * (int)c->hs.wide_depth + 3 + TUTU_STACK_SENTINELS;
+		const int lds_tier = std::max((int)c->hs.ref_depth + 1, std::min(need, c->knobs.wide_lds_stack));
+		c->ktrace_entries = std::min(need, lds_tier);
+		c->ktrace_deep = need - c->ktrace_entries;
+	} else if (!c->lds_scene && c->knobs.lds_stack_max > 0) {
+		const int lds_tier = std::max((int)c->hs.ref_depth + 1, c->knobs.lds_stack_max);
+		if (c->stack_entries > lds_tier) {
+			c->ktrace_entries = lds_tier;
+			c->ktrace_deep = c->stack_entries - lds_tier;
+		}
+	}
+	c->ktrace_lds_bytes = (unsigned)((size_t)c->ktrace_entries * 256 * sizeof(int) + (c->lds_scene ? scene_bytes : 0));
+	// (+ the kernel's 32 B of static LDS: eight blocks of exactly 20 KB do NOT fit a CU, and the blocks that do not fit run
+	// after the others, alone -- a persistent grid must be resident as a whole)
+	c->trace_blocks_per_cu = (int)std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / ((size_t)c->ktrace_lds_bytes + 64)));
+	// Fewer resident blocks than the LDS use allows (TUTU_TRACE_BPC): the request is padded so that exactly that many FIT --
+	// a grid of fewer blocks than fit is not spread evenly over the CUs by the dispatcher (some CUs get 8, others 2).
+	if (c->knobs.trace_bpc > 0 && c->knobs.trace_bpc < c->trace_blocks_per_cu) {
+		c->trace_blocks_per_cu = c->knobs.trace_bpc;
+		c->ktrace_lds_bytes = std::max<unsigned>(c->ktrace_lds_bytes, (unsigned)((160 * 1024) / (c->knobs.trace_bpc + 1) + 1024));
+	}
 	*out = c;
 	return TUTU_OK;
 }
@@ -759,7 +829,7 @@ int tutu_hip_destroy(TutuCtx* c) {
 		(void)hipEventDestroy(e.a);
 		(void)hipEventDestroy(e.b);
 	}
-	c->d_tri_tex.release(); c->d_texels.release(); c->d_tex_desc.release(); c->d_leaf_boxes.release();
+	c->d_tri_tex.release(); c->d_texels.release(); c->d_tex_desc.release(); c->d_leaf_boxes.release(); c->d_wnodes.release();
 	c->d_tri_class.release(); c->d_nodes.release(); c->d_tri_isect.release(); c->d_tri_shade.release(); c->d_mats.release(); c->d_lights.release();
 	for (int k = 0; k < TUTU_MAX_SETS - 1; k++)
 		if (c->extra_streams[k]) (void)hipStreamSynchronize(c->extra_streams[k]);
@@ -771,7 +841,7 @@ int tutu_hip_destroy(TutuCtx* c) {
 			w.verdict[k2].release();
 		}
 		w.hitC.release(); w.hitK.release(); w.F.release(); w.lists.release(); w.tile_counts.release(); w.tile_offsets.release();
-		w.list_meta.release(); w.part.release(); w.defer.release();
+		w.list_meta.release(); w.part.release(); w.defer.release(); w.gstack.release();
 		if (w.ev_resolved) (void)hipEventDestroy(w.ev_resolved);
 	}
 	if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
@@ -823,12 +893,24 @@ int tutu_hip_get_option(TutuCtx* c, const char* name, int* value) {
 		*value = c->lds_scene ? 1 : 0;
 		return TUTU_OK;
 	}
+	if (strcmp(name, "wide_tree") == 0) {  // the persistent kernels walk the four-wide quantised tree
+		*value = c->sc.has_wide;
+		return TUTU_OK;
+	}
+	if (strcmp(name, "wide_depth") == 0) {
+		*value = (int)c->hs.wide_depth;
+		return TUTU_OK;
+	}
 	if (strcmp(name, "fast_depth") == 0) {  // depth of the walked (SAH) tree; the reference tree's is TutuBvhInfo::depth
 		*value = (int)c->hs.fast_depth;
 		return TUTU_OK;
 	}
-	if (strcmp(name, "stack_entries") == 0) {
-		*value = c->stack_entries;
+	if (strcmp(name, "stack_entries") == 0) {  // k_trace: LDS tier
+		*value = c->ktrace_entries;
+		return TUTU_OK;
+	}
+	if (strcmp(name, "stack_entries_hbm") == 0) {  // k_trace: HBM tier (deep trees)
+		*value = c->ktrace_deep;
 		return TUTU_OK;
 	}
 	if (strcmp(name, "trace_blocks_per_cu") == 0) {
@@ -836,7 +918,7 @@ int tutu_hip_get_option(TutuCtx* c, const char* name, int* value) {
 		return TUTU_OK;
 	}
 	if (strcmp(name, "trace_lds_bytes") == 0) {
-		*value = (int)c->trace_lds_bytes;
+		*value = (int)c->ktrace_lds_bytes;
 		return TUTU_OK;
 	}
 	if (strcmp(name, "shade_tab") == 0) {
@@ -1056,6 +1138,7 @@ int lt_wavefront_batch(TutuCtx* c, hipStream_t s, BidirParams p) {
 	const uint32_t n_pad = (p.n_units + TUTU_LIST_TILE - 1) / TUTU_LIST_TILE * TUTU_LIST_TILE;
 	int rc = ensure_set(w, n_pad);
 	if (rc != TUTU_OK) return rc;
+	if (c->ktrace_deep > 0 && (rc = w.gstack.ensure((size_t)c->ktrace_deep * TUTU_PART_BLOCKS * 256)) != TUTU_OK) return rc;
 	c->ev_used = 0;
 	p.rec = records_of(w, 0);
 	p.n_pad = n_pad;
@@ -1076,9 +1159,10 @@ int lt_wavefront_batch(TutuCtx* c, hipStream_t s, BidirParams p) {
 	tp.hitK = w.hitK.p;
 	tp.F = w.F.p;
 	tp.tri_class = c->d_tri_class.p;
-	tp.stack_entries = c->stack_entries;
+	tp.stack_entries = c->ktrace_entries;
+	tp.gstack = w.gstack.p;
 	tp.refill_min = c->knobs.refill_min;
-	tp.inner_steps = c->knobs.inner_steps;
+	tp.inner_steps = c->sc.has_wide ? c->knobs.wide_inner_steps : c->knobs.inner_steps;
 	tp.any_near_first = c->knobs.any_near_first;
 	tp.part = nullptr;
 	tp.defer = w.defer.p;
@@ -1480,11 +1564,12 @@ static int run_trace_kernel(TutuCtx* c, uint32_t n, bool any) {
 	tp.hitK = w.hitK.p;
 	tp.F = w.F.p;
 	tp.tri_class = c->d_tri_class.p;
-	tp.stack_entries = c->stack_entries;
+	tp.stack_entries = c->ktrace_entries;
+	tp.gstack = w.gstack.p;
 	tp.part = nullptr;
 	tp.defer = w.defer.p;
 	tp.refill_min = 1;
-	tp.inner_steps = TUTU_INNER_STEPS;
+	tp.inner_steps = c->sc.has_wide ? c->knobs.wide_inner_steps : TUTU_INNER_STEPS;
 	tp.any_near_first = 1;
 	const int grid = persistent_grid(n, c->n_cu, c->trace_blocks_per_cu);
 	if (any) launch_trace<true>(c, s, grid, tp);
