@@ -756,7 +756,7 @@ __global__ void __launch_bounds__(256) k_shade(PassParams pp) {
 //     the occupancy of the memory-resident scenes (latency-bound: 70 % of their wave-cycles wait for a node) no longer
 //     depends on the tree's depth (round 2: bunny stand-in 7 blocks per CU, broom stand-in 5).
 //   * The reference's leaf boxes (candidate validation) and the class table are part of the LDS scene copy.
-#define TUTU_INNER_STEPS 4
+#define TUTU_INNER_STEPS 3
 #define TUTU_TRAV_IDLE (INT_MIN + 1)
 #define TUTU_STACK_SENTINELS 1
 
@@ -784,13 +784,6 @@ struct TraceParams {
 
 // leaf references are negative and above the two markers: (unsigned)ref > 0x80000001
 TUTU_DEV bool ref_is_leaf(int ref) { return (uint32_t)ref > (uint32_t)TUTU_TRAV_IDLE; }
-
-// pick child reference `slot` (0..3) of a wide node
-TUTU_DEV int wide_pick(uint32_t key, int c0, int c1, int c2, int c3) {
-	const uint32_t s = key & 3u;
-	return s == 0u ? c0 : (s == 1u ? c1 : (s == 2u ? c2 : c3));
-}
-#define TUTU_WIDE_MISS 0xFFFFFFFFu
 
 template <typename S, bool ANY, bool SPH, bool DEEP, bool WIDE>
 TUTU_DEV void trace_persistent(const S& ss, const TraceParams& tp, int* stack, const uint8_t* tri_class) {
@@ -923,8 +916,7 @@ TUTU_DEV void trace_persistent(const S& ss, const TraceParams& tp, int* stack, c
 				if (cur >= 0) {
 					// ---- one node of the WIDE tree: four quantised child boxes in one 64-B fetch (host_scene.hpp: GpuWideNode).
 					// Plane q of axis a lies at t = fma(q, 2^e / d, (p - o) / d): conservative by the margin the host quantised
-					// with (host_scene.cpp: build_wide).  The hit children are ordered by entry distance with a five-comparator
-					// network on packed keys (distance bits | slot), the nearest is entered, the others go to the stack far to near.
+					// with (host_scene.cpp: build_wide).  The nearest hit child is entered, the others go to the stack far to near.
 					n_nodes++;
 					const int p1 = entry_read(sp - 1);
 					const float4 n0 = sc.wnodes[4 * cur + 0], n1 = sc.wnodes[4 * cur + 1], n2 = sc.wnodes[4 * cur + 2], n3 = sc.wnodes[4 * cur + 3];
@@ -935,44 +927,50 @@ TUTU_DEV void trace_persistent(const S& ss, const TraceParams& tp, int* stack, c
 					const float ox = (n0.x - r.o.x) * r.inv.x, oy = (n0.y - r.o.y) * r.inv.y, oz = (n0.z - r.o.z) * r.inv.z;
 					const uint32_t qlx = __float_as_uint(n2.x), qly = __float_as_uint(n2.y), qlz = __float_as_uint(n2.z);
 					const uint32_t qhx = __float_as_uint(n2.w), qhy = __float_as_uint(n3.x), qhz = __float_as_uint(n3.y);
-					uint32_t key[4];
+					float te[4];
+					bool h[4];
 #pragma unroll
 					for (int c = 0; c < 4; c++) {
 						const float ax = fmaf((float)((qlx >> (8 * c)) & 0xFFu), sx, ox), bx = fmaf((float)((qhx >> (8 * c)) & 0xFFu), sx, ox);
 						const float ay = fmaf((float)((qly >> (8 * c)) & 0xFFu), sy, oy), by = fmaf((float)((qhy >> (8 * c)) & 0xFFu), sy, oy);
 						const float az = fmaf((float)((qlz >> (8 * c)) & 0xFFu), sz, oz), bz = fmaf((float)((qhz >> (8 * c)) & 0xFFu), sz, oz);
-						const float te = raw_max3(raw_min(ax, bx), raw_min(ay, by), raw_max(raw_min(az, bz), 0.f));
+						te[c] = raw_max3(raw_min(ax, bx), raw_min(ay, by), raw_max(raw_min(az, bz), 0.f));
 						const float tx = raw_min3(raw_max(ax, bx), raw_max(ay, by), raw_min(raw_max(az, bz), lim));
-						key[c] = te <= tx ? ((__float_as_uint(te) & ~3u) | (uint32_t)c) : TUTU_WIDE_MISS;
-					}
-					{  // ascending: (0,1) (2,3) (0,2) (1,3) (1,2)
-						uint32_t a, b;
-						a = min(key[0], key[1]); b = max(key[0], key[1]); key[0] = a; key[1] = b;
-						a = min(key[2], key[3]); b = max(key[2], key[3]); key[2] = a; key[3] = b;
-						a = min(key[0], key[2]); b = max(key[0], key[2]); key[0] = a; key[2] = b;
-						a = min(key[1], key[3]); b = max(key[1], key[3]); key[1] = a; key[3] = b;
-						a = min(key[1], key[2]); b = max(key[1], key[2]); key[1] = a; key[2] = b;
+						h[c] = te[c] <= tx;
 					}
 					const int c0 = __float_as_int(n1.x), c1 = __float_as_int(n1.y), c2 = __float_as_int(n1.z), c3 = __float_as_int(n1.w);
-					const int r0 = wide_pick(key[0], c0, c1, c2, c3), r1 = wide_pick(key[1], c0, c1, c2, c3);
-					const int r2 = wide_pick(key[2], c0, c1, c2, c3), r3 = wide_pick(key[3], c0, c1, c2, c3);
-					const bool none = key[0] == TUTU_WIDE_MISS;
-					const int v1 = key[1] != TUTU_WIDE_MISS ? 1 : 0, v2 = key[2] != TUTU_WIDE_MISS ? 1 : 0, v3 = key[3] != TUTU_WIDE_MISS ? 1 : 0;
+					// Visiting order = the binary walk's: the nearer PAIR first (slots 0,1 are the children of the binary node's
+					// left child, 2,3 of its right child), inside a pair the nearer slot first.  Three compares, no sort.
+					const bool nf = !ANY || tp.any_near_first;
+					const bool a0 = h[1] && (!h[0] || (nf && te[1] < te[0]));  // pair 0: slot 1 before slot 0
+					const bool a1 = h[3] && (!h[2] || (nf && te[3] < te[2]));
+					const bool hg0 = h[0] || h[1], hg1 = h[2] || h[3];
+					const float tg0 = a0 ? te[1] : te[0], tg1 = a1 ? te[3] : te[2];
+					const bool g = hg1 && (!hg0 || (nf && tg1 < tg0));  // pair 1 before pair 0
+					const int f0 = a0 ? c1 : c0, s0 = a0 ? c0 : c1, f1 = a1 ? c3 : c2, s1 = a1 ? c2 : c3;
+					const bool hs0 = h[0] && h[1], hs1 = h[2] && h[3];  // the pair's second slot is hit as well
+					const int o0 = g ? f1 : f0, o1 = g ? s1 : s0, o2 = g ? f0 : f1, o3 = g ? s0 : s1;
+					const bool b0 = hg0 || hg1;               // the nearest child
+					const bool b1 = g ? hs1 : hs0;            // the near pair's other slot
+					const bool b2 = g ? hg0 : hg1;            // the far pair's first slot  (b2 => b0, b3 => b2)
+					const bool b3 = g ? hs0 : hs1;
+					const int v1 = b1 ? 1 : 0, v2 = b2 ? 1 : 0, v3 = b3 ? 1 : 0;
+					const bool none = !b0;
 					// far to near, unconditionally: a store for a child that was not hit lands on the slot the next store (or a
 					// later push) overwrites -- the stack pointer only moves past the children that were hit
 					if (DEEP && __ballot(sp + 2 >= K) != 0ull) {
-						entry_write(sp, r3);
-						entry_write(sp + v3, r2);
-						entry_write(sp + v3 + v2, r1);
+						entry_write(sp, o3);
+						entry_write(sp + v3, o2);
+						entry_write(sp + v3 + v2, o1);
 					} else {
-						lstack[sp * 256] = r3;
-						lstack[(sp + v3) * 256] = r2;
-						lstack[(sp + v3 + v2) * 256] = r1;
+						lstack[sp * 256] = o3;
+						lstack[(sp + v3) * 256] = o2;
+						lstack[(sp + v3 + v2) * 256] = o1;
 					}
-					const int below = v1 ? r1 : p1;  // what lies under the nearest child
-					const bool park = !none && ref_is_leaf(r0) && pend == TUTU_TRAV_IDLE;
-					pend = park ? r0 : pend;
-					cur = none ? p1 : (park ? below : r0);
+					const int below = b1 ? o1 : (b2 ? o2 : p1);  // what lies under the nearest child
+					const bool park = b0 && ref_is_leaf(o0) && pend == TUTU_TRAV_IDLE;
+					pend = park ? o0 : pend;
+					cur = none ? p1 : (park ? below : o0);
 					sp += v1 + v2 + v3 - ((none || park) ? 1 : 0);
 				}
 				continue;

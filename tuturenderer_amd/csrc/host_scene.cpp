@@ -501,8 +501,8 @@ int build_reference_tree(uint32_t n_tris, const float* verts, std::vector<BuildN
 }
 
 // ---- the wide tree (GpuWideNode, host_scene.hpp): the SAH tree collapsed to four children per node, boxes quantised.
-// Collapse: a node's child set starts as its two children; the inner child with the largest box area is replaced by ITS two
-// children until there are four or only leaves are left.
+// Collapse: a wide node holds the GRANDchildren of a binary node -- slots (0, 1) the children of its left child, (2, 3) of
+// its right child; a child that is a leaf keeps the first slot of its pair.
 // Quantisation margin.  The kernel evaluates a plane at real position X = p + q 2^e as  t_q = fma(q, s, b),  s = 2^e inv
 // (exact), b = fl(fl(p - o) inv); the reference evaluates the true plane x as  t_ref = fl(fl(x - o) inv).  With
 // |delta_i| <= 2^-24:  t_q = [inv (X - o) + inv (p - o) (d1 + d2)] (1 + d3),  t_ref = inv (x - o) (1 + d4 + d5), so the
@@ -511,12 +511,6 @@ int build_reference_tree(uint32_t n_tris, const float* verts, std::vector<BuildN
 // Ray origins are restricted to the scene box grown by 3 extents on every side (other rays are not "plain" and walk the
 // reference's tree): every |. - o| <= 4.01 ext, so m = 6 * 2^-22 * 4.01 ext ~ 5.8e-6 ext covers it with a factor 2 to spare.
 // Exponents are clamped to [-60, 60] and plain rays have 2^-60 <= |inv| <= 2^60, so s is a normal number.
-namespace {
-double wide_area(const BuildNode& b) {
-	const double dx = (double)b.pmax[0] - b.pmin[0], dy = (double)b.pmax[1] - b.pmin[1], dz = (double)b.pmax[2] - b.pmin[2];
-	return dx * dy + dy * dz + dz * dx;
-}
-}  // namespace
 
 // t: build tree (pre-order, t[0] = root, must be an inner node); leaf_ref(bn) = the device reference of leaf bn
 template <typename LeafRef>
@@ -548,24 +542,22 @@ static bool build_wide(const std::vector<BuildNode>& t, const LeafRef& leaf_ref,
 	for (size_t qi = 0; qi < queue.size(); qi++) {
 		const Item it = queue[qi];
 		max_level = std::max(max_level, it.level);
-		std::array<int32_t, 4> ch = {t[it.bn].left, t[it.bn].right, -1, -1};
-		int n = 2;
-		while (n < 4) {
-			int best = -1;
-			double best_area = -1;
-			for (int k = 0; k < n; k++)
-				if (is_inner(ch[k]) && wide_area(t[ch[k]]) > best_area) {
-					best_area = wide_area(t[ch[k]]);
-					best = k;
-				}
-			if (best < 0) break;
-			const int32_t bn = ch[best];
-			ch[best] = t[bn].left;
-			ch[n++] = t[bn].right;
+		// slots (0, 1) = the children of the left child, (2, 3) = of the right child (a child that is a leaf keeps its pair's
+		// first slot, the second stays unused): the kernel orders the PAIRS by entry distance, then the two slots of a pair
+		// -- the order the binary walk visits them in -- with three compares instead of a four-key sort
+		std::array<int32_t, 4> ch = {-1, -1, -1, -1};
+		const int32_t two[2] = {t[it.bn].left, t[it.bn].right};
+		for (int g = 0; g < 2; g++) {
+			if (is_inner(two[g])) {
+				ch[2 * g] = t[two[g]].left;
+				ch[2 * g + 1] = t[two[g]].right;
+			} else {
+				ch[2 * g] = two[g];
+			}
 		}
 		kids.push_back(ch);
-		for (int k = 0; k < n; k++)
-			if (is_inner(ch[k])) queue.push_back({ch[k], next_id++, it.level + 1});
+		for (int k = 0; k < 4; k++)
+			if (ch[k] >= 0 && is_inner(ch[k])) queue.push_back({ch[k], next_id++, it.level + 1});
 	}
 	hs.wnodes.resize(queue.size());
 	// ids were handed out in queue order: the children of queue[qi] that are inner got consecutive ids
@@ -575,13 +567,12 @@ static bool build_wide(const std::vector<BuildNode>& t, const LeafRef& leaf_ref,
 		const std::array<int32_t, 4>& ch = kids[qi];
 		GpuWideNode& w = hs.wnodes[queue[qi].id];
 		memset(&w, 0, sizeof(w));
-		int n = 0;
-		while (n < 4 && ch[n] >= 0) n++;
 		double lo[3], hi[3];
 		for (int a = 0; a < 3; a++) {
 			lo[a] = 1e300;
 			hi[a] = -1e300;
-			for (int k = 0; k < n; k++) {
+			for (int k = 0; k < 4; k++) {
+				if (ch[k] < 0) continue;
 				lo[a] = std::min(lo[a], (double)t[ch[k]].pmin[a] - m);
 				hi[a] = std::max(hi[a], (double)t[ch[k]].pmax[a] + m);
 			}
@@ -599,7 +590,7 @@ static bool build_wide(const std::vector<BuildNode>& t, const LeafRef& leaf_ref,
 			e[a] = ea;
 			for (int k = 0; k < 4; k++) {
 				uint32_t ql, qh;
-				if (k < n) {
+				if (ch[k] >= 0) {
 					const double l = ((double)t[ch[k]].pmin[a] - m - (double)pf), h = ((double)t[ch[k]].pmax[a] + m - (double)pf);
 					ql = (uint32_t)std::max(0.0, std::min(255.0, std::floor(std::ldexp(l, -ea))));
 					qh = (uint32_t)std::max(0.0, std::min(255.0, std::ceil(std::ldexp(h, -ea))));
@@ -615,18 +606,20 @@ static bool build_wide(const std::vector<BuildNode>& t, const LeafRef& leaf_ref,
 		}
 		w.exps = (uint32_t)(e[0] + 128) | ((uint32_t)(e[1] + 128) << 8) | ((uint32_t)(e[2] + 128) << 16);
 		int32_t any_leaf = INT_MIN;
-		for (int k = 0; k < n; k++) {
+		for (int k = 0; k < 4; k++) {
+			if (ch[k] < 0) continue;
 			w.child[k] = is_inner(ch[k]) ? id_of[ch[k]] : leaf_ref(ch[k]);
 			if (!is_inner(ch[k]) && any_leaf == INT_MIN) any_leaf = w.child[k];
 		}
-		if (n < 4) {
+		if (ch[1] < 0 || ch[3] < 0) {
 			// an unused slot refers to a leaf of this node's own subtree: find one
 			int32_t bn = ch[0];
 			while (any_leaf == INT_MIN) {
 				if (is_inner(bn)) bn = t[bn].left;
 				else any_leaf = leaf_ref(bn);
 			}
-			for (int k = n; k < 4; k++) w.child[k] = any_leaf;
+			for (int k = 0; k < 4; k++)
+				if (ch[k] < 0) w.child[k] = any_leaf;
 		}
 	}
 	hs.wide_depth = max_level;

@@ -98,10 +98,10 @@ struct TutuCtx {
 		int one_set = 0;          // TUTU_ONE_SET        profiling aid: one work set              {0, 1}
 		int shade_bpc = 0;        // TUTU_SHADE_BPC      shade blocks per CU (persistent grid), 0 = by kernel  [0, 16]
 		int trace_bpc = 0;        // TUTU_TRACE_BPC      traversal blocks per CU, 0 = by LDS use  [0, 8]
-		int refill_min = 16;      // TUTU_REFILL_MIN     idle lanes before a wave refills         [1, 64]
+		int refill_min = 24;      // TUTU_REFILL_MIN     idle lanes before a wave refills         [1, 64]
 		int inner_steps = TUTU_INNER_STEPS;  // TUTU_INNER_STEPS node visits per round            [1, 64]
 		int wide = 1;             // TUTU_WIDE           four-wide quantised tree: 0 never, 1 for big trees, 2 always  [0, 2]
-		int wide_min_mb = 16;     // TUTU_WIDE_MIN_MB    ... "big" = at least this many MB of binary nodes  [0, 65536]
+		int wide_min_mb = 0;      // TUTU_WIDE_MIN_MB    ... "big" = at least this many MB of binary nodes  [0, 65536]
 		int wide_inner_steps = 2; // TUTU_WIDE_INNER_STEPS node visits per round on the wide tree  [1, 64]
 		int lds_stack_max = 32;   // TUTU_LDS_STACK_MAX  k_trace, binary tree: entries of the LDS tier of a deep tree's stack, 0 = all in LDS  [0, 64]
 		int wide_lds_stack = 19;  // TUTU_WIDE_LDS_STACK k_trace, wide tree: entries of the LDS tier (19 KB: eight blocks per CU)  [4, 64]
@@ -787,11 +787,11 @@ int tutu_hip_create(const TutuSceneDesc* scene, int device, TutuCtx** out) {
 	// walked by the one-ray-per-lane loops after the main loop) must fit the LDS tier.
 	c->ktrace_entries = c->stack_entries;
 	c->ktrace_deep = 0;
-	// The wide tree pays where the walked tree does not fit the L2s (4 MB per XCD): a ray then moves half the bytes in
-	// half the round trips (broom stand-in, 42 MB of binary nodes: +37 %).  On trees that do fit, the binary walk waits
-	// for L2 hits with 35-40 % of the vector issue slots in use and the wide node's decode + ordering (2.6 x the vector
-	// instructions per step for 0.55 x the steps) turns it issue-bound for no gain (bunny stand-in, veach room: -0..5 %).
-	// TUTU_WIDE: 0 never, 1 by size (>= TUTU_WIDE_MIN_MB of binary nodes), 2 always.
+	// The wide tree pays most where the walked tree does not fit the L2s (4 MB per XCD): a ray then moves half the bytes in
+	// half the round trips (broom stand-in, 42 MB of binary nodes: +37 %); on trees that do fit it is a few per cent (bunny
+	// stand-in +4 %, veach room +3 %: the binary walk waits for L2 hits with 35-40 % of the vector issue slots in use, the wide
+	// node needs about as many vector instructions as the two binary nodes it replaces).
+	// TUTU_WIDE: 0 never, 1 by size (>= TUTU_WIDE_MIN_MB of binary nodes; default 0 MB = every memory-resident scene), 2 always.
 	const size_t walked_mb = ((size_t)c->hs.n_fast_inner * sizeof(GpuNode)) >> 20;
 	sc.has_wide = (!c->lds_scene && c->hs.has_wide && (c->knobs.wide == 2 || (c->knobs.wide == 1 && walked_mb >= (size_t)c->knobs.wide_min_mb))) ? 1 : 0;
 	if (sc.has_wide) {
