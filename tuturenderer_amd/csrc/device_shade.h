@@ -1017,6 +1017,8 @@ TUTU_DEV void trace_persistent(const S& ss, const TraceParams& tp, int* stack, c
 				if (ANY) cand = h && t < dis && !float_equal(t, dis);  // BVH.hpp:186
 				else cand = h && (t < best_t || (t == best_t && ti < best_tri));
 				if (cand) {  // validated against the reference's leaf box (BVH.hpp:150; device_trace.h)
+					// (requesting the box together with the intersection record -- no second dependent round trip -- was
+					// measured: eight more live registers in the 64-register loop spill, -10 % on every scene)
 					float4 lo, hi;
 					ss.lbox(ti, lo, hi);
 					float te;
