@@ -4,6 +4,7 @@
 
 #include <algorithm>
 #include <array>
+#include <atomic>
 #include <chrono>
 #include <climits>
 #include <cmath>
@@ -355,7 +356,7 @@ struct SahBuilder {
 		return id;
 	}
 	bool serial = getenv("TUTU_BUILD_SERIAL") != nullptr;  // one thread (the tree is the same either way)
-	int sweep_max = getenv("TUTU_SWEEP_MAX") ? atoi(getenv("TUTU_SWEEP_MAX")) : 64;  // nodes of at most this many objects: exact SAH sweep
+	int sweep_max = getenv("TUTU_SWEEP_MAX") ? std::max(0, std::min(4096, atoi(getenv("TUTU_SWEEP_MAX")))) : 64;  // nodes of at most this many objects: exact SAH sweep
 	static constexpr size_t kForkMin = 32768;   // objects below which a subtree is not worth a thread
 	static constexpr uint32_t kForkDepth = 4;   // at most 2^4 threads
 };
@@ -423,13 +424,13 @@ static void poly_bounds(const Poly& q, double lo[3], double hi[3]) {
 			hi[k] = std::max(hi[k], q.p[i][k]);
 		}
 }
-static double kSplitGain = 0.70;    // (0.66 / 64 pieces at first; swept on the two scenes that have slivers: 16 pieces at 0.70 are
-static int kMaxPiecesPerTri = 16;   //  +16 % on the broom stand-in, +9 % on the veach room -- fewer, deeper-cut references)
+static const double kSplitGain = 0.70;    // (0.66 / 64 pieces at first; swept on the two scenes that have slivers: 16 pieces at 0.70 are
+static const int kMaxPiecesPerTri = 16;   //  +16 % on the broom stand-in, +9 % on the veach room -- fewer, deeper-cut references)
 static double box_half_area(const double lo[3], const double hi[3]) {
 	const double d[3] = {hi[0] - lo[0], hi[1] - lo[1], hi[2] - lo[2]};
 	return d[0] * d[1] + d[1] * d[2] + d[2] * d[0];
 }
-static void split_piece(const Poly& q, int budget, double pad, int32_t obj, std::vector<Ref>& out) {
+static void split_piece(const Poly& q, int budget, double pad, double gain, int32_t obj, std::vector<Ref>& out) {
 	double lo[3], hi[3];
 	poly_bounds(q, lo, hi);
 	const double d[3] = {hi[0] - lo[0], hi[1] - lo[1], hi[2] - lo[2]};
@@ -444,9 +445,9 @@ static void split_piece(const Poly& q, int budget, double pad, int32_t obj, std:
 			double la[3], ha[3], lb[3], hb[3];
 			poly_bounds(a, la, ha);
 			poly_bounds(b, lb, hb);
-			if (box_half_area(la, ha) + box_half_area(lb, hb) <= kSplitGain * half_area) {
-				split_piece(a, budget / 2, pad, obj, out);
-				split_piece(b, budget - budget / 2, pad, obj, out);
+			if (box_half_area(la, ha) + box_half_area(lb, hb) <= gain * half_area) {
+				split_piece(a, budget / 2, pad, gain, obj, out);
+				split_piece(b, budget - budget / 2, pad, gain, obj, out);
 				return;
 			}
 		}
@@ -563,7 +564,9 @@ static bool build_wide(const std::vector<BuildNode>& t, const LeafRef& leaf_ref,
 	// ids were handed out in queue order: the children of queue[qi] that are inner got consecutive ids
 	std::vector<int32_t> id_of(t.size(), -1);
 	for (const Item& it : queue) id_of[it.bn] = it.id;
-	for (size_t qi = 0; qi < queue.size(); qi++) {
+	std::atomic<bool> failed{false};
+	auto quantise = [&](size_t q0, size_t q1) {
+	for (size_t qi = q0; qi < q1; qi++) {
 		const std::array<int32_t, 4>& ch = kids[qi];
 		GpuWideNode& w = hs.wnodes[queue[qi].id];
 		memset(&w, 0, sizeof(w));
@@ -586,7 +589,7 @@ static bool build_wide(const std::vector<BuildNode>& t, const LeafRef& leaf_ref,
 			int ea = (int)std::ceil(std::log2(std::max(span, 1e-300) / 255.0));
 			while (std::ldexp(255.0, ea) < span) ea++;
 			ea = std::max(-60, std::min(60, ea));
-			if (std::ldexp(255.0, ea) < span) return false;  // (cannot happen with the extent check above)
+			if (std::ldexp(255.0, ea) < span) { failed = true; return; }  // (cannot happen with the extent check above)
 			e[a] = ea;
 			for (int k = 0; k < 4; k++) {
 				uint32_t ql, qh;
@@ -596,7 +599,7 @@ static bool build_wide(const std::vector<BuildNode>& t, const LeafRef& leaf_ref,
 					qh = (uint32_t)std::max(0.0, std::min(255.0, std::ceil(std::ldexp(h, -ea))));
 					// the guarantees the kernel's exactness argument rests on
 					if ((double)pf + std::ldexp((double)ql, ea) > (double)t[ch[k]].pmin[a] - m || (double)pf + std::ldexp((double)qh, ea) < (double)t[ch[k]].pmax[a] + m)
-						return false;
+						{ failed = true; return; }
 				} else {
 					ql = qh = 255u;  // unused slot: a point at the frame's far corner
 				}
@@ -620,6 +623,20 @@ static bool build_wide(const std::vector<BuildNode>& t, const LeafRef& leaf_ref,
 			}
 			for (int k = 0; k < 4; k++)
 				if (ch[k] < 0) w.child[k] = any_leaf;
+		}
+	}
+	};
+	{
+		// the nodes are independent: ranges of them on their own threads
+		const size_t nq = queue.size();
+		const uint32_t n_thr = (nq >= 65536 && !getenv("TUTU_BUILD_SERIAL")) ? std::min<uint32_t>(16, std::max<uint32_t>(1, std::thread::hardware_concurrency())) : 1;
+		std::vector<std::thread> pool;
+		for (uint32_t k = 1; k < n_thr; k++) pool.emplace_back(quantise, nq * k / n_thr, nq * (k + 1) / n_thr);
+		quantise(0, nq / n_thr);
+		for (std::thread& th : pool) th.join();
+		if (failed) {
+			hs.wnodes.clear();
+			return false;
 		}
 	}
 	hs.wide_depth = max_level;
@@ -692,6 +709,82 @@ int build_host_scene(const TutuSceneDesc* d, HostScene& hs) {
 	for (uint32_t o = 0; o < n; o++)
 		tb[o] = obj_sph[o] >= 0 ? sphere_box(ss->spheres + 4 * (size_t)obj_sph[o]) : triangle_box(d->verts + 9 * (size_t)obj_tri[o]);
 	lap("objects, boxes, materials");
+	// The walked tree (references + SAH build) needs the object boxes only: it is built on its own thread(s) BESIDE the
+	// reference's tree, and joined where it is flattened (the leaf references need the reference tree's leaf order).
+	const bool want_sah = n > 2 && !getenv("TUTU_NO_SAH");
+	std::vector<Ref> refs;
+	std::vector<BuildNode> sah;
+	uint32_t sah_depth = 0;
+	int walked_rc = TUTU_OK;
+	std::thread walked([&] {
+		if (!want_sah) return;
+		// references: one per object, several for sliver / tilted triangles (early split clipping, above)
+		refs.reserve(n);
+		const bool presplit = !getenv("TUTU_NO_PRESPLIT");
+		double diag = 0;  // the largest extent of the scene box (= the reference tree's root box: the union of all object boxes)
+		if (n > 0) {
+			Box all = tb[0];
+			for (uint32_t o = 1; o < n; o++) all = box_union(all, tb[o]);
+			for (int k = 0; k < 3; k++) diag = std::max(diag, (double)all.mx[k] - (double)all.mn[k]);
+		}
+		const double pad = 4e-6 * diag;
+		// The extra references of a scene are capped (a mesh of a million slivers would otherwise grow 64-fold: tree memory
+		// and build time go with the reference count): when the cap is exceeded the per-triangle limit is halved and the
+		// references are generated again.  4 Mi extra references ~ 0.5 GB of nodes and a few seconds of build.
+		// (environment overrides for experiments and tests; none of them can change a hit, only the walked tree)
+		// (locals: contexts may be created on several host threads at once)
+		int max_pieces = kMaxPiecesPerTri;
+		double gain = kSplitGain;
+		if (const char* e = getenv("TUTU_SPLIT_MAX")) max_pieces = std::max(1, std::min(4096, atoi(e)));
+		if (const char* e = getenv("TUTU_SPLIT_GAIN")) gain = std::max(0.3, std::min(0.99, atof(e)));
+		const size_t extra_cap = (size_t)(getenv("TUTU_SPLIT_CAP_MI") ? std::max(0, std::min(64, atoi(getenv("TUTU_SPLIT_CAP_MI")))) : 4) << 20;
+		for (int per_tri = max_pieces; per_tri >= 1; per_tri /= 2) {
+			// object ranges on their own threads, each into its own list, concatenated in object order (the same list as one thread makes)
+			const uint32_t n_thr = (n >= 65536 && !getenv("TUTU_BUILD_SERIAL")) ? std::min<uint32_t>(16, std::max<uint32_t>(1, std::thread::hardware_concurrency())) : 1;
+			std::vector<std::vector<Ref>> part(n_thr);
+			auto work = [&](uint32_t t) {
+				std::vector<Ref>& out_refs = part[t];
+				const uint32_t o0 = (uint32_t)((uint64_t)n * t / n_thr), o1 = (uint32_t)((uint64_t)n * (t + 1) / n_thr);
+				out_refs.reserve(o1 - o0);
+				for (uint32_t o = o0; o < o1; o++) {
+					if (obj_sph[o] >= 0 || !presplit || per_tri == 1) {
+						out_refs.push_back(Ref{tb[o], (int32_t)o});
+						continue;
+					}
+					const float* v = d->verts + 9 * (size_t)obj_tri[o];
+					bool finite = true;
+					for (int k = 0; k < 9; k++) finite = finite && std::isfinite(v[k]);
+					Poly q;
+					q.n = 3;
+					for (int i = 0; i < 3; i++)
+						for (int k = 0; k < 3; k++) q.p[i][k] = v[3 * i + k];
+					const size_t before = out_refs.size();
+					if (finite) split_piece(q, per_tri, pad, gain, (int32_t)o, out_refs);
+					if (out_refs.size() == before + 1 || !finite) {  // not split: keep the object's own box (exactly the reference's leaf box)
+						out_refs.resize(before);
+						out_refs.push_back(Ref{tb[o], (int32_t)o});
+					}
+				}
+			};
+			std::vector<std::thread> pool;
+			for (uint32_t t = 1; t < n_thr; t++) pool.emplace_back(work, t);
+			work(0);
+			for (std::thread& th : pool) th.join();
+			refs.clear();
+			for (uint32_t t = 0; t < n_thr; t++) refs.insert(refs.end(), part[t].begin(), part[t].end());
+			if (refs.size() <= (size_t)n + extra_cap) break;
+		}
+		std::vector<Box> rb(refs.size());
+		for (size_t i = 0; i < refs.size(); i++) rb[i] = refs[i].box;
+		hs.n_refs = (uint32_t)refs.size();
+		walked_rc = build_sah_tree(rb, sah, &sah_depth);
+	});
+	struct Joiner {  // every early return below must not leave the thread running
+		std::thread& t;
+		~Joiner() {
+			if (t.joinable()) t.join();
+		}
+	} joiner{walked};
 	rc = build_tree_of_boxes(tb, tree, &hs.depth);
 	if (rc != TUTU_OK) return rc;
 	if (hs.depth > TUTU_MAX_BVH_DEPTH) return TUTU_E_BVH_DEPTH;
@@ -752,68 +845,11 @@ int build_host_scene(const TutuSceneDesc* d, HostScene& hs) {
 	// The tree the kernels walk first in the node array (so that a partial LDS copy holds ITS top), then the
 	// reference's own tree, which rays with a zero / non-finite direction component fall back to.
 	lap("reference tree");
-	const bool want_sah = n > 2 && !getenv("TUTU_NO_SAH");
 	hs.has_fast_tree = false;
 	if (want_sah) {
-		// references: one per object, several for sliver / tilted triangles (early split clipping, above)
-		std::vector<Ref> refs;
-		refs.reserve(n);
-		const bool presplit = !getenv("TUTU_NO_PRESPLIT");
-		double diag = 0;
-		if (!tree.empty())
-			for (int k = 0; k < 3; k++) diag = std::max(diag, (double)tree[0].pmax[k] - (double)tree[0].pmin[k]);
-		const double pad = 4e-6 * diag;
-		// The extra references of a scene are capped (a mesh of a million slivers would otherwise grow 64-fold: tree memory
-		// and build time go with the reference count): when the cap is exceeded the per-triangle limit is halved and the
-		// references are generated again.  4 Mi extra references ~ 0.5 GB of nodes and a few seconds of build.
-		// (environment overrides for experiments and tests; none of them can change a hit, only the walked tree)
-		if (const char* e = getenv("TUTU_SPLIT_MAX")) kMaxPiecesPerTri = std::max(1, std::min(4096, atoi(e)));
-		if (const char* e = getenv("TUTU_SPLIT_GAIN")) kSplitGain = std::max(0.3, std::min(0.99, atof(e)));
-		const size_t extra_cap = (size_t)(getenv("TUTU_SPLIT_CAP_MI") ? std::max(0, std::min(64, atoi(getenv("TUTU_SPLIT_CAP_MI")))) : 4) << 20;
-		for (int per_tri = kMaxPiecesPerTri; per_tri >= 1; per_tri /= 2) {
-			// object ranges on their own threads, each into its own list, concatenated in object order (the same list as one thread makes)
-			const uint32_t n_thr = (n >= 65536 && !getenv("TUTU_BUILD_SERIAL")) ? std::min<uint32_t>(16, std::max<uint32_t>(1, std::thread::hardware_concurrency())) : 1;
-			std::vector<std::vector<Ref>> part(n_thr);
-			auto work = [&](uint32_t t) {
-				std::vector<Ref>& out_refs = part[t];
-				const uint32_t o0 = (uint32_t)((uint64_t)n * t / n_thr), o1 = (uint32_t)((uint64_t)n * (t + 1) / n_thr);
-				out_refs.reserve(o1 - o0);
-				for (uint32_t o = o0; o < o1; o++) {
-					if (obj_sph[o] >= 0 || !presplit || per_tri == 1) {
-						out_refs.push_back(Ref{tb[o], (int32_t)o});
-						continue;
-					}
-					const float* v = d->verts + 9 * (size_t)obj_tri[o];
-					bool finite = true;
-					for (int k = 0; k < 9; k++) finite = finite && std::isfinite(v[k]);
-					Poly q;
-					q.n = 3;
-					for (int i = 0; i < 3; i++)
-						for (int k = 0; k < 3; k++) q.p[i][k] = v[3 * i + k];
-					const size_t before = out_refs.size();
-					if (finite) split_piece(q, per_tri, pad, (int32_t)o, out_refs);
-					if (out_refs.size() == before + 1 || !finite) {  // not split: keep the object's own box (exactly the reference's leaf box)
-						out_refs.resize(before);
-						out_refs.push_back(Ref{tb[o], (int32_t)o});
-					}
-				}
-			};
-			std::vector<std::thread> pool;
-			for (uint32_t t = 1; t < n_thr; t++) pool.emplace_back(work, t);
-			work(0);
-			for (std::thread& th : pool) th.join();
-			refs.clear();
-			for (uint32_t t = 0; t < n_thr; t++) refs.insert(refs.end(), part[t].begin(), part[t].end());
-			if (refs.size() <= (size_t)n + extra_cap) break;
-		}
-		lap("references (split clipping)");
-		std::vector<Box> rb(refs.size());
-		for (size_t i = 0; i < refs.size(); i++) rb[i] = refs[i].box;
-		hs.n_refs = (uint32_t)refs.size();
-		std::vector<BuildNode> sah;
-		uint32_t sah_depth = 0;
-		rc = build_sah_tree(rb, sah, &sah_depth);
-		lap("walked tree (SAH)");
+		walked.join();  // references + SAH tree were built beside the reference tree (above)
+		lap("walked tree (references + SAH), joined");
+		rc = walked_rc;
 		if (rc != TUTU_OK) return rc;
 		for (BuildNode& bn : sah)
 			if (bn.tri >= 0) bn.tri = refs[(size_t)bn.tri].obj;  // a leaf says which OBJECT to test
