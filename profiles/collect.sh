@@ -20,7 +20,7 @@ if [ "$STAGE" = "pmc" ]; then
   grep "^{" $O/bench_under_rocprof.log > $O/bench_line_under_rocprof.json
   # the same command with ONE pass in flight (kernels run one at a time: exclusive per-launch durations, cf. the bench line's roofline)
   (cd /tmp && export TUTU_SETS=1 && rocprofv3 --kernel-trace --stats --output-format csv -d $O/rocprof_exclusive -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras > $O/bench_exclusive_under_rocprof.log 2>&1); echo "rocprof exclusive rc=$?"
-  for a in "c2 76 19" "c3 24 12" "c4 16 8" "c5 52 26"; do set -- $a; bash profiles/run_pmc.sh $TAG $1 $2 $3 > $O/pmc_$1.log 2>&1; echo "pmc $1 rc=$?"; done
+  for a in "c2 76 19" "c3 22 11" "c4 16 8" "c5 52 26"; do  # <config> <spp> <spp per pass as bench.py sizes it at the full spp> set -- $a; bash profiles/run_pmc.sh $TAG $1 $2 $3 > $O/pmc_$1.log 2>&1; echo "pmc $1 rc=$?"; done
 else
   for c in c2 c1 c3 c5; do
     timeout -k 10 400 python bench.py --config $c --steps 3 --warmup 1 > $O/bench_$c.log 2>&1; echo "bench $c rc=$?"
