@@ -333,7 +333,13 @@ int tutu_hip_quantise(TutuCtx* ctx, uint32_t n, const float* values, int32_t* le
  *   "trace_bpc" TUTU_TRACE_BPC [0,8] (0 = from the LDS footprint) | "refill_min" TUTU_REFILL_MIN [1,64] |
  *   "inner_steps" TUTU_INNER_STEPS [1,64] | "any_near_first" TUTU_ANY_NEAR_FIRST {0,1} |
  *   "util_stats" TUTU_UTIL_STATS {0,1} | "bidir_units" TUTU_BIDIR_UNITS [64, 2^24] ((pixel, sample) units per batch of
- *   tutu_hip_render_integrator; batches are whole pixels).
+ *   tutu_hip_render_integrator; batches are whole pixels) |
+ *   "wide" TUTU_WIDE [0,2] (memory-resident scenes: 0 walk the binary SAH tree, 1 the four-wide quantised tree when the binary
+ *   nodes take at least "wide_min_mb" TUTU_WIDE_MIN_MB [0,65536] megabytes (default 0: always), 2 always) |
+ *   "wide_inner_steps" TUTU_WIDE_INNER_STEPS [1,64] | "wide_lds_stack" TUTU_WIDE_LDS_STACK [4,64] and "lds_stack_max"
+ *   TUTU_LDS_STACK_MAX [0,64]: entries of the traversal stack kept in LDS (wide / binary tree); deeper ones live in HBM.
+ *   Read-only facts: "wide_tree", "wide_depth", "fast_depth", "stack_entries", "stack_entries_hbm", "trace_blocks_per_cu",
+ *   "trace_lds_bytes".
  * tutu_hip_get_option reports the effective value of any of them, plus the read-only facts "sah_tree", "lds_scene"
  * and "shade_tab" -- a benchmark line should echo them (bench.py does). */
 int tutu_hip_set_option(TutuCtx* ctx, const char* name, int value);

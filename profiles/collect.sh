@@ -1,11 +1,12 @@
 #!/bin/bash
 # Refreshes everything under profiles/ for a tag, in TWO gpurun calls (the bench lines quote profiles/traffic.json, which is
 # made from the first call's PMC passes):
-#   gpurun -- 'bash profiles/collect.sh <tag> pmc'     GPU tests; rocprofv3 kernel stats of the default bench command, four
-#                                                      passes overlapped and with one pass in flight; PMC passes for c2..c5
+#   gpurun -- 'bash profiles/collect.sh <tag> pmc'     GPU tests; PMC passes for c2..c5
 #   bash profiles/publish.sh <tag> pmc                 (here: traffic.json, PMC summaries, kernel stats -> profiles/)
-#   gpurun -- 'bash profiles/collect.sh <tag> lines'   bench lines of all five configs with the reference CPU baseline,
-#                                                      shard balance of an 8-way split (c2, c4), the other integrators
+#   gpurun -- 'bash profiles/collect.sh <tag> lines'   rocprofv3 kernel stats of the default bench command (four passes overlapped
+#                                                      and with one pass in flight); bench lines of all five configs with the
+#                                                      reference CPU baseline; shard balance of an 8-way split (c2, c4); the
+#                                                      other integrators
 #   bash profiles/publish.sh <tag> lines
 TAG=${1:-r03}
 STAGE=${2:-pmc}
@@ -16,12 +17,14 @@ cd $R
 export TMPDIR=/tmp
 if [ "$STAGE" = "pmc" ]; then
   timeout -k 10 900 python -m pytest tests -m gpu -q > $O/gpu_tests.log 2>&1; echo "tests rc=$?" | tee -a $O/gpu_tests.log
+  # <config> <spp> <spp per pass, as bench.py sizes it at the config's full spp: bench.py refuses counters of another pass size>
+  for a in "c2 76 19" "c3 22 11" "c4 16 8" "c5 52 26"; do set -- $a; bash profiles/run_pmc.sh $TAG $1 $2 $3 > $O/pmc_$1.log 2>&1; echo "pmc $1 rc=$?"; done
+else
+  # (the rocprofv3 runs sit in THIS stage so that their per-kernel averages and the bench lines' avg_launch_ms come from one box)
   (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $O/rocprof -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras > $O/bench_under_rocprof.log 2>&1); echo "rocprof rc=$?"
   grep "^{" $O/bench_under_rocprof.log > $O/bench_line_under_rocprof.json
   # the same command with ONE pass in flight (kernels run one at a time: exclusive per-launch durations, cf. the bench line's roofline)
   (cd /tmp && export TUTU_SETS=1 && rocprofv3 --kernel-trace --stats --output-format csv -d $O/rocprof_exclusive -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras > $O/bench_exclusive_under_rocprof.log 2>&1); echo "rocprof exclusive rc=$?"
-  for a in "c2 76 19" "c3 22 11" "c4 16 8" "c5 52 26"; do  # <config> <spp> <spp per pass as bench.py sizes it at the full spp> set -- $a; bash profiles/run_pmc.sh $TAG $1 $2 $3 > $O/pmc_$1.log 2>&1; echo "pmc $1 rc=$?"; done
-else
   for c in c2 c1 c3 c5; do
     timeout -k 10 400 python bench.py --config $c --steps 3 --warmup 1 > $O/bench_$c.log 2>&1; echo "bench $c rc=$?"
   done
