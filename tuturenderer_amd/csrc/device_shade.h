@@ -756,7 +756,7 @@ __global__ void __launch_bounds__(256) k_shade(PassParams pp) {
 //     the occupancy of the memory-resident scenes (latency-bound: 70 % of their wave-cycles wait for a node) no longer
 //     depends on the tree's depth (round 2: bunny stand-in 7 blocks per CU, broom stand-in 5).
 //   * The reference's leaf boxes (candidate validation) and the class table are part of the LDS scene copy.
-#define TUTU_INNER_STEPS 3
+#define TUTU_INNER_STEPS 6
 #define TUTU_TRAV_IDLE (INT_MIN + 1)
 #define TUTU_STACK_SENTINELS 1
 
@@ -779,6 +779,7 @@ struct TraceParams {
 	int refill_min;  // idle lanes a wave waits for before it fetches new rays (1 = refill at once)
 	int inner_steps;  // node visits between two leaf / finish / refill rounds
 	int any_near_first;  // any-hit: descend into the nearer child first
+	int leaf_again;      // lanes that must still hold a leaf for a second leaf step in the round (65: never)
 	uint32_t* defer;     // >= *n_ptr entries: list positions of the rays that are not plain, per wave range (below)
 };
 
@@ -1002,17 +1003,28 @@ TUTU_DEV void trace_persistent(const S& ss, const TraceParams& tp, int* stack, c
 			}
 		}
 
-		// ---- leaf: the parked leaf, or the leaf the lane sits on
-		{
+		// ---- leaf: the parked leaf, or the leaf the lane sits on (a second time in the round while at least `leaf_again` lanes
+		// still hold one: pair leaves make a ray's leaf tests outnumber a third of its node steps)
+#pragma unroll 1
+		for (int lk = 0; lk < 2; lk++) {
 			const bool has_pend = pend != TUTU_TRAV_IDLE;
 			const bool on_leaf = ref_is_leaf(cur);
-			if (__ballot(has_pend || on_leaf) != 0ull) w_leaf_steps++;
+			const unsigned long long m_leaf = __ballot(has_pend || on_leaf);
+			if (m_leaf == 0ull || (lk > 0 && __popcll(m_leaf) < tp.leaf_again)) break;
+			w_leaf_steps++;
 			if (has_pend || on_leaf) {
 				n_leaves++;
 				const int p1 = entry_read(sp - 1);
 				int ti;
 				float t, u, v;
-				const bool h = leaf_test<SPH>(ss, has_pend ? ~pend : ~cur, r, ti, t, u, v);
+				// (a leaf of a small scene's walked tree may name two objects -- the triangles of a quad: the first is tested now,
+				// the second stays parked for the next leaf step)
+				int item = has_pend ? ~pend : ~cur, second = 0;
+				if (!WIDE && !SPH && sc.pair_leaves) {
+					second = item >> TUTU_PAIR_BITS;
+					item &= (1 << TUTU_PAIR_BITS) - 1;
+				}
+				const bool h = leaf_test<SPH>(ss, item, r, ti, t, u, v);
 				bool cand;
 				if (ANY) cand = h && t < dis && !float_equal(t, dis);  // BVH.hpp:186
 				else cand = h && (t < best_t || (t == best_t && ti < best_tri));
@@ -1030,10 +1042,16 @@ TUTU_DEV void trace_persistent(const S& ss, const TraceParams& tp, int* stack, c
 						}
 					}
 				}
-				// the leaf the lane sits on was either tested (nothing was parked) or moves into the parking slot
-				pend = (has_pend && on_leaf) ? cur : TUTU_TRAV_IDLE;
-				cur = on_leaf ? p1 : cur;
-				sp -= on_leaf ? 1 : 0;
+				if (second != 0) {
+					// the pair's second object takes the leaf's place: where it was parked, or where the lane sits
+					if (has_pend) pend = ~(second - 1);
+					else cur = ~(second - 1);
+				} else {
+					// the leaf the lane sits on was either tested (nothing was parked) or moves into the parking slot
+					pend = (has_pend && on_leaf) ? cur : TUTU_TRAV_IDLE;
+					cur = on_leaf ? p1 : cur;
+					sp -= on_leaf ? 1 : 0;
+				}
 				if (ANY && blocked) {
 					cur = TUTU_TRAV_DONE;
 					pend = TUTU_TRAV_IDLE;

@@ -30,6 +30,7 @@ namespace tutu {
 #define TUTU_STACK_DEPTH 32
 #define TUTU_PRUNE_SLACK 1.0001f
 #define TUTU_TRAV_DONE INT_MIN
+#define TUTU_PAIR_BITS 14
 
 struct SceneDev {
 	const float4* nodes;      // 4 x float4 per inner node (GpuNode)
@@ -56,6 +57,7 @@ struct SceneDev {
 	int root_ref_exact;
 	int has_fast;
 	const float4* leaf_boxes;  // 2 x float4 per leaf (leaf order): min xyz, max xyz
+	int pair_leaves;           // a leaf reference of the walked tree may name two objects: ~(a | (b + 1) << TUTU_PAIR_BITS), b + 1 = 0: one
 	// the wide tree (GpuWideNode, host_scene.hpp), walked by the persistent kernels on memory-resident scenes
 	const float4* wnodes;      // 4 x float4 per node; node 0 = root
 	int has_wide;
@@ -325,15 +327,25 @@ TUTU_DEV void trace_closest(const S& ss, const SceneDev& sc, V3 o, V3 d, int* st
 			}
 		}
 		if (cur == TUTU_TRAV_DONE) break;
-		int ti;
-		float t, u, v;
-		if (leaf_test<true>(ss, ~cur, r, ti, t, u, v)) {
-			if ((t < best_t || (t == best_t && ti < best_tri)) && (!validate || leaf_box_hit(sc, ti, r))) {
-				best_t = t;
-				best_u = u;
-				best_v = v;
-				best_tri = ti;
+		int item = ~cur, second = 0;  // a leaf of the walked tree may name two objects
+		if (validate && sc.pair_leaves) {
+			second = item >> TUTU_PAIR_BITS;
+			item &= (1 << TUTU_PAIR_BITS) - 1;
+		}
+		for (;;) {
+			int ti;
+			float t, u, v;
+			if (leaf_test<true>(ss, item, r, ti, t, u, v)) {
+				if ((t < best_t || (t == best_t && ti < best_tri)) && (!validate || leaf_box_hit(sc, ti, r))) {
+					best_t = t;
+					best_u = u;
+					best_v = v;
+					best_tri = ti;
+				}
 			}
+			if (second == 0) break;
+			item = second - 1;
+			second = 0;
 		}
 		if (sp == 0) break;
 		sp--;
@@ -374,14 +386,22 @@ TUTU_DEV bool trace_any(const S& ss, const SceneDev& sc, V3 orig, V3 lightPos, i
 			}
 		}
 		if (cur == TUTU_TRAV_DONE) break;
-		int ti;
-		float t, u, v;
-		if (leaf_test<true>(ss, ~cur, r, ti, t, u, v)) {
-			if (t < dis && !float_equal(t, dis) && (!validate || leaf_box_hit(sc, ti, r))) {
-				blocked = true;
-				break;
-			}
+		int item = ~cur, second = 0;
+		if (validate && sc.pair_leaves) {
+			second = item >> TUTU_PAIR_BITS;
+			item &= (1 << TUTU_PAIR_BITS) - 1;
 		}
+		for (;;) {
+			int ti;
+			float t, u, v;
+			if (leaf_test<true>(ss, item, r, ti, t, u, v)) {
+				if (t < dis && !float_equal(t, dis) && (!validate || leaf_box_hit(sc, ti, r))) blocked = true;
+			}
+			if (blocked || second == 0) break;
+			item = second - 1;
+			second = 0;
+		}
+		if (blocked) break;
 		if (sp == 0) break;
 		sp--;
 		cur = stack[sp * stride];

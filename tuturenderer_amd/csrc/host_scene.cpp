@@ -19,6 +19,7 @@ namespace {
 
 const int32_t kSphereBit = 0x40000000;  // device_trace.h: TUTU_SPHERE_BIT
 const int32_t kClsSphere = 0x100;       // device_shade.h: TUTU_CLS_SPHERE
+const int kPairBits = 14;               // device_trace.h: TUTU_PAIR_BITS
 
 struct Box {
 	float mn[3], mx[3];
@@ -804,25 +805,45 @@ int build_host_scene(const TutuSceneDesc* d, HostScene& hs) {
 	}
 	// Flatten a build tree into hs.nodes (appending); returns the reference of its root.  Inner nodes are numbered
 	// breadth-first, so that the first ids are the top of the tree -- the part every ray walks.
-	auto flatten = [&](const std::vector<BuildNode>& t) -> int32_t {
+	// pairs: an inner node of the WALKED tree whose two children are leaves with boxes about as large as its own (the two
+	// triangles of a quad: splitting them apart costs a node step and saves no triangle test -- SAH: 2 Ct <= Cn + (A_L + A_R) / A
+	// Ct with Ct ~ Cn) becomes ONE leaf reference that names both objects (device_trace.h: TUTU_PAIR_BITS); small triangle-only
+	// scenes only (the reference fits two 14-bit indices; the LDS-resident scenes are the ones whose node steps are the cost)
+	auto flatten = [&](const std::vector<BuildNode>& t, bool pairs) -> int32_t {
 		if (t.empty()) return INT_MIN;
+		auto inner = [&](int32_t bn) { return t[bn].left >= 0 || t[bn].right >= 0; };
+		std::vector<uint8_t> is_pair(t.size(), 0);
+		if (pairs) {
+			auto area = [&](const BuildNode& b) {
+				const double dx = (double)b.pmax[0] - b.pmin[0], dy = (double)b.pmax[1] - b.pmin[1], dz = (double)b.pmax[2] - b.pmin[2];
+				return dx * dy + dy * dz + dz * dx;
+			};
+			for (size_t i = 0; i < t.size(); i++)
+				if (inner((int32_t)i) && !inner(t[i].left) && !inner(t[i].right) && area(t[t[i].left]) + area(t[t[i].right]) >= area(t[i]))
+					is_pair[i] = 1;
+		}
+		auto walked_inner = [&](int32_t bn) { return inner(bn) && !is_pair[bn]; };
 		std::vector<int32_t> inner_id(t.size(), -1);
 		int32_t next_inner = (int32_t)hs.nodes.size();
 		std::vector<int32_t> level;
-		if (t[0].left >= 0 || t[0].right >= 0) level.push_back(0);
+		if (walked_inner(0)) level.push_back(0);
 		while (!level.empty()) {
 			std::vector<int32_t> next_level;
 			for (int32_t bn : level) {
 				inner_id[bn] = next_inner++;
 				const int32_t ch[2] = {t[bn].left, t[bn].right};
 				for (int k = 0; k < 2; k++)
-					if (ch[k] >= 0 && (t[ch[k]].left >= 0 || t[ch[k]].right >= 0)) next_level.push_back(ch[k]);
+					if (ch[k] >= 0 && walked_inner(ch[k])) next_level.push_back(ch[k]);
 			}
 			level.swap(next_level);
 		}
 		hs.nodes.resize((size_t)next_inner, GpuNode{});
 		auto ref_of = [&](int32_t bn) -> int32_t {
-			if (t[bn].left >= 0 || t[bn].right >= 0) return inner_id[bn];
+			if (walked_inner(bn)) return inner_id[bn];
+			if (is_pair[bn]) {
+				const int32_t a = hs.leaf_of_orig[t[t[bn].left].tri], b = hs.leaf_of_orig[t[t[bn].right].tri];
+				return ~(a | ((b + 1) << kPairBits));
+			}
 			const int32_t leaf = hs.leaf_of_orig[t[bn].tri];
 			return obj_sph[t[bn].tri] >= 0 ? ~(leaf | kSphereBit) : ~leaf;  // device_trace.h: TUTU_SPHERE_BIT
 		};
@@ -854,7 +875,9 @@ int build_host_scene(const TutuSceneDesc* d, HostScene& hs) {
 		for (BuildNode& bn : sah)
 			if (bn.tri >= 0) bn.tri = refs[(size_t)bn.tri].obj;  // a leaf says which OBJECT to test
 		if (sah_depth <= TUTU_MAX_BVH_DEPTH) {
-			hs.root_ref = flatten(sah);
+			// (TUTU_NO_PAIRS: every leaf names one object, for A/B runs and tests)
+			hs.pair_leaves = n_sph == 0 && n < 256 && !getenv("TUTU_NO_PAIRS");
+			hs.root_ref = flatten(sah, hs.pair_leaves);
 			hs.n_fast_inner = (int32_t)hs.nodes.size();
 			hs.has_fast_tree = true;
 			hs.depth = std::max(hs.depth, sah_depth);
@@ -869,7 +892,7 @@ int build_host_scene(const TutuSceneDesc* d, HostScene& hs) {
 			}
 		}
 	}
-	hs.root_ref_exact = flatten(tree);
+	hs.root_ref_exact = flatten(tree, false);
 	lap("flatten both trees");
 	if (!hs.has_fast_tree) {
 		hs.root_ref = hs.root_ref_exact;

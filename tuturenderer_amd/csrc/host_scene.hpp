@@ -118,6 +118,7 @@ struct HostScene {
 	int32_t root_ref;  // >=0 inner node index, <0 leaf (~tri), or INT32_MIN for an empty scene: the tree the kernels walk
 	int32_t root_ref_exact = 0;  // root of the reference's own tree (fallback for rays with a zero / non-finite direction component)
 	bool has_fast_tree = false;  // root_ref is the SAH tree (else both roots are the reference tree)
+	bool pair_leaves = false;    // leaf references of the walked tree may name TWO objects (device_trace.h: TUTU_PAIR_BITS)
 	int32_t n_fast_inner = 0;    // nodes [0, n_fast_inner) belong to the walked tree
 	uint32_t fast_depth = 0, ref_depth = 0;
 	uint32_t n_refs = 0;         // leaves of the walked tree (>= objects: sliver triangles get several references)

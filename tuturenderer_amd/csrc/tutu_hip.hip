@@ -99,12 +99,14 @@ struct TutuCtx {
 		int shade_bpc = 0;        // TUTU_SHADE_BPC      shade blocks per CU (persistent grid), 0 = by kernel  [0, 16]
 		int trace_bpc = 0;        // TUTU_TRACE_BPC      traversal blocks per CU, 0 = by LDS use  [0, 8]
 		int refill_min = 24;      // TUTU_REFILL_MIN     idle lanes before a wave refills         [1, 64]
-		int inner_steps = TUTU_INNER_STEPS;  // TUTU_INNER_STEPS node visits per round            [1, 64]
+		int inner_steps = TUTU_INNER_STEPS;  // TUTU_INNER_STEPS node visits per round, closest-hit  [1, 64]
+		int inner_steps_any = 4;  // TUTU_INNER_STEPS_ANY ... any-hit (it ends at the first blocker: shorter rounds)  [1, 64]
 		int wide = 1;             // TUTU_WIDE           four-wide quantised tree: 0 never, 1 for big trees, 2 always  [0, 2]
 		int wide_min_mb = 0;      // TUTU_WIDE_MIN_MB    ... "big" = at least this many MB of binary nodes  [0, 65536]
 		int wide_inner_steps = 2; // TUTU_WIDE_INNER_STEPS node visits per round on the wide tree  [1, 64]
 		int lds_stack_max = 32;   // TUTU_LDS_STACK_MAX  k_trace, binary tree: entries of the LDS tier of a deep tree's stack, 0 = all in LDS  [0, 64]
 		int wide_lds_stack = 19;  // TUTU_WIDE_LDS_STACK k_trace, wide tree: entries of the LDS tier (19 KB: eight blocks per CU)  [4, 64]
+		int leaf_again = 24;      // TUTU_LEAF_AGAIN     lanes still holding a leaf that trigger a second leaf step per round, 65 = never  [1, 65]
 		int any_near_first = 1;   // TUTU_ANY_NEAR_FIRST any-hit: nearer child first              {0, 1}
 		int util_stats = 0;       // TUTU_UTIL_STATS     phase counters of the traversal kernels  {0, 1}
 		int bidir_units = 1 << 21;  // TUTU_BIDIR_UNITS  LightTracing / NaivePT / BDPT: (pixel, sample) units per batch  [64, 2^24]
@@ -165,12 +167,14 @@ const KnobDesc kKnobs[] = {
     {"trace_bpc", "TUTU_TRACE_BPC", &TutuCtx::Knobs::trace_bpc, 0, 8},
     {"refill_min", "TUTU_REFILL_MIN", &TutuCtx::Knobs::refill_min, 1, 64},
     {"inner_steps", "TUTU_INNER_STEPS", &TutuCtx::Knobs::inner_steps, 1, 64},
+    {"inner_steps_any", "TUTU_INNER_STEPS_ANY", &TutuCtx::Knobs::inner_steps_any, 1, 64},
     {"lds_stack_max", "TUTU_LDS_STACK_MAX", &TutuCtx::Knobs::lds_stack_max, 0, 64},
     {"wide_lds_stack", "TUTU_WIDE_LDS_STACK", &TutuCtx::Knobs::wide_lds_stack, 4, 64},
     {"wide", "TUTU_WIDE", &TutuCtx::Knobs::wide, 0, 2},
     {"wide_min_mb", "TUTU_WIDE_MIN_MB", &TutuCtx::Knobs::wide_min_mb, 0, 65536},
     {"wide_inner_steps", "TUTU_WIDE_INNER_STEPS", &TutuCtx::Knobs::wide_inner_steps, 1, 64},
     {"any_near_first", "TUTU_ANY_NEAR_FIRST", &TutuCtx::Knobs::any_near_first, 0, 1},
+    {"leaf_again", "TUTU_LEAF_AGAIN", &TutuCtx::Knobs::leaf_again, 1, 65},
     {"util_stats", "TUTU_UTIL_STATS", &TutuCtx::Knobs::util_stats, 0, 1},
     {"bidir_units", "TUTU_BIDIR_UNITS", &TutuCtx::Knobs::bidir_units, 64, 1 << 24},
 };
@@ -442,10 +446,11 @@ int run_pass(TutuCtx* c, WorkSet& w, hipStream_t s, const TutuCameraFrame* cam, 
 		tp.F = w.F.p;
 		tp.tri_class = c->d_tri_class.p;
 		tp.stack_entries = c->ktrace_entries;
-	tp.gstack = w.gstack.p;
+		tp.gstack = w.gstack.p;
 		tp.refill_min = c->knobs.refill_min;
 		tp.inner_steps = c->sc.has_wide ? c->knobs.wide_inner_steps : c->knobs.inner_steps;
 		tp.any_near_first = c->knobs.any_near_first;
+		tp.leaf_again = c->knobs.leaf_again;
 		tp.part = w.part.p;
 		tp.defer = w.defer.p;
 		TIMED(EV_TRACE_CLOSEST, launch_trace<false>(c, s, trace_grid, tp));
@@ -453,6 +458,7 @@ int run_pass(TutuCtx* c, WorkSet& w, hipStream_t s, const TutuCameraFrame* cam, 
 		tp.list = w.lists.p + w.cap;
 		tp.n_ptr = meta + 1;
 		tp.part = w.part.p + 4 * TUTU_PART_BLOCKS;
+		tp.inner_steps = c->sc.has_wide ? c->knobs.wide_inner_steps : c->knobs.inner_steps_any;
 		TIMED(EV_TRACE_ANY, launch_trace<true>(c, s, trace_grid, tp));
 	}
 	return TUTU_OK;
@@ -720,6 +726,7 @@ int tutu_hip_create(const TutuSceneDesc* scene, int device, TutuCtx** out) {
 	sc.root_ref_exact = c->hs.root_ref_exact;
 	sc.has_fast = c->hs.has_fast_tree ? 1 : 0;
 	sc.leaf_boxes = c->d_leaf_boxes.p;
+	sc.pair_leaves = c->hs.pair_leaves ? 1 : 0;
 	sc.wnodes = c->d_wnodes.p;
 	sc.has_wide = 0;  // decided below, with the traversal kernels' LDS budget
 	memcpy(sc.wide_lo, c->hs.wide_origin_lo, 12);
@@ -891,6 +898,10 @@ int tutu_hip_get_option(TutuCtx* c, const char* name, int* value) {
 	}
 	if (strcmp(name, "lds_scene") == 0) {
 		*value = c->lds_scene ? 1 : 0;
+		return TUTU_OK;
+	}
+	if (strcmp(name, "pair_leaves") == 0) {  // leaf references of the walked tree may name two objects (quads of small scenes)
+		*value = c->hs.pair_leaves ? 1 : 0;
 		return TUTU_OK;
 	}
 	if (strcmp(name, "wide_tree") == 0) {  // the persistent kernels walk the four-wide quantised tree
@@ -1164,6 +1175,7 @@ int lt_wavefront_batch(TutuCtx* c, hipStream_t s, BidirParams p) {
 	tp.refill_min = c->knobs.refill_min;
 	tp.inner_steps = c->sc.has_wide ? c->knobs.wide_inner_steps : c->knobs.inner_steps;
 	tp.any_near_first = c->knobs.any_near_first;
+	tp.leaf_again = c->knobs.leaf_again;
 	tp.part = nullptr;
 	tp.defer = w.defer.p;
 	const int grid = persistent_grid(p.n_units, c->n_cu, c->trace_blocks_per_cu);
@@ -1571,6 +1583,7 @@ static int run_trace_kernel(TutuCtx* c, uint32_t n, bool any) {
 	tp.refill_min = 1;
 	tp.inner_steps = c->sc.has_wide ? c->knobs.wide_inner_steps : TUTU_INNER_STEPS;
 	tp.any_near_first = 1;
+	tp.leaf_again = c->knobs.leaf_again;
 	const int grid = persistent_grid(n, c->n_cu, c->trace_blocks_per_cu);
 	if (any) launch_trace<true>(c, s, grid, tp);
 	else launch_trace<false>(c, s, grid, tp);
