@@ -889,12 +889,13 @@ TUTU_DEV void trace_persistent(const S& ss, const TraceParams& tp, int* stack, c
 						exact = true;  // the reference's own tree with the reference's own slab: after the main loop
 						cur = TUTU_TRAV_IDLE;
 					} else {
-						float te;
-						if (slab_plain(r, sc.root_min[0], sc.root_min[1], sc.root_min[2], sc.root_max[0], sc.root_max[1], sc.root_max[2], inf, te)) {
-							if (WIDE) cur = 0;  // the wide tree's root
-							else if (sc.root_ref >= 0) cur = sc.root_ref;
-							else pend = sc.root_ref;  // a scene of one object: the root is a leaf
-						}
+						// No test of the root box here (BVH.hpp:150 for the root): a plain ray that misses it misses every box inside
+						// it (§4: the slab arithmetic is monotone in the box), so the walk ends one node later by itself -- and the
+						// rays of this pipeline start ON the scene's surfaces, i.e. inside the root box: the test (23 vector
+						// instructions on the few lanes a refill serves) practically never fails.
+						if (WIDE) cur = 0;  // the wide tree's root
+						else if (sc.root_ref >= 0) cur = sc.root_ref;
+						else pend = sc.root_ref;  // a scene of one object: the root is a leaf
 					}
 				}
 			}
