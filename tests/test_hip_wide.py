@@ -165,3 +165,25 @@ def test_million_triangle_scene_create_time_and_hits(tr, monkeypatch):
     assert 0.2 < (hits["default"]["tri"] >= 0).mean() < 0.99
     assert bit_equal(hits["default"]["tri"], hits["reference_tree"]["tri"])
     assert bit_equal(hits["default"]["t"], hits["reference_tree"]["t"])
+
+
+def test_pair_leaves_do_not_change_a_frame(tr, monkeypatch):
+    """Cornell box (LDS-resident, 32 triangles = 16 quads): the walked tree names both triangles of a quad in one leaf reference
+    (`pair_leaves`); with TUTU_NO_PAIRS=1 every leaf names one object.  Same frame, byte for byte; fewer nodes entered."""
+    from tuturenderer_amd import scenes
+
+    out = {}
+    for tag, env in (("pairs", {}), ("single", {"TUTU_NO_PAIRS": "1"})):
+        monkeypatch.delenv("TUTU_NO_PAIRS", raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        with tr.Context(scenes.cornell_box(128, 128)) as ctx:
+            assert ctx.get_option("pair_leaves") == (1 if tag == "pairs" else 0)
+            assert ctx.get_option("lds_scene") == 1
+            img = ctx.render(spp=8, key0=0x5EED0001, key1=2)
+            st = dict(ctx.last_stats)
+        out[tag] = (img, st)
+    monkeypatch.delenv("TUTU_NO_PAIRS", raising=False)
+    assert out["pairs"][0].tobytes() == out["single"][0].tobytes()
+    assert out["pairs"][1]["closest_rays"] == out["single"][1]["closest_rays"]
+    assert out["pairs"][1]["nodes_closest"] < out["single"][1]["nodes_closest"]
