@@ -786,7 +786,7 @@ struct TraceParams {
 // leaf references are negative and above the two markers: (unsigned)ref > 0x80000001
 TUTU_DEV bool ref_is_leaf(int ref) { return (uint32_t)ref > (uint32_t)TUTU_TRAV_IDLE; }
 
-template <typename S, bool ANY, bool SPH, bool DEEP, bool WIDE>
+template <typename S, bool ANY, bool SPH, bool DEEP, bool WIDE, bool EARLY = false>
 TUTU_DEV void trace_persistent(const S& ss, const TraceParams& tp, int* stack, const uint8_t* tri_class) {
 	const SceneDev& sc = tp.sc;
 	const int lane = __lane_id();
@@ -889,13 +889,17 @@ TUTU_DEV void trace_persistent(const S& ss, const TraceParams& tp, int* stack, c
 						exact = true;  // the reference's own tree with the reference's own slab: after the main loop
 						cur = TUTU_TRAV_IDLE;
 					} else {
-						// No test of the root box here (BVH.hpp:150 for the root): a plain ray that misses it misses every box inside
-						// it (§4: the slab arithmetic is monotone in the box), so the walk ends one node later by itself -- and the
-						// rays of this pipeline start ON the scene's surfaces, i.e. inside the root box: the test (23 vector
-						// instructions on the few lanes a refill serves) practically never fails.
-						if (WIDE) cur = 0;  // the wide tree's root
-						else if (sc.root_ref >= 0) cur = sc.root_ref;
-						else pend = sc.root_ref;  // a scene of one object: the root is a leaf
+						// LDS scenes: no test of the root box (BVH.hpp:150 for the root): a plain ray that misses it misses every box
+						// inside it (§4: the slab arithmetic is monotone in the box), so the walk ends one node later by itself --
+						// and the rays of this pipeline start ON the scene's surfaces, i.e. inside the root box: the test (23 vector
+						// instructions on the few lanes a refill serves) practically never fails.  (The wide kernels keep it:
+						// without it their register allocation spills inside the loop, -5 % on the broom stand-in.)
+						float te;
+						if (!WIDE || slab_plain(r, sc.root_min[0], sc.root_min[1], sc.root_min[2], sc.root_max[0], sc.root_max[1], sc.root_max[2], inf, te)) {
+							if (WIDE) cur = 0;  // the wide tree's root
+							else if (sc.root_ref >= 0) cur = sc.root_ref;
+							else pend = sc.root_ref;  // a scene of one object: the root is a leaf
+						}
 					}
 				}
 			}
@@ -1025,21 +1029,43 @@ TUTU_DEV void trace_persistent(const S& ss, const TraceParams& tp, int* stack, c
 					second = item >> TUTU_PAIR_BITS;
 					item &= (1 << TUTU_PAIR_BITS) - 1;
 				}
-				const bool h = leaf_test<SPH>(ss, item, r, ti, t, u, v);
-				bool cand;
-				if (ANY) cand = h && t < dis && !float_equal(t, dis);  // BVH.hpp:186
-				else cand = h && (t < best_t || (t == best_t && ti < best_tri));
-				if (cand) {  // validated against the reference's leaf box (BVH.hpp:150; device_trace.h)
-					// (requesting the box together with the intersection record -- no second dependent round trip -- was
-					// measured: eight more live registers in the 64-register loop spill, -10 % on every scene)
+				// EARLY (memory-resident scenes whose tree fits the L2s): the reference's leaf box of the object is requested WITH
+				// its intersection record, so that a candidate does not wait for a second, dependent round trip (bunny stand-in
+				// +3 %, veach room +2.5 %).  The eight registers this keeps live make it a kernel of 7 waves per SIMD (in the
+				// 64-register loop they spill: -10 %); on the broom stand-in, which is short of bandwidth beyond L2, the 32 B more
+				// per leaf test cost 5 % of the frame, so big trees keep the dependent fetch.
+				// (the two forms are written out separately: hoisting the box's declaration alone changes the register allocation
+				// of the non-EARLY kernels -- spills inside the loop, -5 % on the broom stand-in)
+				if (EARLY) {
 					float4 lo, hi;
-					ss.lbox(ti, lo, hi);
+					ss.lbox(SPH ? (item & ~TUTU_SPHERE_BIT) : item, lo, hi);
+					const bool h = leaf_test<SPH>(ss, item, r, ti, t, u, v);
+					bool cand;
+					if (ANY) cand = h && t < dis && !float_equal(t, dis);  // BVH.hpp:186
+					else cand = h && (t < best_t || (t == best_t && ti < best_tri));
 					float te;
-					if (slab_plain(r, lo.x, lo.y, lo.z, hi.x, hi.y, hi.z, inf, te)) {
+					if (cand && slab_plain(r, lo.x, lo.y, lo.z, hi.x, hi.y, hi.z, inf, te)) {  // validated (BVH.hpp:150; device_trace.h)
 						if (ANY) blocked = true;
 						else {
 							best_t = t; best_u = u; best_v = v; best_tri = ti;
 							lim = t * TUTU_PRUNE_SLACK;
+						}
+					}
+				} else {
+					const bool h = leaf_test<SPH>(ss, item, r, ti, t, u, v);
+					bool cand;
+					if (ANY) cand = h && t < dis && !float_equal(t, dis);  // BVH.hpp:186
+					else cand = h && (t < best_t || (t == best_t && ti < best_tri));
+					if (cand) {  // validated against the reference's leaf box (BVH.hpp:150; device_trace.h)
+						float4 lo, hi;
+						ss.lbox(ti, lo, hi);
+						float te;
+						if (slab_plain(r, lo.x, lo.y, lo.z, hi.x, hi.y, hi.z, inf, te)) {
+							if (ANY) blocked = true;
+							else {
+								best_t = t; best_u = u; best_v = v; best_tri = ti;
+								lim = t * TUTU_PRUNE_SLACK;
+							}
 						}
 					}
 				}
@@ -1138,6 +1164,18 @@ TUTU_DEV void trace_persistent(const S& ss, const TraceParams& tp, int* stack, c
 // SPH: the scene has sphere leaves (the triangle-only instantiations do not contain the sphere test)
 // DEEP: the stack has a second tier in HBM (memory-resident scenes with deep trees)
 // WIDE: memory-resident scenes walk the four-wide quantised tree (always with the two-tier stack: a wide node can push three)
+// (the wide tree's kernel with the leaf box fetched early: 7 waves per SIMD = 72 registers, see the leaf step; without it the
+// wide tree runs through k_trace<false, .., true, true> below)
+template <bool ANY, bool SPH, bool EARLY>
+__global__ void __launch_bounds__(256, 7) k_trace_wide(TraceParams tp) {
+	extern __shared__ int lds[];  // [LDS-tier stack entries][256 lanes]
+	SceneGlobal sg;
+	sg.nodes = tp.sc.nodes;
+	sg.tris = tp.sc.tri_isect;
+	sg.lboxes = tp.sc.leaf_boxes;
+	trace_persistent<SceneGlobal, ANY, SPH, true, true, EARLY>(sg, tp, lds + threadIdx.x, tp.tri_class);
+}
+
 template <bool LDS_SCENE, bool ANY, bool SPH, bool DEEP, bool WIDE>
 __global__ void __launch_bounds__(256, 8) k_trace(TraceParams tp) {
 	extern __shared__ int lds[];  // [stack entries][256 lanes] | optional scene copy | optional class table

@@ -77,6 +77,7 @@ struct TutuCtx {
 	unsigned trace_lds_bytes = TUTU_STACK_DEPTH * 256 * sizeof(int);
 	int ktrace_entries = TUTU_STACK_DEPTH;  // k_trace: entries of the LDS tier of its stack ...
 	int ktrace_deep = 0;                    // ... and of the HBM tier (0: the whole stack is in LDS)
+	bool wide_early = false;                // wide tree: leaf box fetched with the triangle record (7 waves per SIMD)
 	unsigned ktrace_lds_bytes = TUTU_STACK_DEPTH * 256 * sizeof(int);
 	bool lds_scene = false;
 	uint32_t type_mask = 0;  // MaterialType values present among the non-emissive materials
@@ -103,6 +104,8 @@ struct TutuCtx {
 		int inner_steps_any = 4;  // TUTU_INNER_STEPS_ANY ... any-hit (it ends at the first blocker: shorter rounds)  [1, 64]
 		int wide = 1;             // TUTU_WIDE           four-wide quantised tree: 0 never, 1 for big trees, 2 always  [0, 2]
 		int wide_min_mb = 0;      // TUTU_WIDE_MIN_MB    ... "big" = at least this many MB of binary nodes  [0, 65536]
+		int wide_early = 1;       // TUTU_WIDE_EARLY     leaf box with the triangle record: 0 never, 1 small trees, 2 always  [0, 2]
+		int wide_early_max_mb = 8;  // TUTU_WIDE_EARLY_MAX_MB  ... "small" = fewer MB of wide nodes than this  [0, 65536]
 		int wide_inner_steps = 2; // TUTU_WIDE_INNER_STEPS node visits per round on the wide tree  [1, 64]
 		int lds_stack_max = 32;   // TUTU_LDS_STACK_MAX  k_trace, binary tree: entries of the LDS tier of a deep tree's stack, 0 = all in LDS  [0, 64]
 		int wide_lds_stack = 19;  // TUTU_WIDE_LDS_STACK k_trace, wide tree: entries of the LDS tier (19 KB: eight blocks per CU)  [4, 64]
@@ -173,6 +176,8 @@ const KnobDesc kKnobs[] = {
     {"wide", "TUTU_WIDE", &TutuCtx::Knobs::wide, 0, 2},
     {"wide_min_mb", "TUTU_WIDE_MIN_MB", &TutuCtx::Knobs::wide_min_mb, 0, 65536},
     {"wide_inner_steps", "TUTU_WIDE_INNER_STEPS", &TutuCtx::Knobs::wide_inner_steps, 1, 64},
+    {"wide_early", "TUTU_WIDE_EARLY", &TutuCtx::Knobs::wide_early, 0, 2},
+    {"wide_early_max_mb", "TUTU_WIDE_EARLY_MAX_MB", &TutuCtx::Knobs::wide_early_max_mb, 0, 65536},
     {"any_near_first", "TUTU_ANY_NEAR_FIRST", &TutuCtx::Knobs::any_near_first, 0, 1},
     {"leaf_again", "TUTU_LEAF_AGAIN", &TutuCtx::Knobs::leaf_again, 1, 65},
     {"util_stats", "TUTU_UTIL_STATS", &TutuCtx::Knobs::util_stats, 0, 1},
@@ -298,8 +303,13 @@ template <bool ANY>
 void launch_trace(TutuCtx* c, hipStream_t s, int grid, const TraceParams& tp) {
 	if (c->sc.has_wide) {  // memory-resident scene: the four-wide quantised tree, two-tier stack
 		dim3 g(grid), b(256);
-		if (c->has_spheres) k_trace<false, ANY, true, true, true><<<g, b, c->ktrace_lds_bytes, s>>>(tp);
-		else k_trace<false, ANY, false, true, true><<<g, b, c->ktrace_lds_bytes, s>>>(tp);
+		if (c->wide_early) {
+			if (c->has_spheres) k_trace_wide<ANY, true, true><<<g, b, c->ktrace_lds_bytes, s>>>(tp);
+			else k_trace_wide<ANY, false, true><<<g, b, c->ktrace_lds_bytes, s>>>(tp);
+		} else {
+			if (c->has_spheres) k_trace<false, ANY, true, true, true><<<g, b, c->ktrace_lds_bytes, s>>>(tp);
+			else k_trace<false, ANY, false, true, true><<<g, b, c->ktrace_lds_bytes, s>>>(tp);
+		}
 		return;
 	}
 	if (c->ktrace_deep > 0) {  // memory-resident scene with a deep tree: second stack tier in HBM
@@ -818,6 +828,12 @@ int tutu_hip_create(const TutuSceneDesc* scene, int device, TutuCtx** out) {
 	// (+ the kernel's 32 B of static LDS: eight blocks of exactly 20 KB do NOT fit a CU, and the blocks that do not fit run
 	// after the others, alone -- a persistent grid must be resident as a whole)
 	c->trace_blocks_per_cu = (int)std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / ((size_t)c->ktrace_lds_bytes + 64)));
+	// Wide tree, leaf box requested with the triangle record (device_shade.h: EARLY): for trees that fit the L2s (TUTU_WIDE_EARLY:
+	// 0 never, 1 below TUTU_WIDE_EARLY_MAX_MB of wide nodes, 2 always).  Those kernels are built for 7 waves per SIMD -- 72
+	// registers -- so 7 blocks of 4 waves is what a CU holds.
+	const size_t wide_mb = (c->hs.wnodes.size() * sizeof(GpuWideNode)) >> 20;
+	c->wide_early = sc.has_wide && (c->knobs.wide_early == 2 || (c->knobs.wide_early == 1 && wide_mb < (size_t)c->knobs.wide_early_max_mb));
+	if (c->wide_early) c->trace_blocks_per_cu = std::min(c->trace_blocks_per_cu, 7);
 	// Fewer resident blocks than the LDS use allows (TUTU_TRACE_BPC): the request is padded so that exactly that many FIT --
 	// a grid of fewer blocks than fit is not spread evenly over the CUs by the dispatcher (some CUs get 8, others 2).
 	if (c->knobs.trace_bpc > 0 && c->knobs.trace_bpc < c->trace_blocks_per_cu) {
