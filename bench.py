@@ -214,6 +214,9 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # The timed region runs WITHOUT the library's per-launch HIP event pairs (TutuStats' per-kernel times: 2400 events per frame
+    # cost 2.7 % of it); ray / node counters are device-side and stay.  Per-kernel times come from the extra steps below.
+    ctx.set_option("kernel_events", 0)
     for _ in range(args.warmup):
         step()
     fence()
@@ -232,6 +235,13 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
 
+    # One more step of the timed configuration, now WITH per-launch events: launch counts and the overlapped per-kernel spans
+    ctx.set_option("kernel_events", 1)
+    ov = dict(step())
+    fence()
+    for k in ("ms_trace_closest", "ms_trace_any", "ms_shade", "ms_shade_first", "ms_shade_material", "ms_shade_terminal", "ms_other", "ms_total",
+              "trace_launches", "shade_material_launches"):
+        agg[k] = ov[k] * args.steps  # (per-step figures of the instrumented step, scaled like the sums of the timed steps)
     # One more step outside the timed region with ONE pass in flight: kernels then run one at a time, and the HIP-event
     # duration of a launch is the time that kernel needs for its work -- with four passes in flight (the timed
     # configuration) every launch's duration also contains the time it shares the device with three other streams.
@@ -347,7 +357,8 @@ def main():
                                                         "k_shade_connect_only": excl["ms_shade_terminal"], "other": excl["ms_other"]}
             roofline["overlapped_timed_region"] = {
                 "note": "four wavefront passes in flight on four streams: a launch's HIP-event duration includes the time it shares the device "
-                        "with other streams' kernels, so these are NOT kernel durations (they sum to more than ms_per_step)",
+                        "with other streams' kernels, so these are NOT kernel durations (they sum to more than ms_per_step); from one extra "
+                        "step with per-launch events switched on (the timed steps run without them)",
                 "per_kernel_ms_per_step": {k: tab[k]["ms"] / args.steps for k in tab}}
         # The pipeline as a whole against the VALU roofline: every kernel's exclusive time x the share of the SIMDs' issue cycles
         # its vector instructions take (committed PMC collection) = the time the frame would need if vector instructions were
@@ -392,7 +403,8 @@ def main():
                        "spp_per_pass": spp_per_pass, "passes_per_step": agg["passes"] // max(args.steps, 1),
                        "wall_clock_to_512spp_s": dt / args.steps if (spp == 512 and args.config == "c2") else None,
                        "rays_per_s": (agg["closest_rays"] + agg["shadow_rays"]) / dt if world == 1 else None,
-                       "timed": "tutu_hip_render_device: scene, BVH and work buffers resident in HBM, frame left in HBM (bench contract); "
+                       "timed": "tutu_hip_render_device without per-launch event pairs (knob kernel_events = 0: instrumentation only, 2.7 % of a "
+                                "frame); scene, BVH and work buffers resident in HBM, frame left in HBM (bench contract); "
                                 "see `drop_in` for the SURVEY 8d bracket (create + H2D + render + D2H + destroy)",
                        "knobs": options, "env": {k: v for k, v in os.environ.items() if k.startswith("TUTU_")}},
             "frame": frame_check,
@@ -404,6 +416,7 @@ def main():
             t0 = time.perf_counter()
             c2 = tr.Context(scene, device=local_rank)
             t_c2 = time.perf_counter() - t0
+            c2.set_option("kernel_events", 0)  # a caller that wants the frame, not per-kernel times (stats = NULL does the same)
             t0 = time.perf_counter()
             c2.render(spp, KEY0, key1, full_frame=False)
             t_r1 = time.perf_counter() - t0

@@ -77,6 +77,7 @@ struct TutuCtx {
 	unsigned trace_lds_bytes = TUTU_STACK_DEPTH * 256 * sizeof(int);
 	int ktrace_entries = TUTU_STACK_DEPTH;  // k_trace: entries of the LDS tier of its stack ...
 	int ktrace_deep = 0;                    // ... and of the HBM tier (0: the whole stack is in LDS)
+	bool want_stats = true;                 // the current call was given a TutuStats (else no event pairs are recorded)
 	bool wide_early = false;                // wide tree: leaf box fetched with the triangle record (7 waves per SIMD)
 	unsigned ktrace_lds_bytes = TUTU_STACK_DEPTH * 256 * sizeof(int);
 	bool lds_scene = false;
@@ -110,6 +111,7 @@ struct TutuCtx {
 		int lds_stack_max = 32;   // TUTU_LDS_STACK_MAX  k_trace, binary tree: entries of the LDS tier of a deep tree's stack, 0 = all in LDS  [0, 64]
 		int wide_lds_stack = 19;  // TUTU_WIDE_LDS_STACK k_trace, wide tree: entries of the LDS tier (19 KB: eight blocks per CU)  [4, 64]
 		int leaf_again = 24;      // TUTU_LEAF_AGAIN     lanes still holding a leaf that trigger a second leaf step per round, 65 = never  [1, 65]
+		int kernel_events = 1;    // TUTU_KERNEL_EVENTS  a HIP event pair around every launch (per-kernel times in TutuStats)  {0, 1}
 		int any_near_first = 1;   // TUTU_ANY_NEAR_FIRST any-hit: nearer child first              {0, 1}
 		int util_stats = 0;       // TUTU_UTIL_STATS     phase counters of the traversal kernels  {0, 1}
 		int bidir_units = 1 << 21;  // TUTU_BIDIR_UNITS  LightTracing / NaivePT / BDPT: (pixel, sample) units per batch  [64, 2^24]
@@ -179,6 +181,7 @@ const KnobDesc kKnobs[] = {
     {"wide_early", "TUTU_WIDE_EARLY", &TutuCtx::Knobs::wide_early, 0, 2},
     {"wide_early_max_mb", "TUTU_WIDE_EARLY_MAX_MB", &TutuCtx::Knobs::wide_early_max_mb, 0, 65536},
     {"any_near_first", "TUTU_ANY_NEAR_FIRST", &TutuCtx::Knobs::any_near_first, 0, 1},
+    {"kernel_events", "TUTU_KERNEL_EVENTS", &TutuCtx::Knobs::kernel_events, 0, 1},
     {"leaf_again", "TUTU_LEAF_AGAIN", &TutuCtx::Knobs::leaf_again, 1, 65},
     {"util_stats", "TUTU_UTIL_STATS", &TutuCtx::Knobs::util_stats, 0, 1},
     {"bidir_units", "TUTU_BIDIR_UNITS", &TutuCtx::Knobs::bidir_units, 64, 1 << 24},
@@ -270,6 +273,8 @@ int ensure_work(TutuCtx* c, size_t want_slots, size_t nitems, int n_sets) {
 }
 
 int ev_begin(TutuCtx* c, hipStream_t s, int kind, size_t* idx) {
+	*idx = (size_t)-1;
+	if (!c->knobs.kernel_events || !c->want_stats) return TUTU_OK;  // no per-launch timing: TutuStats' per-kernel times stay 0
 	if (c->ev_used == c->ev_pool.size()) {
 		EvPair p;
 		HIP_TRY(hipEventCreate(&p.a));
@@ -283,6 +288,7 @@ int ev_begin(TutuCtx* c, hipStream_t s, int kind, size_t* idx) {
 	return TUTU_OK;
 }
 int ev_end(TutuCtx* c, hipStream_t s, size_t idx) {
+	if (idx == (size_t)-1) return TUTU_OK;
 	HIP_TRY(hipEventRecord(c->ev_pool[idx].b, s));
 	return TUTU_OK;
 }
@@ -576,6 +582,7 @@ int render_impl(TutuCtx* c, const TutuCameraFrame* cam, const TutuRenderParams* 
 		npix = rect_w * (rp->y1 - rp->y0);
 	}
 	HIP_TRY(hipSetDevice(c->device));
+	c->want_stats = st != nullptr;
 	// Paths in flight: max_paths in total, split over the work sets whose passes run concurrently, one stream each
 	// (measured on the Cornell box, 512 spp: 2 sets x 8 Mi 1518 Msamples/s, 3 x 8 Mi 1619, 4 x 8 Mi 1645; later, on a
 	// faster box: 4 x 4 Mi 1545, 4 x 8 Mi 1725, 4 x 12 Mi 1753, 4 x 16 Mi 1714; 5, 6 or 8 sets are slower than 4).
