@@ -141,7 +141,8 @@ typedef struct TutuStats {
 	uint64_t segments;     /* path vertices shaded */
 	uint32_t passes;
 	uint32_t trace_launches; /* launches of the closest-hit traversal kernel */
-	float ms_total;          /* device time of the whole call's kernels, HIP events on the library's stream */
+	float ms_total;          /* device time of the whole call's kernels, HIP events on the library's stream.  The ms_* fields and
+	                          * shade_material_launches are filled only with the knob "kernel_events" = 1 (TUTU_KERNEL_EVENTS; default 0) */
 	float ms_trace_closest;  /* summed over launches */
 	float ms_trace_any;
 	float ms_shade;          /* all shade launches (= ms_shade_first + ms_shade_material + ms_shade_terminal) */
@@ -333,9 +334,9 @@ int tutu_hip_quantise(TutuCtx* ctx, uint32_t n, const float* values, int32_t* le
  *   "trace_bpc" TUTU_TRACE_BPC [0,8] (0 = from the LDS footprint) | "refill_min" TUTU_REFILL_MIN [1,64] |
  *   "inner_steps" TUTU_INNER_STEPS [1,64] / "inner_steps_any" TUTU_INNER_STEPS_ANY [1,64] (node visits per round of the closest-hit /
  *   any-hit kernel) | "leaf_again" TUTU_LEAF_AGAIN [1,65] (lanes still holding a leaf that trigger a second leaf step in a round;
- *   65 = never) | "any_near_first" TUTU_ANY_NEAR_FIRST {0,1} | "kernel_events" TUTU_KERNEL_EVENTS {0,1} (a HIP event pair around
- *   every launch, for TutuStats' per-kernel times: ~2400 events, 2.7 % of a 512-spp Cornell frame; a call without a TutuStats
- *   records none) |
+ *   65 = never) | "any_near_first" TUTU_ANY_NEAR_FIRST {0,1} | "kernel_events" TUTU_KERNEL_EVENTS {0,1} (default 0; 1 = a HIP
+ *   event pair around every launch, which is what fills TutuStats' ms_* fields: ~2400 events, 2.7 % of a 512-spp Cornell frame;
+ *   the ray / node counters of TutuStats do not need it) |
  *   "util_stats" TUTU_UTIL_STATS {0,1} | "bidir_units" TUTU_BIDIR_UNITS [64, 2^24] ((pixel, sample) units per batch of
  *   tutu_hip_render_integrator; batches are whole pixels) |
  *   "wide" TUTU_WIDE [0,2] (memory-resident scenes: 0 walk the binary SAH tree, 1 the four-wide quantised tree when the binary

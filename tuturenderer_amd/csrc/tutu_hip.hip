@@ -111,7 +111,7 @@ struct TutuCtx {
 		int lds_stack_max = 32;   // TUTU_LDS_STACK_MAX  k_trace, binary tree: entries of the LDS tier of a deep tree's stack, 0 = all in LDS  [0, 64]
 		int wide_lds_stack = 19;  // TUTU_WIDE_LDS_STACK k_trace, wide tree: entries of the LDS tier (19 KB: eight blocks per CU)  [4, 64]
 		int leaf_again = 24;      // TUTU_LEAF_AGAIN     lanes still holding a leaf that trigger a second leaf step per round, 65 = never  [1, 65]
-		int kernel_events = 1;    // TUTU_KERNEL_EVENTS  a HIP event pair around every launch (per-kernel times in TutuStats)  {0, 1}
+		int kernel_events = 0;    // TUTU_KERNEL_EVENTS  a HIP event pair around every launch (per-kernel times in TutuStats; 2.7 % of a frame)  {0, 1}
 		int any_near_first = 1;   // TUTU_ANY_NEAR_FIRST any-hit: nearer child first              {0, 1}
 		int util_stats = 0;       // TUTU_UTIL_STATS     phase counters of the traversal kernels  {0, 1}
 		int bidir_units = 1 << 21;  // TUTU_BIDIR_UNITS  LightTracing / NaivePT / BDPT: (pixel, sample) units per batch  [64, 2^24]
