@@ -216,7 +216,9 @@ def main():
 
     # The timed region runs WITHOUT the library's per-launch HIP event pairs (TutuStats' per-kernel times: 2400 events per frame
     # cost 2.7 % of it); ray / node counters are device-side and stay.  Per-kernel times come from the extra steps below.
-    ctx.set_option("kernel_events", 0)
+    # (--no-extras = profiling runs, rocprofv3 stats / PMC passes: exactly `steps` frames and nothing else must run, so the
+    # timed frames themselves carry the events there.)
+    ctx.set_option("kernel_events", 1 if args.no_extras else 0)
     for _ in range(args.warmup):
         step()
     fence()
@@ -236,12 +238,13 @@ def main():
         dt = float(tmax.item())
 
     # One more step of the timed configuration, now WITH per-launch events: launch counts and the overlapped per-kernel spans
-    ctx.set_option("kernel_events", 1)
-    ov = dict(step())
-    fence()
-    for k in ("ms_trace_closest", "ms_trace_any", "ms_shade", "ms_shade_first", "ms_shade_material", "ms_shade_terminal", "ms_other", "ms_total",
-              "trace_launches", "shade_material_launches"):
-        agg[k] = ov[k] * args.steps  # (per-step figures of the instrumented step, scaled like the sums of the timed steps)
+    if not args.no_extras:
+        ctx.set_option("kernel_events", 1)
+        ov = dict(step())
+        fence()
+        for k in ("ms_trace_closest", "ms_trace_any", "ms_shade", "ms_shade_first", "ms_shade_material", "ms_shade_terminal", "ms_other", "ms_total",
+                  "trace_launches", "shade_material_launches"):
+            agg[k] = ov[k] * args.steps  # (per-step figures of the instrumented step, scaled like the sums of the timed steps)
     # One more step outside the timed region with ONE pass in flight: kernels then run one at a time, and the HIP-event
     # duration of a launch is the time that kernel needs for its work -- with four passes in flight (the timed
     # configuration) every launch's duration also contains the time it shares the device with three other streams.

@@ -59,6 +59,16 @@ def main(root, tag, cfg):
                 val[st][row["Counter_Name"]] += float(row["Counter_Value"])
                 disp[st][row["Counter_Name"]].add(row["Dispatch_Id"])
     line = json.loads([x for x in open(f"{root}/g2.log") if x.startswith("{")][0])
+    # the counters cover every dispatch of the run: the line's launch counts must too (an extra, uncounted frame doubled every
+    # byte count once more while this tool was being written -- and 5.9 TB/s slipped under the 8 TB/s check)
+    n_disp = {}
+    for f in files:
+        for row in csv.DictReader(open(f)):
+            if row["Counter_Name"] in ("FETCH_SIZE",) and stage(row["Kernel_Name"]) == "k_shade":
+                n_disp[row["Dispatch_Id"]] = 1
+    want = line["roofline"]["per_kernel"]["k_shade"]["launches"]
+    if n_disp and len(n_disp) != want:
+        raise SystemExit(f"refusing: {len(n_disp)} k_shade dispatches were profiled, the bench line accounts for {want}")
     pk = line["roofline"]["per_kernel"]
     units = {k: pk[k]["units_per_launch"] * pk[k]["launches"] for k in pk}
     samples = line["value"] * 1e6 * line["ms_per_step"] * 1e-3 * line["steps"]
