@@ -29,8 +29,11 @@ from collections import defaultdict
 
 def stage(name):
     if "k_trace<" in name:
-        params = name.split("k_trace<")[1].split(">")[0].replace(" ", "").split(",")  # <LDS_SCENE, ANY, SPH>
+        params = name.split("k_trace<")[1].split(">")[0].replace(" ", "").split(",")  # <LDS_SCENE, ANY, SPH, DEEP, WIDE>
         return "k_trace_any" if params[1] == "true" else "k_trace_closest"
+    if "k_trace_wide<" in name:
+        params = name.split("k_trace_wide<")[1].split(">")[0].replace(" ", "").split(",")  # <ANY, SPH, EARLY>
+        return "k_trace_any" if params[0] == "true" else "k_trace_closest"
     if "k_shade<" in name:  # the stage launches at depth >= 1 (MODE 1..4, 6); depth 0 (MODE 0) and connect-only (MODE 5) are separate
         mode = name.split("k_shade<")[1].split(",")[0].strip()
         return {"0": "k_shade_depth0", "5": "k_shade_connect_only"}.get(mode, "k_shade")
