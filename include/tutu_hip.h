@@ -334,7 +334,8 @@ int tutu_hip_quantise(TutuCtx* ctx, uint32_t n, const float* values, int32_t* le
  *   "trace_bpc" TUTU_TRACE_BPC [0,8] (0 = from the LDS footprint) | "refill_min" TUTU_REFILL_MIN [1,64] |
  *   "inner_steps" TUTU_INNER_STEPS [1,64] / "inner_steps_any" TUTU_INNER_STEPS_ANY [1,64] (node visits per round of the closest-hit /
  *   any-hit kernel) | "leaf_again" TUTU_LEAF_AGAIN [1,65] (lanes still holding a leaf that trigger a second leaf step in a round;
- *   65 = never) | "any_near_first" TUTU_ANY_NEAR_FIRST {0,1} | "kernel_events" TUTU_KERNEL_EVENTS {0,1} (default 0; 1 = a HIP
+ *   65 = never) | "trace_xcd" TUTU_TRACE_XCD {0,1} (default 1: the traversal blocks of one XCD take adjacent ranges of the ray
+ *   list, so that each XCD's L2 serves one part of the picture) | "any_near_first" TUTU_ANY_NEAR_FIRST {0,1} | "kernel_events" TUTU_KERNEL_EVENTS {0,1} (default 0; 1 = a HIP
  *   event pair around every launch, which is what fills TutuStats' ms_* fields: ~2400 events, 2.7 % of a 512-spp Cornell frame;
  *   the ray / node counters of TutuStats do not need it) |
  *   "util_stats" TUTU_UTIL_STATS {0,1} | "bidir_units" TUTU_BIDIR_UNITS [64, 2^24] ((pixel, sample) units per batch of

@@ -30,7 +30,8 @@
 enum Op {
 	ADD_F32, MUL_F32, FMA_F32, MAX_F32, MIN3_F32, CNDMASK, MOV_B32, PK_MUL_F32, PK_ADD_F32, PK_FMA_F32, RCP_F32, SQRT_F32, CMP_F32,
 	ADD_DEP, FMA_DEP, PK_MUL_DEP, DIV_F32, SALU_AND, MIX_VALU_SALU, LDS_B128, LDS_B32, MIX_VALU_LDS,
-	CNDMASK_E64, SUB_F32, MIN_F32, AND_B32, ADD_U32, LSHL_B32, CMP_E64, MAX_I32, MED3_F32, MIX_SLAB, CMP_CND_VCC, CND_E64_VCC, CND_VCC_DST, CMP_CND_SGPR, N_OPS
+	CNDMASK_E64, SUB_F32, MIN_F32, AND_B32, ADD_U32, LSHL_B32, CMP_E64, MAX_I32, MED3_F32, MIX_SLAB, CMP_CND_VCC, CND_E64_VCC, CND_VCC_DST,  CMP_CND_SGPR,
+	CVT_UBYTE0, CVT_UBYTE2, CVT_F32_U32, BFI_B32, ASHR_I32, PERM_B32, XOR_B32, MAD_U64_U32, MUL_LO_U32, MUL_HI_U32, BFE_U32, LDEXP_F32, AND_OR_B32, ADD3_U32, MAX3_F32, MUL_U24, READLANE, FMA_MIX_LO, FMA_MIX_HI, CVT_F32_F16, OR_SDWA, LSHL_OR, N_OPS
 };
 static const char* op_name[N_OPS] = {
 	"v_add_f32", "v_mul_f32", "v_fma_f32", "v_max_f32", "v_min3_f32", "v_cndmask_b32", "v_mov_b32", "v_pk_mul_f32", "v_pk_add_f32",
@@ -41,7 +42,8 @@ static const char* op_name[N_OPS] = {
 	"v_add_u32", "v_lshlrev_b32", "v_cmp_lt_f32_e64 (into an SGPR pair)", "v_max_i32", "v_med3_f32",
 	"slab mix: 2 v_sub + 2 v_mul + 1 v_cmp_e64 + 2 v_cndmask_e64 + 1 v_max (counted: all 8)",
 	"v_cmp_lt_f32 vcc + v_cndmask_b32_e32 vcc pairs (counted: both)", "v_cndmask_b32_e64 with vcc as the mask operand",
-	"v_cndmask_b32_e32 vcc, dst != src", "v_cmp_lt_f32_e64 sgpr + v_cndmask_b32_e64 sgpr pairs (counted: both)"};
+	"v_cndmask_b32_e32 vcc, dst != src", "v_cmp_lt_f32_e64 sgpr + v_cndmask_b32_e64 sgpr pairs (counted: both)",
+	"v_cvt_f32_ubyte0", "v_cvt_f32_ubyte2", "v_cvt_f32_u32", "v_bfi_b32", "v_ashrrev_i32", "v_perm_b32", "v_xor_b32", "v_mad_u64_u32", "v_mul_lo_u32", "v_mul_hi_u32", "v_bfe_u32", "v_ldexp_f32", "v_and_or_b32", "v_add3_u32", "v_max3_f32", "v_mul_u32_u24", "v_readlane_b32", "v_fma_mix_f32 (src0 = f16 low half)", "v_fma_mix_f32 (src0 = f16 high half)", "v_cvt_f32_f16", "v_or_b32_sdwa (src0 = byte 1)", "v_lshl_or_b32"};
 
 #define R8(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7)
 
@@ -63,6 +65,7 @@ __global__ void __launch_bounds__(256) k_issue(unsigned long long* cycles, float
 	const uint32_t laddr = (threadIdx.x & 63) * 16;
 	const uint32_t laddr4 = (threadIdx.x & 63) * 4;
 	unsigned long long s0 = 1, s1 = 3;
+	int sr = 0;
 	__builtin_amdgcn_s_barrier();
 	const unsigned long long t0 = __builtin_amdgcn_s_memtime();
 	for (int it = 0; it < iters; it++) {
@@ -208,6 +211,94 @@ __global__ void __launch_bounds__(256) k_issue(unsigned long long* cycles, float
 #define X(i) asm volatile("v_cmp_lt_f32_e64 %1, %0, %2\n\tv_cndmask_b32_e64 %0, %0, %2, %1" : "+v"(a[i]), "=&s"(s0) : "v"(b));
 				R8(X)
 #undef X
+			} else if (OP == CVT_UBYTE0) {
+#define X(i) asm volatile("v_cvt_f32_ubyte0 %0, %1" : "=v"(a[i]) : "v"(b));
+				R8(X)
+#undef X
+			} else if (OP == CVT_UBYTE2) {
+#define X(i) asm volatile("v_cvt_f32_ubyte2 %0, %1" : "=v"(a[i]) : "v"(b));
+				R8(X)
+#undef X
+			} else if (OP == CVT_F32_U32) {
+#define X(i) asm volatile("v_cvt_f32_u32 %0, %1" : "=v"(a[i]) : "v"(b));
+				R8(X)
+#undef X
+			} else if (OP == BFI_B32) {
+#define X(i) asm volatile("v_bfi_b32 %0, %1, %0, %2" : "+v"(a[i]) : "v"(b), "v"(c));
+				R8(X)
+#undef X
+			} else if (OP == ASHR_I32) {
+#define X(i) asm volatile("v_ashrrev_i32 %0, 31, %1" : "=v"(a[i]) : "v"(b));
+				R8(X)
+#undef X
+			} else if (OP == PERM_B32) {
+#define X(i) asm volatile("v_perm_b32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(b), "v"(c));
+				R8(X)
+#undef X
+			} else if (OP == XOR_B32) {
+#define X(i) asm volatile("v_xor_b32 %0, %0, %1" : "+v"(a[i]) : "v"(b));
+				R8(X)
+#undef X
+			} else if (OP == MAD_U64_U32) {
+#define X(i) asm volatile("v_mad_u64_u32 %0, %1, %2, %3, 0" : "=v"(p[i]), "=s"(s0) : "v"(b), "v"(c));
+				R8(X)
+#undef X
+			} else if (OP == MUL_LO_U32) {
+#define X(i) asm volatile("v_mul_lo_u32 %0, %0, %1" : "+v"(a[i]) : "v"(b));
+				R8(X)
+#undef X
+			} else if (OP == MUL_HI_U32) {
+#define X(i) asm volatile("v_mul_hi_u32 %0, %0, %1" : "+v"(a[i]) : "v"(b));
+				R8(X)
+#undef X
+			} else if (OP == BFE_U32) {
+#define X(i) asm volatile("v_bfe_u32 %0, %1, 8, 8" : "=v"(a[i]) : "v"(b));
+				R8(X)
+#undef X
+			} else if (OP == LDEXP_F32) {
+#define X(i) asm volatile("v_ldexp_f32 %0, %0, %1" : "+v"(a[i]) : "v"(b));
+				R8(X)
+#undef X
+			} else if (OP == AND_OR_B32) {
+#define X(i) asm volatile("v_and_or_b32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(b), "v"(c));
+				R8(X)
+#undef X
+			} else if (OP == ADD3_U32) {
+#define X(i) asm volatile("v_add3_u32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(b), "v"(c));
+				R8(X)
+#undef X
+			} else if (OP == MAX3_F32) {
+#define X(i) asm volatile("v_max3_f32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(b), "v"(c));
+				R8(X)
+#undef X
+			} else if (OP == MUL_U24) {
+#define X(i) asm volatile("v_mul_u32_u24 %0, %0, %1" : "+v"(a[i]) : "v"(b));
+				R8(X)
+#undef X
+			} else if (OP == READLANE) {
+#define X(i) asm volatile("v_readlane_b32 %0, %1, 3" : "=s"(sr) : "v"(a[i]));
+				R8(X)
+#undef X
+			} else if (OP == FMA_MIX_LO) {
+#define X(i) asm volatile("v_fma_mix_f32 %0, %1, %2, %0 op_sel_hi:[1,0,0]" : "+v"(a[i]) : "v"(b), "v"(c));
+				R8(X)
+#undef X
+			} else if (OP == FMA_MIX_HI) {
+#define X(i) asm volatile("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(a[i]) : "v"(b), "v"(c));
+				R8(X)
+#undef X
+			} else if (OP == CVT_F32_F16) {
+#define X(i) asm volatile("v_cvt_f32_f16 %0, %1" : "=v"(a[i]) : "v"(b));
+				R8(X)
+#undef X
+			} else if (OP == OR_SDWA) {
+#define X(i) asm volatile("v_or_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD" : "=v"(a[i]) : "v"(b), "v"(c));
+				R8(X)
+#undef X
+			} else if (OP == LSHL_OR) {
+#define X(i) asm volatile("v_lshl_or_b32 %0, %0, 3, %1" : "+v"(a[i]) : "v"(b));
+				R8(X)
+#undef X
 			} else if (OP == MIX_SLAB) {
 				asm volatile(
 					"v_sub_f32 %0, %0, %8\n\tv_sub_f32 %1, %1, %8\n\tv_mul_f32 %2, %2, %9\n\tv_mul_f32 %3, %3, %9\n\t"
@@ -226,7 +317,7 @@ __global__ void __launch_bounds__(256) k_issue(unsigned long long* cycles, float
 		}
 	}
 	const unsigned long long t1 = __builtin_amdgcn_s_memtime();
-	float acc = b + c + (float)(s0 & 1);
+	float acc = b + c + (float)(s0 & 1) + (float)sr;
 	for (int i = 0; i < 8; i++) acc += a[i] + p[i].x + p[i].y;
 	for (int i = 0; i < 4; i++) acc += q[i].x + q[i].w;
 	if (acc == 12345.678f) sink[0] = acc;

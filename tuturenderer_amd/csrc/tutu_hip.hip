@@ -110,6 +110,7 @@ struct TutuCtx {
 		int wide_inner_steps = 2; // TUTU_WIDE_INNER_STEPS node visits per round on the wide tree  [1, 64]
 		int lds_stack_max = 32;   // TUTU_LDS_STACK_MAX  k_trace, binary tree: entries of the LDS tier of a deep tree's stack, 0 = all in LDS  [0, 64]
 		int wide_lds_stack = 19;  // TUTU_WIDE_LDS_STACK k_trace, wide tree: entries of the LDS tier (19 KB: eight blocks per CU)  [4, 64]
+		int trace_xcd = 1;        // TUTU_TRACE_XCD      1: the blocks of one XCD take ADJACENT ranges of the work list  [0, 1]
 		int leaf_again = 24;      // TUTU_LEAF_AGAIN     lanes still holding a leaf that trigger a second leaf step per round, 65 = never  [1, 65]
 		int kernel_events = 0;    // TUTU_KERNEL_EVENTS  a HIP event pair around every launch (per-kernel times in TutuStats; 2.7 % of a frame)  {0, 1}
 		int any_near_first = 1;   // TUTU_ANY_NEAR_FIRST any-hit: nearer child first              {0, 1}
@@ -183,6 +184,7 @@ const KnobDesc kKnobs[] = {
     {"any_near_first", "TUTU_ANY_NEAR_FIRST", &TutuCtx::Knobs::any_near_first, 0, 1},
     {"kernel_events", "TUTU_KERNEL_EVENTS", &TutuCtx::Knobs::kernel_events, 0, 1},
     {"leaf_again", "TUTU_LEAF_AGAIN", &TutuCtx::Knobs::leaf_again, 1, 65},
+    {"trace_xcd", "TUTU_TRACE_XCD", &TutuCtx::Knobs::trace_xcd, 0, 1},
     {"util_stats", "TUTU_UTIL_STATS", &TutuCtx::Knobs::util_stats, 0, 1},
     {"bidir_units", "TUTU_BIDIR_UNITS", &TutuCtx::Knobs::bidir_units, 64, 1 << 24},
 };
@@ -467,6 +469,7 @@ int run_pass(TutuCtx* c, WorkSet& w, hipStream_t s, const TutuCameraFrame* cam, 
 		tp.inner_steps = c->sc.has_wide ? c->knobs.wide_inner_steps : c->knobs.inner_steps;
 		tp.any_near_first = c->knobs.any_near_first;
 		tp.leaf_again = c->knobs.leaf_again;
+		tp.xcd_map = c->knobs.trace_xcd;
 		tp.part = w.part.p;
 		tp.defer = w.defer.p;
 		TIMED(EV_TRACE_CLOSEST, launch_trace<false>(c, s, trace_grid, tp));
@@ -1199,6 +1202,7 @@ int lt_wavefront_batch(TutuCtx* c, hipStream_t s, BidirParams p) {
 	tp.inner_steps = c->sc.has_wide ? c->knobs.wide_inner_steps : c->knobs.inner_steps;
 	tp.any_near_first = c->knobs.any_near_first;
 	tp.leaf_again = c->knobs.leaf_again;
+	tp.xcd_map = 0;
 	tp.part = nullptr;
 	tp.defer = w.defer.p;
 	const int grid = persistent_grid(p.n_units, c->n_cu, c->trace_blocks_per_cu);
@@ -1607,6 +1611,7 @@ static int run_trace_kernel(TutuCtx* c, uint32_t n, bool any) {
 	tp.inner_steps = c->sc.has_wide ? c->knobs.wide_inner_steps : TUTU_INNER_STEPS;
 	tp.any_near_first = 1;
 	tp.leaf_again = c->knobs.leaf_again;
+	tp.xcd_map = 0;
 	const int grid = persistent_grid(n, c->n_cu, c->trace_blocks_per_cu);
 	if (any) launch_trace<true>(c, s, grid, tp);
 	else launch_trace<false>(c, s, grid, tp);
