@@ -342,7 +342,7 @@ int tutu_hip_quantise(TutuCtx* ctx, uint32_t n, const float* values, int32_t* le
  *   tutu_hip_render_integrator; batches are whole pixels) |
  *   "wide" TUTU_WIDE [0,2] (memory-resident scenes: 0 walk the binary SAH tree, 1 the four-wide quantised tree when the binary
  *   nodes take at least "wide_min_mb" TUTU_WIDE_MIN_MB [0,65536] megabytes (default 0: always), 2 always) |
- *   "wide_inner_steps" TUTU_WIDE_INNER_STEPS [1,64] | "wide_lds_stack" TUTU_WIDE_LDS_STACK [4,64] and "lds_stack_max"
+ *   "wide_inner_steps" TUTU_WIDE_INNER_STEPS [1,64] / "wide_inner_steps_any" TUTU_WIDE_INNER_STEPS_ANY [1,64] | "wide_lds_stack" TUTU_WIDE_LDS_STACK [4,64] and "lds_stack_max"
  *   TUTU_LDS_STACK_MAX [0,64]: entries of the traversal stack kept in LDS (wide / binary tree); deeper ones live in HBM.
  *   Read-only facts: "wide_tree", "wide_depth", "fast_depth", "stack_entries", "stack_entries_hbm", "trace_blocks_per_cu",
  *   "trace_lds_bytes".

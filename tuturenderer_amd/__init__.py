@@ -301,7 +301,7 @@ class Context:
         _check(self.lib.tutu_hip_set_option(self.h, C.c_char_p(name.encode()), C.c_int(int(value))), "tutu_hip_set_option")
 
     OPTION_NAMES = ("sets", "sets_default", "one_set", "shade_bpc", "trace_bpc", "refill_min", "inner_steps", "inner_steps_any", "leaf_again", "trace_xcd", "kernel_events", "any_near_first",
-                    "util_stats", "bidir_units", "sah_tree", "n_refs", "lds_scene", "shade_tab", "fast_depth", "stack_entries", "stack_entries_hbm", "lds_stack_max", "wide", "wide_min_mb", "wide_inner_steps", "wide_tree", "wide_depth", "wide_early", "pair_leaves",
+                    "util_stats", "bidir_units", "sah_tree", "n_refs", "lds_scene", "shade_tab", "fast_depth", "stack_entries", "stack_entries_hbm", "lds_stack_max", "wide", "wide_min_mb", "wide_inner_steps", "wide_inner_steps_any", "wide_tree", "wide_depth", "wide_early", "pair_leaves",
                     "trace_blocks_per_cu", "trace_lds_bytes")
 
     def get_option(self, name):

@@ -107,7 +107,8 @@ struct TutuCtx {
 		int wide_min_mb = 0;      // TUTU_WIDE_MIN_MB    ... "big" = at least this many MB of binary nodes  [0, 65536]
 		int wide_early = 1;       // TUTU_WIDE_EARLY     leaf box with the triangle record: 0 never, 1 small trees, 2 always  [0, 2]
 		int wide_early_max_mb = 8;  // TUTU_WIDE_EARLY_MAX_MB  ... "small" = fewer MB of wide nodes than this  [0, 65536]
-		int wide_inner_steps = 2; // TUTU_WIDE_INNER_STEPS node visits per round on the wide tree  [1, 64]
+		int wide_inner_steps = 4; // TUTU_WIDE_INNER_STEPS node visits per round on the wide tree, closest-hit  [1, 64]
+		int wide_inner_steps_any = 4;  // TUTU_WIDE_INNER_STEPS_ANY  the same, any-hit  [1, 64]
 		int lds_stack_max = 32;   // TUTU_LDS_STACK_MAX  k_trace, binary tree: entries of the LDS tier of a deep tree's stack, 0 = all in LDS  [0, 64]
 		int wide_lds_stack = 19;  // TUTU_WIDE_LDS_STACK k_trace, wide tree: entries of the LDS tier (19 KB: eight blocks per CU)  [4, 64]
 		int trace_xcd = 1;        // TUTU_TRACE_XCD      1: the blocks of one XCD take ADJACENT ranges of the work list  [0, 1]
@@ -179,6 +180,7 @@ const KnobDesc kKnobs[] = {
     {"wide", "TUTU_WIDE", &TutuCtx::Knobs::wide, 0, 2},
     {"wide_min_mb", "TUTU_WIDE_MIN_MB", &TutuCtx::Knobs::wide_min_mb, 0, 65536},
     {"wide_inner_steps", "TUTU_WIDE_INNER_STEPS", &TutuCtx::Knobs::wide_inner_steps, 1, 64},
+    {"wide_inner_steps_any", "TUTU_WIDE_INNER_STEPS_ANY", &TutuCtx::Knobs::wide_inner_steps_any, 1, 64},
     {"wide_early", "TUTU_WIDE_EARLY", &TutuCtx::Knobs::wide_early, 0, 2},
     {"wide_early_max_mb", "TUTU_WIDE_EARLY_MAX_MB", &TutuCtx::Knobs::wide_early_max_mb, 0, 65536},
     {"any_near_first", "TUTU_ANY_NEAR_FIRST", &TutuCtx::Knobs::any_near_first, 0, 1},
@@ -477,7 +479,7 @@ int run_pass(TutuCtx* c, WorkSet& w, hipStream_t s, const TutuCameraFrame* cam, 
 		tp.list = w.lists.p + w.cap;
 		tp.n_ptr = meta + 1;
 		tp.part = w.part.p + 4 * TUTU_PART_BLOCKS;
-		tp.inner_steps = c->sc.has_wide ? c->knobs.wide_inner_steps : c->knobs.inner_steps_any;
+		tp.inner_steps = c->sc.has_wide ? c->knobs.wide_inner_steps_any : c->knobs.inner_steps_any;
 		TIMED(EV_TRACE_ANY, launch_trace<true>(c, s, trace_grid, tp));
 	}
 	return TUTU_OK;
