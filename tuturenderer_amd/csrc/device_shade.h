@@ -938,10 +938,7 @@ TUTU_DEV void trace_persistent(const S& ss, const TraceParams& tp, int* stack, c
 					n_nodes++;
 					const int p1 = entry_read(sp - 1);
 					const float4 n0 = sc.wnodes[4 * cur + 0], n1 = sc.wnodes[4 * cur + 1], n2 = sc.wnodes[4 * cur + 2], n3 = sc.wnodes[4 * cur + 3];
-					const uint32_t exps = __float_as_uint(n0.w);
-					const float sx = ldexpf(r.inv.x, (int)(exps & 0xFFu) - 128);
-					const float sy = ldexpf(r.inv.y, (int)((exps >> 8) & 0xFFu) - 128);
-					const float sz = ldexpf(r.inv.z, (int)((exps >> 16) & 0xFFu) - 128);
+					const float sx = r.inv.x * n0.w, sy = r.inv.y * n3.z, sz = r.inv.z * n3.w;  // 2^e / d: the scales are powers of two
 					const float ox = (n0.x - r.o.x) * r.inv.x, oy = (n0.y - r.o.y) * r.inv.y, oz = (n0.z - r.o.z) * r.inv.z;
 					const uint32_t qlx = __float_as_uint(n2.x), qly = __float_as_uint(n2.y), qlz = __float_as_uint(n2.z);
 					const uint32_t qhx = __float_as_uint(n2.w), qhy = __float_as_uint(n3.x), qhz = __float_as_uint(n3.y);

@@ -608,7 +608,9 @@ static bool build_wide(const std::vector<BuildNode>& t, const LeafRef& leaf_ref,
 				w.qhi[a] |= qh << (8 * k);
 			}
 		}
-		w.exps = (uint32_t)(e[0] + 128) | ((uint32_t)(e[1] + 128) << 8) | ((uint32_t)(e[2] + 128) << 16);
+		w.scale_x = std::ldexp(1.0f, e[0]);
+		w.scale_yz[0] = std::ldexp(1.0f, e[1]);
+		w.scale_yz[1] = std::ldexp(1.0f, e[2]);
 		int32_t any_leaf = INT_MIN;
 		for (int k = 0; k < 4; k++) {
 			if (ch[k] < 0) continue;

@@ -26,7 +26,7 @@ static_assert(sizeof(GpuNode) == 64, "GpuNode must be 64 B");
 // One node of the WIDE tree the persistent traversal kernels walk on memory-resident scenes (round 3): four children,
 // their boxes quantised to 8 bits per plane in the node's own frame -- 64 B for four children where GpuNode spends 64 B on
 // two, so a ray fetches half the bytes in half the round trips.  Plane k of child c along axis a lies at
-//     p[a] + q * 2^e[a],  q = byte c of qlo[a] / qhi[a]
+//     p[a] + q * scale[a],  q = byte c of qlo[a] / qhi[a],  scale[a] = 2^e[a] as a float (-60 <= e <= 60)
 // and the quantised box CONTAINS the child's true box with a margin that covers the rounding of the kernel's
 // fma(q, 2^e * inv, (p - o) * inv) against the reference's (x - o) * inv (host_scene.cpp: build_wide).  A wider box can
 // only let more candidates through; every candidate is still validated against the reference's leaf box.
@@ -34,11 +34,11 @@ static_assert(sizeof(GpuNode) == 64, "GpuNode must be 64 B");
 // corner and the reference of one of the node's own leaves (harmless if ever hit: a leaf test is idempotent).
 struct GpuWideNode {
 	float p[3];
-	uint32_t exps;      // byte a: e[a] + 128
+	float scale_x;      // 2^e[0]: the kernel scales 1/d by a multiplication (exact: a power of two, no overflow for the rays it admits)
 	int32_t child[4];
 	uint32_t qlo[3];    // axis a: byte c = child c
 	uint32_t qhi[3];
-	uint32_t pad[2];
+	float scale_yz[2];  // 2^e[1], 2^e[2]
 };
 static_assert(sizeof(GpuWideNode) == 64, "GpuWideNode must be 64 B");
 
