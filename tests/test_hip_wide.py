@@ -187,3 +187,51 @@ def test_pair_leaves_do_not_change_a_frame(tr, monkeypatch):
     assert out["pairs"][0].tobytes() == out["single"][0].tobytes()
     assert out["pairs"][1]["closest_rays"] == out["single"][1]["closest_rays"]
     assert out["pairs"][1]["nodes_closest"] < out["single"][1]["nodes_closest"]
+
+
+def test_clipped_references_do_not_lose_an_ill_conditioned_hit(tr, port):
+    """One ray of the broom stand-in (found in round 3 through a frame CRC that took two values): the reference's fp32
+    triangle test reports the hit of a needle triangle 0.06 in FRONT of where the ray crosses it, outside the box of the
+    clipped reference the ray passes through -- with a pruning slack of 1 + 1e-4 the hit was lost whenever the farther
+    neighbour had been found first, which depends on the other lanes of the wave (alone: right; 64 copies in lock step:
+    wrong).  device_trace.h: TUTU_PRUNE_SLACK_CLOSEST."""
+    from tuturenderer_amd import scenes
+
+    sc = scenes.broom_room(1600, 900)
+    o = np.array([0.000500953639857471, 426.0531311035156, 500.1503601074219], np.float32)
+    d = np.array([0.9181594848632812, -0.3909607231616974, -0.06428715586662292], np.float32)
+    S = port.scene(sc)
+    hit, t, tri, _, _, _ = S.closest(o[None], d[None])
+    S.close()
+    assert hit[0] == 1
+    rng = np.random.default_rng(7)
+    n = 1 << 18
+    O = np.empty((n, 3), np.float32)
+    O[:, 0] = rng.uniform(5, 545, n)
+    O[:, 1] = rng.uniform(5, 545, n)
+    O[:, 2] = rng.uniform(5, 555, n)
+    D = rng.normal(size=(n, 3)).astype(np.float32)
+    D /= np.linalg.norm(D, axis=1, keepdims=True)
+    pos = rng.choice(n, 4096, replace=False)
+    O[pos] = o
+    D[pos] = d
+    with tr.Context(sc) as ctx:
+        assert ctx.options()["n_refs"] > len(sc["mat_id"])  # the scene is built WITH clipped references
+        for oo, dd, idx in ((o[None], d[None], np.arange(1)), (np.repeat(o[None], 4096, 0), np.repeat(d[None], 4096, 0), np.arange(4096)), (O, D, pos)):
+            h = ctx.trace_closest(oo, dd)[idx]
+            assert (h["tri"] == tri[0]).all(), np.unique(h["tri"], return_counts=True)
+            assert bit_equal(h["t"], np.full(len(idx), t[0], np.float32))
+
+
+def test_a_frame_does_not_depend_on_what_fresh_allocations_contain(tr, monkeypatch):
+    """TUTU_DEBUG_FILL: every device allocation of the second context starts out as 0xAA bytes"""
+    sc, key1 = _scene("veach_slight")
+    monkeypatch.delenv("TUTU_DEBUG_FILL", raising=False)
+    with tr.Context(sc) as ctx:
+        a = ctx.render(8, 0x5EED0001, key1)
+    monkeypatch.setenv("TUTU_DEBUG_FILL", "170")
+    with tr.Context(sc) as ctx:
+        b = ctx.render(8, 0x5EED0001, key1)
+        c = ctx.render(8, 0x5EED0001, key1)
+    monkeypatch.delenv("TUTU_DEBUG_FILL", raising=False)
+    assert bit_equal(a, b) and bit_equal(a, c)

@@ -1067,7 +1067,7 @@ TUTU_DEV void trace_persistent(const S& ss, const TraceParams& tp, int* stack, c
 						if (ANY) blocked = true;
 						else {
 							best_t = t; best_u = u; best_v = v; best_tri = ti;
-							lim = t * TUTU_PRUNE_SLACK;
+							lim = t * TUTU_PRUNE_SLACK_CLOSEST;
 						}
 					}
 				} else {
@@ -1083,7 +1083,7 @@ TUTU_DEV void trace_persistent(const S& ss, const TraceParams& tp, int* stack, c
 							if (ANY) blocked = true;
 							else {
 								best_t = t; best_u = u; best_v = v; best_tri = ti;
-								lim = t * TUTU_PRUNE_SLACK;
+								lim = t * TUTU_PRUNE_SLACK_CLOSEST;
 							}
 						}
 					}

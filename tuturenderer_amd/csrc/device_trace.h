@@ -11,7 +11,7 @@
 //   * closest hit = minimum t, exact ties resolved toward the leftmost leaf (`<=` at BVH.hpp:165) -- triangles are
 //     stored in left-to-right leaf order, so the tie-break is `index <`.
 // What is new: near-child-first order and pruning of subtrees whose entry distance exceeds the best t so far
-// (times 1+1e-4 of slack, to stay on the safe side of the two different roundings of slab-t and triangle-t).
+// (times a slack: TUTU_PRUNE_SLACK_CLOSEST below, and what it has to cover).
 // The reference visits every node whose box is hit; the result is the same, the work is not.
 //
 // Two scene accessors: SceneGlobal reads nodes/triangles from HBM (L1/L2-cached gathers); SceneLds reads a
@@ -28,7 +28,19 @@
 namespace tutu {
 
 #define TUTU_STACK_DEPTH 32
-#define TUTU_PRUNE_SLACK 1.0001f
+// Pruning limits.  A subtree is skipped when the ray enters its box beyond limit = (best t so far | length of the shadow ray)
+// x slack.  The slack has to cover more than the two roundings of slab-t and triangle-t: the reference's fp32 triangle
+// test (Triangle.hpp:23-59) is ill-conditioned for needle-shaped triangles and grazing rays -- its t can lie in FRONT of
+// the point where the ray crosses the triangle by 16 u (|o - v0| + t) / (sin(angle at v0) |cos(ray, normal)|), 0.06 for one
+// ray of the broom stand-in at t = 312 -- while a CLIPPED reference of such a triangle (host_scene.cpp: early split
+// clipping) has a box that hugs the crossing point.  With 1 + 1e-4 that ray lost its closest hit whenever a farther
+// triangle had been found first (one sample of the 1.5e9 of BASELINE config 4, found because the order in which a lane
+// meets leaves depends on the other lanes of its wave: the frame's CRC took two values).  Closest-hit rays therefore
+// prune at 1 + 2^-8: forty times the distance, for +0.7 % node visits on the broom stand-in and none elsewhere.  Shadow
+// rays keep 1 + 1e-4 (a larger slack makes every shadow ray test what lies just behind the light it aims at: -5 % on the
+// Cornell box); their exposure is the shell of that thickness in front of the light only.  DESIGN.md section 4.
+#define TUTU_PRUNE_SLACK 1.0001f              // shadow rays: length of the ray
+#define TUTU_PRUNE_SLACK_CLOSEST 1.00390625f  // closest-hit rays: best t so far
 #define TUTU_TRAV_DONE INT_MIN
 #define TUTU_PAIR_BITS 14
 
@@ -308,7 +320,7 @@ TUTU_DEV void trace_closest(const S& ss, const SceneDev& sc, V3 o, V3 d, int* st
 	int sp = 0;
 	for (;;) {
 		while (cur >= 0) {
-			const float lim = best_tri >= 0 ? best_t * TUTU_PRUNE_SLACK : FLT_MAX;
+			const float lim = best_tri >= 0 ? best_t * TUTU_PRUNE_SLACK_CLOSEST : FLT_MAX;
 			const ChildTest ct = test_children(ss, cur, r, lim);
 			if (ct.hl && ct.hr) {
 				const bool right_first = ct.tr < ct.tl;

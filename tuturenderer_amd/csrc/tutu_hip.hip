@@ -43,6 +43,13 @@ struct EvPair {
 	int kind;
 };
 
+// TUTU_DEBUG_FILL=<byte>: every fresh device allocation is filled with that byte (tests: no result may depend on what
+// hipMalloc hands out).  The fill is followed by a device synchronisation: it runs on the null stream, which is not
+// ordered with the library's non-blocking streams.
+static int debug_fill() {
+	const char* e = getenv("TUTU_DEBUG_FILL");  // (read at every allocation: a test switches it between two contexts)
+	return e ? std::max(0, std::min(255, atoi(e))) : -1;
+}
 template <typename T>
 struct DevBuf {
 	T* p = nullptr;
@@ -54,6 +61,10 @@ struct DevBuf {
 		n = 0;
 		if (want == 0) return TUTU_OK;
 		HIP_TRY(hipMalloc((void**)&p, want * sizeof(T)));
+		if (debug_fill() >= 0) {
+			HIP_TRY(hipMemset(p, debug_fill(), want * sizeof(T)));
+			HIP_TRY(hipDeviceSynchronize());
+		}
 		n = want;
 		return TUTU_OK;
 	}
