@@ -235,3 +235,40 @@ def test_a_frame_does_not_depend_on_what_fresh_allocations_contain(tr, monkeypat
         c = ctx.render(8, 0x5EED0001, key1)
     monkeypatch.delenv("TUTU_DEBUG_FILL", raising=False)
     assert bit_equal(a, b) and bit_equal(a, c)
+
+
+def test_broom_stand_in_rays_from_surfaces_vs_oracle(tr, port):
+    """The scene with 14 clipped references per triangle, rays as a path tracer casts them: from random points, then from
+    the hit points into the hemisphere, then shadow segments between surface points -- object, t bits and blocked flags
+    against the CPU restatement (which never prunes).  (16.6 M such rays were compared once in round 3: no difference.)"""
+    from tuturenderer_amd import scenes
+
+    sc = scenes.broom_room(1600, 900)
+    S = port.scene(sc)
+    rng = np.random.default_rng(11)
+    n = 1 << 17
+    O = np.empty((n, 3), np.float32)
+    O[:, 0] = rng.uniform(5, 545, n)
+    O[:, 1] = rng.uniform(5, 545, n)
+    O[:, 2] = rng.uniform(5, 555, n)
+    D = rng.normal(size=(n, 3)).astype(np.float32)
+    D /= np.linalg.norm(D, axis=1, keepdims=True)
+    with tr.Context(sc) as ctx:
+        hit, t, tri, pos, Ns, _ = S.closest(O, D)
+        h = ctx.trace_closest(O, D)
+        assert bit_equal(h["tri"], np.where(hit == 1, tri, -1).astype(np.int32))
+        assert bit_equal(h["t"][hit == 1], t[hit == 1])
+        m = hit == 1
+        O2 = (pos[m] + Ns[m] * np.float32(5e-4)).astype(np.float32)
+        D2 = rng.normal(size=O2.shape).astype(np.float32)
+        D2 /= np.linalg.norm(D2, axis=1, keepdims=True)
+        back = (D2 * Ns[m]).sum(axis=1) < 0
+        D2[back] = -D2[back]
+        hit2, t2, tri2, pos2, _, _ = S.closest(O2, D2)
+        h2 = ctx.trace_closest(O2, D2)
+        assert bit_equal(h2["tri"], np.where(hit2 == 1, tri2, -1).astype(np.int32))
+        assert bit_equal(h2["t"][hit2 == 1], t2[hit2 == 1])
+        A = O2[hit2 == 1]
+        B = pos2[hit2 == 1][::-1].copy()
+        assert bit_equal(ctx.trace_any(A, B), S.any_hit(A, B))
+    S.close()
