@@ -131,7 +131,7 @@ typedef struct TutuRenderParams {
 	int32_t n_pixels;
 	int32_t x0, y0, x1, y1;
 	int32_t spp_per_pass; /* samples per pixel traced per wavefront pass; 0 = choose from max_paths */
-	int64_t max_paths;    /* cap on paths in flight, summed over the (up to 4) work sets whose passes overlap (device memory ~ 190 B each); 0 = default 48 Mi */
+	int64_t max_paths;    /* cap on paths in flight, summed over the (up to 4) work sets whose passes overlap (device memory ~ 400 B each); 0 = default 168 Mi = 67 GB, less if the device has less free */
 } TutuRenderParams;
 
 typedef struct TutuStats {

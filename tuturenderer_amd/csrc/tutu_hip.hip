@@ -78,6 +78,7 @@ struct DevBuf {
 }  // namespace
 
 #define TUTU_MAX_SETS 4  // work sets = passes in flight, one stream each
+#define TUTU_BYTES_PER_SLOT 400  // device memory of a work set per path slot (two record sets of ten 16-B fields, hits, lists, ...)
 
 struct TutuCtx {
 	int device = 0;
@@ -600,19 +601,29 @@ int render_impl(TutuCtx* c, const TutuCameraFrame* cam, const TutuRenderParams* 
 	HIP_TRY(hipSetDevice(c->device));
 	c->want_stats = st != nullptr;
 	// Paths in flight: max_paths in total, split over the work sets whose passes run concurrently, one stream each
-	// (measured on the Cornell box, 512 spp: 2 sets x 8 Mi 1518 Msamples/s, 3 x 8 Mi 1619, 4 x 8 Mi 1645; later, on a
-	// faster box: 4 x 4 Mi 1545, 4 x 8 Mi 1725, 4 x 12 Mi 1753, 4 x 16 Mi 1714; 5, 6 or 8 sets are slower than 4).
-	const int64_t max_paths = rp->max_paths > 0 ? rp->max_paths : ((int64_t)48 << 20);
+	// (round 1, Cornell box, 512 spp: 2 sets x 8 Mi 1518 Msamples/s, 3 x 8 Mi 1619, 4 x 8 Mi 1645; 4 x 12 Mi 1753, 4 x 16 Mi
+	// 1714; 5, 6 or 8 sets are slower than 4.  Round 3, with the persistent kernels: the bigger the pass the better, as long
+	// as every stream gets the same whole number of passes -- Cornell box 27 passes of 19 spp 2593, 8 x 64 spp 2750, 4 x 128
+	// 2794, but 6 x 86 2618 and 5 x 103 2463; bunny stand-in 24 x 11 spp 1316, 8 x 32 1389; veach room 20 x 26 1235, 8 x 64
+	// 1291; broom stand-in 128 x 8 613, 47 x 22 644.  Hence 42 Mi slots per work set: 16.6 GB each, 67 GB of the 288.)
+	int64_t max_paths = rp->max_paths > 0 ? rp->max_paths : ((int64_t)168 << 20);
+	if (rp->max_paths <= 0) {
+		// the default must fit the device: at most half of what is free now plus what this context's work sets already hold
+		size_t free_b = 0, total_b = 0, held = 0;
+		for (int k = 0; k < TUTU_MAX_SETS; k++) held += c->ws[k].cap * (size_t)TUTU_BYTES_PER_SLOT;
+		if (hipMemGetInfo(&free_b, &total_b) == hipSuccess)
+			max_paths = std::max<int64_t>((int64_t)4 << 20, std::min<int64_t>(max_paths, (int64_t)((free_b + held) / 2 / TUTU_BYTES_PER_SLOT)));
+	}
 	const int want_sets = std::max(1, std::min(c->opt_sets > 0 ? c->opt_sets : c->knobs.sets, TUTU_MAX_SETS));
 	// the pass size does not depend on how many passes are in flight (TUTU_SETS / tutu_hip_set_option "sets" are
-	// measuring aids): max_paths is always split into TUTU_MAX_SETS passes' worth of slots
+	// measuring aids): max_paths is always split into TUTU_MAX_SETS passes' worth of slots, and the passes of a frame are
+	// equal and a multiple of TUTU_MAX_SETS in number (no stream is left alone with a last pass)
 	int spp_pass = rp->spp_per_pass > 0 ? rp->spp_per_pass : (int)std::max<int64_t>(1, (max_paths / TUTU_MAX_SETS) / npix);
 	spp_pass = std::min(spp_pass, rp->spp);
 	spp_pass = std::min(spp_pass, 65535);  // grid.y limit
 	int n_passes = (rp->spp + spp_pass - 1) / spp_pass;
-	if (rp->spp_per_pass <= 0 && n_passes > want_sets && n_passes % want_sets != 0) {
-		// equal passes, a whole number of them per stream: no stream is left alone with a last pass
-		n_passes = (n_passes + want_sets - 1) / want_sets * want_sets;
+	if (rp->spp_per_pass <= 0 && n_passes >= TUTU_MAX_SETS) {
+		n_passes = (n_passes + TUTU_MAX_SETS - 1) / TUTU_MAX_SETS * TUTU_MAX_SETS;
 		spp_pass = (rp->spp + n_passes - 1) / n_passes;
 		n_passes = (rp->spp + spp_pass - 1) / spp_pass;
 	}
