@@ -665,7 +665,7 @@ def test_config3_frame_bunny_stand_in_1024x1024_256spp(tr, port):
     from tuturenderer_amd import scenes
 
     frame, st = _frame_checks(tr, port, scenes.bunny_box(1024, 1024), key1=3, spp=256, n_probe_pixels=8)
-    assert 0.2 < frame.mean() < 0.6 and st["passes"] >= 16
+    assert 0.2 < frame.mean() < 0.6 and st["passes"] >= 8
 
 
 def test_config4_frame_broom_stand_in_1600x900_1024spp(tr, port):
