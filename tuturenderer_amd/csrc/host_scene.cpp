@@ -385,17 +385,6 @@ struct Poly {
 	int n;
 	double p[12][3];
 };
-static double poly_area(const Poly& q) {
-	double ax = 0, ay = 0, az = 0;
-	for (int i = 1; i + 1 < q.n; i++) {
-		const double e1[3] = {q.p[i][0] - q.p[0][0], q.p[i][1] - q.p[0][1], q.p[i][2] - q.p[0][2]};
-		const double e2[3] = {q.p[i + 1][0] - q.p[0][0], q.p[i + 1][1] - q.p[0][1], q.p[i + 1][2] - q.p[0][2]};
-		ax += e1[1] * e2[2] - e1[2] * e2[1];
-		ay += e1[2] * e2[0] - e1[0] * e2[2];
-		az += e1[0] * e2[1] - e1[1] * e2[0];
-	}
-	return 0.5 * std::sqrt(ax * ax + ay * ay + az * az);
-}
 // the part of q with coordinate `axis` <= plane (keep_low) or >= plane
 static Poly poly_clip(const Poly& q, int axis, double plane, bool keep_low) {
 	Poly r;
