@@ -322,6 +322,15 @@ __global__ void __launch_bounds__(256) k_shade(PassParams pp) {
 	__shared__ uint32_t g_next[1];
 	uint32_t win = blockIdx.x, win_chunks = 0;
 	bool have_win = false;
+	uint32_t next_slot = 0;  // (one-class kernels) list entry and class of this lane's record in the NEXT chunk of the wave
+	int next_class = 0;
+	if (!FIRST && !GROUP) {
+		const uint32_t j0 = chunk * 64u + lane;
+		if (j0 < n_in) {
+			next_slot = pp.list[j0];
+			next_class = pp.hitK[j0] & 7;
+		}
+	}
 
 	for (;;) {
 		if (GROUP) {
@@ -404,13 +413,22 @@ __global__ void __launch_bounds__(256) k_shade(PassParams pp) {
 				const uint32_t e0 = win * WCH * 64u;
 				act = e < min(WCH * 64u, n_in - e0);
 				j = e0 + (act ? (uint32_t)g_src[e] : 0u);
+				if (act) {
+					slot_in = pp.list[j];
+					chunk_class = pp.hitK[j] & 7;
+				}
 			} else {
+				// the list entry and the class byte of a chunk are requested one chunk AHEAD (next_slot / next_class): the records
+				// hang on the list entry, and two dependent round trips per chunk are what a wave of this kernel mostly waits for
 				j = chunk * 64u + lane;
 				act = j < n_in;
-			}
-			if (act) {
-				slot_in = pp.list[j];
-				chunk_class = pp.hitK[j] & 7;
+				slot_in = next_slot;
+				chunk_class = next_class;
+				const uint32_t jn = (chunk + chunk_step) * 64u + lane;
+				if (jn < n_in) {
+					next_slot = pp.list[jn];
+					next_class = pp.hitK[jn] & 7;
+				}
 			}
 		}
 		uint32_t key = 0;       // TUTU_KEY_* of the record this lane leaves behind (0: the path ended here)
