@@ -346,6 +346,8 @@ int tutu_hip_quantise(TutuCtx* ctx, uint32_t n, const float* values, int32_t* le
  *   TUTU_LDS_STACK_MAX [0,64]: entries of the traversal stack kept in LDS (wide / binary tree); deeper ones live in HBM.
  *   Read-only facts: "wide_tree", "wide_depth", "fast_depth", "stack_entries", "stack_entries_hbm", "trace_blocks_per_cu",
  *   "trace_lds_bytes".
+ *   Testing aid, read at every device allocation rather than at create: TUTU_DEBUG_FILL=<0..255> fills every fresh allocation
+ *   with that byte (no result may depend on what hipMalloc hands out; tests/test_hip_wide.py).
  * tutu_hip_get_option reports the effective value of any of them, plus the read-only facts "sah_tree", "lds_scene"
  * and "shade_tab" -- a benchmark line should echo them (bench.py does). */
 int tutu_hip_set_option(TutuCtx* ctx, const char* name, int value);
