@@ -128,7 +128,7 @@ struct TutuCtx {
 		int kernel_events = 0;    // TUTU_KERNEL_EVENTS  a HIP event pair around every launch (per-kernel times in TutuStats; 2.7 % of a frame)  {0, 1}
 		int any_near_first = 1;   // TUTU_ANY_NEAR_FIRST any-hit: nearer child first              {0, 1}
 		int util_stats = 0;       // TUTU_UTIL_STATS     phase counters of the traversal kernels  {0, 1}
-		int bidir_units = 1 << 21;  // TUTU_BIDIR_UNITS  LightTracing / NaivePT / BDPT: (pixel, sample) units per batch  [64, 2^24]
+		int bidir_units = 1 << 23;  // TUTU_BIDIR_UNITS  LightTracing / NaivePT / BDPT: (pixel, sample) units per batch  [64, 2^24]  (2 -> 8 Mi: LightTracing +8 %, NaivePT +20 %, BDPT flat; 3.8 GB of BDPT lists)
 	} knobs;
 	int shade_mode_all = SHADE_ANY;  // the kernel of that launch: the scene's only scattering class, or SHADE_ANY
 	DevBuf<float4> d_tri_tex, d_texels, d_tex_desc, d_leaf_boxes, d_wnodes;
