@@ -272,3 +272,24 @@ def test_broom_stand_in_rays_from_surfaces_vs_oracle(tr, port):
         B = pos2[hit2 == 1][::-1].copy()
         assert bit_equal(ctx.trace_any(A, B), S.any_hit(A, B))
     S.close()
+
+
+def test_broom_stand_in_frame_is_the_same_every_time(tr, monkeypatch):
+    """The frame must not depend on how the lanes of a wave happen to be filled (the generic shade kernel orders a window's
+    records by LDS atomics, the persistent traversal kernels interleave their lanes' steps): repeated renders, one pass in
+    flight instead of four, other round lengths of the traversal -- the same bits."""
+    from tuturenderer_amd import scenes
+
+    sc = scenes.broom_room(480, 270)
+    frames = []
+    with tr.Context(sc) as ctx:
+        for _ in range(3):
+            frames.append(ctx.render(96, 0x5EED0001, 4))
+        ctx.set_option("sets", 1)
+        frames.append(ctx.render(96, 0x5EED0001, 4))
+    for k, v in {"TUTU_WIDE_INNER_STEPS": "2", "TUTU_WIDE_INNER_STEPS_ANY": "6", "TUTU_LEAF_AGAIN": "65", "TUTU_REFILL_MIN": "1"}.items():
+        monkeypatch.setenv(k, v)
+    with tr.Context(sc) as ctx:
+        frames.append(ctx.render(96, 0x5EED0001, 4))
+    for f in frames[1:]:
+        assert bit_equal(frames[0], f)
