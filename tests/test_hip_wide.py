@@ -293,3 +293,29 @@ def test_broom_stand_in_frame_is_the_same_every_time(tr, monkeypatch):
         frames.append(ctx.render(96, 0x5EED0001, 4))
     for f in frames[1:]:
         assert bit_equal(frames[0], f)
+
+
+def test_a_range_of_nothing_but_rays_for_the_exact_walk(tr, port):
+    """A million rays that all start far outside the box the wide tree was quantised for: every one of them is set aside for
+    the reference's own tree, so a wave's refill leaves all its lanes idle while most of its range is still unfetched (round
+    3: the loop took that for the end of the range and left all but the first 64 rays of every wave untraced)."""
+    sc, _ = _scene("veach_slight")
+    v = np.asarray(sc["verts"], np.float32).reshape(-1, 3)
+    lo, hi = v.min(axis=0), v.max(axis=0)
+    rng = np.random.default_rng(3)
+    n = 1 << 20
+    u = rng.normal(size=(n, 3)).astype(np.float32)
+    u /= np.linalg.norm(u, axis=1, keepdims=True)
+    O = ((lo + hi) / 2 + 20 * (hi - lo).max() * u).astype(np.float32)
+    T = (lo + (hi - lo) * rng.uniform(size=(n, 3))).astype(np.float32)
+    D = T - O
+    D /= np.linalg.norm(D, axis=1, keepdims=True)
+    S = port.scene(sc)
+    hit, t, tri, _, _, _ = S.closest(O, D)
+    S.close()
+    assert hit.mean() > 0.5
+    with tr.Context(sc) as ctx:
+        assert ctx.options()["wide_tree"] == 1
+        h = ctx.trace_closest(O, D.astype(np.float32))
+    assert bit_equal(h["tri"], np.where(hit == 1, tri, -1).astype(np.int32))
+    assert bit_equal(h["t"][hit == 1], t[hit == 1])

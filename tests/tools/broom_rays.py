@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""broom stand-in: GPU closest / any hits against the CPU restatement on rays that start on surfaces (like path vertices)"""
+"""broom stand-in (or `veach` / `bunny` as second argument): GPU closest / any hits against the CPU restatement on rays that
+start on surfaces (like path vertices).  python tests/tools/broom_rays.py <rays> [scene]"""
 import os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
@@ -7,7 +8,8 @@ import tuturenderer_amd as tr
 from tuturenderer_amd import scenes
 from oracle import pyoracle
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1 << 18
-sc = scenes.broom_room(1600, 900)
+which = sys.argv[2] if len(sys.argv) > 2 else "broom"
+sc = {"broom": lambda: scenes.broom_room(1600, 900), "veach": lambda: scenes.veach_room(800, 600, small_light=False), "bunny": lambda: scenes.bunny_box(1024, 1024)}[which]()
 S = pyoracle.Oracle("port").scene(sc)
 rng = np.random.default_rng(11)
 O = np.empty((n, 3), np.float32)

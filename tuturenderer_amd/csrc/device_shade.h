@@ -916,8 +916,12 @@ TUTU_DEV void trace_persistent(const S& ss, const TraceParams& tp, int* stack, c
 				cur = TUTU_TRAV_DONE;
 				if (sc.root_ref != INT_MIN) {
 					if (!ray_is_plain(r) || (WIDE && !ray_fits_wide(sc, r))) {
-						exact = true;  // the reference's own tree with the reference's own slab: after the main loop
-						cur = TUTU_TRAV_IDLE;
+						// the reference's own tree with the reference's own slab: after the main loop.  The lane stays DONE for
+						// this round and goes idle in its finish step (its write there -- a miss, or nothing for a shadow ray marked
+						// blocked -- is replaced by the exact walk's): if it went idle at once, a refill that serves nothing but
+						// such rays would leave every lane idle and the loop would take that for the end of the wave's range.
+						exact = true;
+						if (ANY) blocked = true;
 					} else {
 						// LDS scenes: no test of the root box (BVH.hpp:150 for the root): a plain ray that misses it misses every box
 						// inside it (§4: the slab arithmetic is monotone in the box), so the walk ends one node later by itself --
