@@ -131,7 +131,9 @@ typedef struct TutuRenderParams {
 	int32_t n_pixels;
 	int32_t x0, y0, x1, y1;
 	int32_t spp_per_pass; /* samples per pixel traced per wavefront pass; 0 = choose from max_paths */
-	int64_t max_paths;    /* cap on paths in flight, summed over the (up to 4) work sets whose passes overlap (device memory ~ 400 B each); 0 = default 168 Mi = 67 GB, less if the device has less free */
+	int64_t max_paths;    /* cap on paths in flight, summed over the (up to 4) work sets whose passes overlap (device memory ~ 400 B each); 0 = default 168 Mi = 67 GB, less if the device has less free.
+	                       * With the default (both 0), a context's FIRST render allocates only knob "cold_paths_mi" (12 Mi slots, 4.8 GB) itself and a host thread
+	                       * allocates the rest meanwhile (tutu_hip_work_ready); a caller that names a size gets exactly that, allocated before the call renders. */
 } TutuRenderParams;
 
 typedef struct TutuStats {
@@ -224,8 +226,20 @@ int tutu_hip_destroy(TutuCtx* ctx);
 int tutu_hip_render(TutuCtx* ctx, const TutuCameraFrame* cam, const TutuRenderParams* params, float* out_rgb,
                     TutuStats* stats);
 
+/* Cold start.  The reference's scene programs render once per process (src/main_cornellBox.cpp:75-79): what the FIRST render of
+ * a context costs is what a drop-in user waits for.  Device allocations cost time in proportion to their size whenever the
+ * driver has to clear memory another process left behind (0.0 - 1.7 s for the default 67 GB of work sets), so with the default
+ * sizing the first render allocates a small set of work buffers itself (knob "cold_paths_mi"), renders with smaller passes,
+ * and a host thread owned by the context allocates the full-size sets meanwhile; the first later render that finds them ready
+ * switches over (same frame, bit for bit: only the grouping of samples into passes changes).
+ * tutu_hip_work_ready: returns 1 while that allocation is still running, 0 when the context has its full-size sets (or never
+ * needed more), negative on error; wait != 0 blocks until it is done.  A caller that renders many frames and wants the
+ * steady state from the first one sets "cold_paths_mi" to 0 before its first render (bench.py's timed context does). */
+int tutu_hip_work_ready(TutuCtx* ctx, int wait);
+
 /* Same, but out_rgb is a DEVICE pointer on ctx's device (e.g. a torch tensor's data_ptr); work is enqueued on
- * `stream` (a hipStream_t, NULL = the context's own stream) and the call returns after the work is complete. */
+ * `stream` (a hipStream_t, NULL = the context's own stream) and the call returns after the work is complete (it ends with a hipStreamSynchronize of that stream: the ray counters of TutuStats
+ * are read back then; stats == NULL skips the read-back, not the wait). */
 int tutu_hip_render_device(TutuCtx* ctx, const TutuCameraFrame* cam, const TutuRenderParams* params,
                            float* d_out_rgb, void* stream, TutuStats* stats);
 
@@ -236,6 +250,14 @@ int tutu_hip_render_device(TutuCtx* ctx, const TutuCameraFrame* cam, const TutuR
  * tutu_hip_render).  The frame is bit-identical for any n.  stats: n entries or NULL. */
 int tutu_hip_render_multi(TutuCtx* const* ctxs, int32_t n, const TutuCameraFrame* cam, const TutuRenderParams* params,
                           float* out_rgb, TutuStats* stats);
+/* Same, with the frame left in DEVICE memory of ctxs[0]'s device (d_out_rgb: n_items*3 floats there).  The gather is on the
+ * device side -- what replaces the shared frame buffer the reference's threads write into (PathTracing.hpp:393-429): every
+ * context renders its piece into its own device's memory, the pieces travel to ctxs[0]'s device by peer copies (xGMI inside a
+ * node) into one buffer in context order, and one kernel un-tiles it into d_out_rgb on `stream` (a hipStream_t of that
+ * device, NULL = ctxs[0]'s own); the call returns after that kernel.  tutu_hip_render_multi is this + one frame-sized D2H
+ * copy.  (bench.py's process-per-GPU form does the same with one grouped RCCL send / recv: tuturenderer_amd/dist.py.) */
+int tutu_hip_render_multi_device(TutuCtx* const* ctxs, int32_t n, const TutuCameraFrame* cam, const TutuRenderParams* params,
+                                 float* d_out_rgb, void* stream, TutuStats* stats);
 
 /* Kernel-level entry points for parity tests.
  * closest: BVHStrategy::UpdateInter -> getIntersection (BVHStrategy.hpp:8-11, BVH.hpp:145-167)
@@ -338,6 +360,9 @@ int tutu_hip_quantise(TutuCtx* ctx, uint32_t n, const float* values, int32_t* le
  *   list, so that each XCD's L2 serves one part of the picture) | "any_near_first" TUTU_ANY_NEAR_FIRST {0,1} | "kernel_events" TUTU_KERNEL_EVENTS {0,1} (default 0; 1 = a HIP
  *   event pair around every launch, which is what fills TutuStats' ms_* fields: ~2400 events, 2.7 % of a 512-spp Cornell frame;
  *   the ray / node counters of TutuStats do not need it) |
+ *   "exact" TUTU_EXACT {0,1} (1: EVERY ray takes the exact walk -- the reference's own tree, the reference's own slab test, no distance
+ *   pruning, BVH.hpp:145-194 visit for visit: the strict form, several times slower on big scenes; DESIGN.md section 4 says what the default
+ *   walk assumes instead) | "cold_paths_mi" TUTU_COLD_PATHS_MI [0,4096] (see tutu_hip_work_ready; 0 = allocate everything in the first render) |
  *   "util_stats" TUTU_UTIL_STATS {0,1} | "bidir_units" TUTU_BIDIR_UNITS [64, 2^24] ((pixel, sample) units per batch of
  *   tutu_hip_render_integrator; batches are whole pixels) |
  *   "wide" TUTU_WIDE [0,2] (memory-resident scenes: 0 walk the binary SAH tree, 1 the four-wide quantised tree when the binary
@@ -345,7 +370,9 @@ int tutu_hip_quantise(TutuCtx* ctx, uint32_t n, const float* values, int32_t* le
  *   "wide_inner_steps" TUTU_WIDE_INNER_STEPS [1,64] / "wide_inner_steps_any" TUTU_WIDE_INNER_STEPS_ANY [1,64] | "wide_lds_stack" TUTU_WIDE_LDS_STACK [4,64] and "lds_stack_max"
  *   TUTU_LDS_STACK_MAX [0,64]: entries of the traversal stack kept in LDS (wide / binary tree); deeper ones live in HBM.
  *   Read-only facts: "wide_tree", "wide_depth", "fast_depth", "stack_entries", "stack_entries_hbm", "trace_blocks_per_cu",
- *   "trace_lds_bytes".
+ *   "trace_lds_bytes", "work_paths_mi", "growing", "grow_ms".
+ *   The knobs tutu_hip_create consumes (tree choice, LDS carve-up: "wide", "wide_min_mb", "wide_early", "wide_early_max_mb", "lds_stack_max",
+ *   "wide_lds_stack", "trace_bpc") are refused by tutu_hip_set_option afterwards (TUTU_E_INVALID) unless the value is the one in effect.
  *   Testing aid, read at every device allocation rather than at create: TUTU_DEBUG_FILL=<0..255> fills every fresh allocation
  *   with that byte (no result may depend on what hipMalloc hands out; tests/test_hip_wide.py).
  * tutu_hip_get_option reports the effective value of any of them, plus the read-only facts "sah_tree", "lds_scene"

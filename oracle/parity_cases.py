@@ -329,3 +329,64 @@ def run_postprocess(O):
     for stage, name in ((0, "full"), (1, "emissive"), (2, "blur"), (3, "hdr")):
         out[name] = O.postprocess(stage, img)
     return out
+
+
+# ------------------------------------------------------------------------------------------------ adversarial geometry
+def needle_scene(n=2000, length=1000.0, width=1.0, seed=5, box=1000.0):
+    """2 n needle-shaped triangles (n quads of length : width = 1000 : 1, random orientation) -- the geometry on which the
+    reference's fp32 triangle test (Triangle.hpp:23-59) is ill-conditioned: half the triangles have an angle of ~1e-3 rad at
+    v0.  Returned as a scene dict on the Cornell camera (only the ray-batch entry points are used on it)."""
+    from tuturenderer_amd import scenes
+
+    r = np.random.default_rng(seed)
+    c = r.uniform(0.2 * box, 0.8 * box, (n, 3))
+    ax = r.normal(size=(n, 3))
+    ax /= np.linalg.norm(ax, axis=1, keepdims=True)
+    sd = np.cross(ax, r.normal(size=(n, 3)))
+    sd /= np.linalg.norm(sd, axis=1, keepdims=True)
+    p0 = c - ax * length / 2 - sd * width / 2
+    p1 = c - ax * length / 2 + sd * width / 2
+    p2 = c + ax * length / 2 + sd * width / 2
+    p3 = c + ax * length / 2 - sd * width / 2
+    verts = np.concatenate([np.concatenate([p0, p2, p1], 1), np.concatenate([p0, p3, p2], 1)]).astype(np.float32)
+    sc = scenes.cornell_box(64, 64)
+    return dict(sc, verts=verts, normals=scenes.face_normals(verts), mat_id=np.zeros(len(verts), np.int32))
+
+
+def grazing_rays(sc, n, seed=9, cmin=1e-4, cmax=1e-1):
+    """n rays aimed at random points of random triangles of `sc`, |cos(ray, triangle normal)| log-uniform in [cmin, cmax]
+    (the reference rejects below 1e-4, Triangle.hpp:36), from 5..900 units away"""
+    r = np.random.default_rng(seed)
+    V = np.asarray(sc["verts"], np.float64).reshape(-1, 3, 3)
+    k = r.integers(0, len(V), n)
+    w = r.dirichlet([1, 1, 1], n)
+    p = (V[k] * w[:, :, None]).sum(1)
+    nrm = np.cross(V[k, 1] - V[k, 0], V[k, 2] - V[k, 0])
+    nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+    e = np.cross(nrm, r.normal(size=(n, 3)))
+    e /= np.linalg.norm(e, axis=1, keepdims=True)
+    c = np.exp(r.uniform(np.log(cmin), np.log(cmax), n)) * np.sign(r.uniform(-1, 1, n))
+    d = e + c[:, None] * nrm
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    s = r.uniform(5, 900, n)
+    return (p - d * s[:, None]).astype(np.float32), d.astype(np.float32)
+
+
+def hit_conditioning(sc, O, D, tri, t):
+    """float64 facts about reported hits (rows with tri >= 0): rel = (true crossing distance - reported fp32 t) / t (> 0: the fp32
+    hit lies in FRONT of where the ray crosses the triangle's plane), kappa = |E1| |E2| |d| / |d . (E1 x E2)| =
+    1 / (sin(angle at v0) |cos(ray, normal)|), the amplification of the triangle test's rounding errors,
+    and inside = the true crossing point lies in the triangle (barycentrics >= 0 in float64)."""
+    V = np.asarray(sc["verts"], np.float64).reshape(-1, 3, 3)
+    o, d, tf = O.astype(np.float64), D.astype(np.float64), t.astype(np.float64)
+    v0, e1, e2 = V[tri, 0], V[tri, 1] - V[tri, 0], V[tri, 2] - V[tri, 0]
+    n = np.cross(e1, e2)
+    det = (d * n).sum(1)
+    tt = ((v0 - o) * n).sum(1) / det
+    kappa = np.linalg.norm(e1, axis=1) * np.linalg.norm(e2, axis=1) * np.linalg.norm(d, axis=1) / np.abs(det)
+    x = o + tt[:, None] * d - v0
+    nn = (n * n).sum(1)
+    b1 = (np.cross(x, e2) * n).sum(1) / nn
+    b2 = (np.cross(e1, x) * n).sum(1) / nn
+    inside = (b1 >= 0) & (b2 >= 0) & (1 - b1 - b2 >= 0)
+    return (tt - tf) / np.maximum(np.abs(tf), 1e-30), kappa, inside

@@ -16,6 +16,9 @@ LIBS = {
     "reference": os.path.join(HERE, "_ref", "libtutu_ref.so"),
     # the same harness built -O3 for TIMING only (bench.py cpu_baseline); never used as a checker
     "reference_fast": os.path.join(HERE, "_ref", "libtutu_ref_fast.so"),
+    # the same harness WITHOUT the RNG engine swap of ref_shim.h: the reference's own thread_local std::mt19937
+    # (global.hpp:182-199) draws.  Only oracle/gen_frames.py uses it, for the statistical pin (SURVEY.md 8d parity (ii))
+    "reference_native": os.path.join(HERE, "_ref", "libtutu_ref_native.so"),
 }
 
 MAT_DTYPE = np.dtype(

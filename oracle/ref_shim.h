@@ -45,5 +45,10 @@ struct tutu_ref_random_device {
 	unsigned operator()() { return 1u; }
 };
 }
+// -DTUTU_REF_NATIVE_RNG (oracle/Makefile: _ref/libtutu_ref_native.so) leaves the reference's own engine in place: its
+// thread_local std::mt19937 seeded from std::random_device draws, nothing is injected -- the statistical pin of
+// tests/golden/frame_native_cornell.npz (SURVEY.md 8d parity (ii)).
+#ifndef TUTU_REF_NATIVE_RNG
 #define mt19937 tutu_ref_engine
 #define random_device tutu_ref_random_device
+#endif

@@ -177,6 +177,17 @@ def test_multi_context_render_is_the_single_context_frame(built):
         b = tr.Context.render_multi(ctxs, 5, 1, 2, pixels=pixels)
         assert a.tobytes() == b.tobytes()
         assert all(c.last_stats["samples"] > 0 for c in ctxs)
+        # the device-side gather by itself (tutu_hip_render_multi_device): the frame stays in device memory -- a torch tensor
+        # here --, pieces gathered by peer copies in context order, ONE un-tiling kernel, on a stream of the caller's
+        import torch
+
+        d = torch.full((200 * 136, 3), -1.0, dtype=torch.float32, device="cuda:0")
+        s = torch.cuda.Stream()
+        n = tr.Context.render_multi_device(ctxs, d.data_ptr(), 12, 0x5EED0001, 3, stream=s.cuda_stream)
+        assert n == 200 * 136 and d.cpu().numpy().tobytes() == one.tobytes()
+        d5 = torch.zeros((5000, 3), dtype=torch.float32, device="cuda:0")
+        tr.Context.render_multi_device(ctxs, d5.data_ptr(), 5, 1, 2, pixels=pixels)
+        assert d5.cpu().numpy().tobytes() == a.tobytes()
     finally:
         for c in ctxs:
             c.close()

@@ -698,3 +698,65 @@ def test_two_ranks_on_one_gpu_gather_the_single_process_frame(tr, tmp_path):
     with tr.Context(scenes.cornell_box(800, 800)) as ctx:
         one = ctx.render(6, pc.KEY0, 1)
     assert bit_equal(two, one)
+
+
+def test_rccl_process_group_self_loop_gathers_the_plain_frame(tr, tmp_path):
+    """The `nccl` (= RCCL) leg of the N > 1 path, executed on the hardware there is: ONE rank under torch.distributed.run, the
+    process group really initialised with backend nccl, and every frame's piece sent through ONE grouped self send / recv
+    (FrameGather(self_loop=True): the same dist.batch_isend_irecv call as with N ranks) before the un-tiling kernel -- bit-equal
+    to the plain call.  (What this cannot show: more than one device, xGMI.  PathTracing.hpp:393-429 is what the gather replaces.)"""
+    import os
+    import subprocess
+    import sys
+
+    from conftest import ROOT
+    from tuturenderer_amd import scenes
+
+    out = str(tmp_path / "frame_loop.npy")
+    port_no = 29900 + (hash(out) % 90)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", str(port_no), "bench.py", "--gpus", "1", "--self-loop", "--backend", "nccl", "--config", "c1", "--spp", "6",
+           "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-extras", "--dump", out]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:]
+    looped = np.load(out)
+    with tr.Context(scenes.cornell_box(800, 800)) as ctx:
+        one = ctx.render(6, pc.KEY0, 1)
+    assert bit_equal(looped, one)
+
+
+def test_cold_start_first_render_is_not_an_allocation(tr):
+    """The reference's scene programs render once per process (src/main_cornellBox.cpp:75-79): create + FIRST render is what a
+    drop-in user waits for.  Round 3 allocated 67 GB of work sets before tracing the 32-triangle box (first render 1.84 s for
+    a 0.12 s frame).  Now the first default-sized render allocates `cold_paths_mi` Mi path slots itself, a host thread brings
+    the full-size sets, and a later render adopts them: create + first render stay within 1 s (north_star's 50 x the
+    reference CPU = 1.0 s for this frame) and within 2 x a steady-state render + 0.1 s; every render returns the same bits."""
+    import time
+
+    from tuturenderer_amd import scenes
+
+    sc = scenes.cornell_box(800, 800)
+    t0 = time.perf_counter()
+    ctx = tr.Context(sc)
+    try:
+        first = ctx.render(512, pc.KEY0, 2, full_frame=False)
+        t_cold = time.perf_counter() - t0
+        cold_paths = ctx.get_option("work_paths_mi")
+        t0 = time.perf_counter()
+        second = ctx.render(512, pc.KEY0, 2, full_frame=False)
+        t_second = time.perf_counter() - t0
+        ctx.work_ready(wait=True)
+        t0 = time.perf_counter()
+        third = ctx.render(512, pc.KEY0, 2, full_frame=False)
+        t_steady = time.perf_counter() - t0
+        steady_paths = ctx.get_option("work_paths_mi")
+        grow_ms = ctx.get_option("grow_ms")
+    finally:
+        ctx.close()
+    print(f"\n[cold start] create + first render {t_cold:.3f} s on {cold_paths} Mi path slots; second {t_second:.3f} s; steady {t_steady:.3f} s on "
+          f"{steady_paths} Mi (background allocation {grow_ms} ms)")
+    assert bit_equal(first, second) and bit_equal(first, third)
+    assert cold_paths <= 16 and steady_paths >= 96
+    assert t_cold < 1.0, t_cold
+    assert t_cold < 2 * t_steady + 0.1, (t_cold, t_steady)

@@ -319,3 +319,110 @@ def test_a_range_of_nothing_but_rays_for_the_exact_walk(tr, port):
         h = ctx.trace_closest(O, D.astype(np.float32))
     assert bit_equal(h["tri"], np.where(hit == 1, tri, -1).astype(np.int32))
     assert bit_equal(h["t"][hit == 1], t[hit == 1])
+
+
+# ---- what distance pruning assumes, tested on geometry built to break it -------------------------------
+_NEEDLES = {}
+
+
+def _needle_sets(port=None):
+    """the scene, the two ray sets and (cached: four tests use them) the unpruned recursion's answers"""
+    if not _NEEDLES:
+        sc = pc.needle_scene()
+        _NEEDLES["sc"] = sc
+        _NEEDLES["sets"] = {"grazing": pc.grazing_rays(sc, 400_000), "oblique": pc.grazing_rays(sc, 200_000, cmin=1e-2, cmax=1.0)}
+        _NEEDLES["want"] = {}
+    if port is not None and not _NEEDLES["want"]:
+        S = port.scene(_NEEDLES["sc"])
+        for name, (O, D) in _NEEDLES["sets"].items():
+            _NEEDLES["want"][name] = S.closest(O, D)
+        S.close()
+    return _NEEDLES["sc"], _NEEDLES["sets"], _NEEDLES["want"]
+
+
+def test_needles_exact_walk_is_the_reference_recursion(tr, port, monkeypatch):
+    """4000 triangles of aspect 1000 : 1 and 600 k rays that graze them (|cos| down to the reference's own cut-off of 1e-4): the
+    reference's fp32 `t` lies up to 34 t in FRONT of the true crossing there, 2 253 times even in front of the triangle's own
+    box (tests/tools/needle_study.py).  TUTU_EXACT=1 -- the reference's tree, the reference's slab, no pruning -- returns the
+    object and the bits of t of the CPU restatement's unpruned recursion for every one of them, shadow answers included."""
+    sc, sets, wants = _needle_sets(port)
+    S = port.scene(sc)
+    monkeypatch.setenv("TUTU_EXACT", "1")
+    with tr.Context(sc) as ctx:
+        assert ctx.get_option("exact") == 1
+        for name, (O, D) in sets.items():
+            hit, t, tri, pos, _, _ = wants[name]
+            h = ctx.trace_closest(O, D)
+            assert bit_equal(h["tri"], np.where(hit == 1, tri, -1).astype(np.int32)), name
+            assert bit_equal(h["t"][hit == 1], t[hit == 1]), name
+            m = hit == 1
+            A, B = O[m][:100_000], (pos[m][::-1].copy())[:100_000]  # shadow segments from the origins to other rays' hit points
+            assert bit_equal(np.asarray(ctx.trace_any(A, B)).astype(np.uint8), S.any_hit(A, B)), name
+    S.close()
+
+
+@pytest.mark.parametrize("form", ["default", "whole_triangle_boxes", "reference_tree_pruned"])
+def test_needles_pruned_walks_differ_only_where_the_hypothesis_fails(tr, port, monkeypatch, form):
+    """The same rays through the DEFAULT walk (SAH tree over clipped references, pruning at 1 + 2^-8), through whole-triangle
+    boxes (TUTU_SPLIT_MAX=1) and through the reference's own tree with pruning (TUTU_NO_SAH=1).  DESIGN.md section 4 states when a pruned
+    walk returns the reference's answer: whenever the reference's winning hit (object O*, fp32 t*) has its TRUE crossing inside
+    the triangle and no farther than t* (1 + 2^-8) -- then a reference of O* is entered before the limit t* (1 + 2^-8) and O* is
+    tested.  Here: every ray on which a pruned walk differs from the unpruned recursion violates that hypothesis (checked in
+    float64), rays that satisfy it never differ, and a pruned walk never reports a hit the reference does not have.  Counts are
+    printed: they are what the wider slack of round 3 could not bound."""
+    env = {"default": {}, "whole_triangle_boxes": {"TUTU_SPLIT_MAX": "1"}, "reference_tree_pruned": {"TUTU_NO_SAH": "1"}}[form]
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    sc, sets, wants = _needle_sets(port)
+    slack = 1.0 + 2.0 ** -8
+    with tr.Context(sc) as ctx:
+        if form == "default":
+            assert ctx.get_option("n_refs") > len(sc["mat_id"])  # the walked tree holds clipped references
+        for name, (O, D) in sets.items():
+            hit, t, tri, *_ = wants[name]
+            want = np.where(hit == 1, tri, -1).astype(np.int32)
+            h = ctx.trace_closest(O, D)
+            m = want >= 0
+            rel, kappa, inside = pc.hit_conditioning(sc, O[m], D[m], want[m], t[m])
+            ok_hyp = inside & (rel <= (slack - 1.0) * 0.999)          # the hypothesis holds for the reference's winner
+            same = (h["tri"][m] == want[m]) & (h["t"][m].view(np.uint32) == t[m].view(np.uint32))
+            n_diff = int((~same).sum())
+            print(f"\n[needles, {form}, {name}] rays {len(O)}, hits {int(m.sum())}, hypothesis violated {int((~ok_hyp).sum())}, differ from the reference {n_diff}"
+                  f" (median kappa of those {np.median(kappa[~same]) if n_diff else 0:.2e}; of all hits {np.median(kappa):.2e})")
+            assert not (ok_hyp & ~same).any(), "a ray that satisfies the hypothesis differs from the reference"
+            # what a pruned walk reports instead is another hit the reference also accepts: a real one, not nearer than the winner
+            got = h["tri"][m]
+            lost = ~same & (got >= 0)
+            assert (h["t"][m][lost] >= t[m][lost]).all()
+            assert (h["tri"][~m] == -1).all()  # and never a hit where the reference has none
+
+
+def test_far_origin_ray_batch_on_the_broom_stand_in(tr, port):
+    """Rays whose origins lie outside the region the wide tree was quantised for are set aside for the exact walk; that walk uses
+    the REFERENCE's tree (which fits the LDS tier of the stack by construction), never the SAH tree, whose depth on this scene
+    (27) exceeds the tier (19) -- round 3's deferred walk picked the tree by `ray_is_plain` alone and could overrun LDS here."""
+    from tuturenderer_amd import scenes
+
+    sc = scenes.broom_room(1600, 900)
+    v = np.asarray(sc["verts"], np.float32).reshape(-1, 3)
+    lo, hi = v.min(axis=0), v.max(axis=0)
+    rng = np.random.default_rng(31)
+    n = 1 << 16
+    u = rng.normal(size=(n, 3)).astype(np.float32)
+    u /= np.linalg.norm(u, axis=1, keepdims=True)
+    O = ((lo + hi) / 2 + 20 * (hi - lo).max() * u).astype(np.float32)
+    T = (lo + (hi - lo) * rng.uniform(size=(n, 3))).astype(np.float32)
+    D = T - O
+    D /= np.linalg.norm(D, axis=1, keepdims=True)
+    O[::2] = (lo + (hi - lo) * rng.uniform(size=(n // 2, 3))).astype(np.float32)  # every other ray starts inside: both kinds in every wave
+    S = port.scene(sc)
+    hit, t, tri, pos, _, _ = S.closest(O, D.astype(np.float32))
+    with tr.Context(sc) as ctx:
+        opt = ctx.options()
+        assert opt["wide_tree"] == 1 and opt["fast_depth"] > opt["stack_entries"]
+        h = ctx.trace_closest(O, D.astype(np.float32))
+        assert bit_equal(h["tri"], np.where(hit == 1, tri, -1).astype(np.int32))
+        assert bit_equal(h["t"][hit == 1], t[hit == 1])
+        m = hit == 1
+        assert bit_equal(np.asarray(ctx.trace_any(O[m], pos[m][::-1].copy())).astype(np.uint8), S.any_hit(O[m], pos[m][::-1].copy()))
+    S.close()

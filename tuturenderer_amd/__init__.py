@@ -20,7 +20,7 @@ ABI_SYMBOLS = [
     "tutu_hip_device_count", "tutu_hip_create", "tutu_hip_destroy", "tutu_hip_render", "tutu_hip_render_device", "tutu_hip_render_multi",
     "tutu_hip_trace_closest", "tutu_hip_trace_any", "tutu_hip_trace_samples", "tutu_hip_eval_bxdf", "tutu_hip_eval_pdf",
     "tutu_hip_eval_sample", "tutu_hip_eval_sample_light", "tutu_hip_eval_fn", "tutu_hip_scene_info", "tutu_hip_eval_texture", "tutu_hip_set_option", "tutu_hip_get_option", "tutu_hip_postprocess", "tutu_hip_quantise",
-    "tutu_camera_raster", "tutu_hip_render_integrator", "tutu_hip_integrator_samples",
+    "tutu_camera_raster", "tutu_hip_render_integrator", "tutu_hip_integrator_samples", "tutu_hip_work_ready", "tutu_hip_render_multi_device",
 ]
 
 
@@ -302,7 +302,14 @@ class Context:
 
     OPTION_NAMES = ("sets", "sets_default", "one_set", "shade_bpc", "trace_bpc", "refill_min", "inner_steps", "inner_steps_any", "leaf_again", "trace_xcd", "kernel_events", "any_near_first",
                     "util_stats", "bidir_units", "sah_tree", "n_refs", "lds_scene", "shade_tab", "fast_depth", "stack_entries", "stack_entries_hbm", "lds_stack_max", "wide", "wide_min_mb", "wide_inner_steps", "wide_inner_steps_any", "wide_tree", "wide_depth", "wide_early", "pair_leaves",
-                    "trace_blocks_per_cu", "trace_lds_bytes")
+                    "trace_blocks_per_cu", "trace_lds_bytes", "wide_lds_stack", "wide_early_max_mb", "exact", "cold_paths_mi", "work_paths_mi")
+
+    def work_ready(self, wait=False):
+        """tutu_hip_work_ready: False while a background thread still allocates this context's full-size work sets (cold start)"""
+        rc = self.lib.tutu_hip_work_ready(self.h, C.c_int(1 if wait else 0))
+        if rc < 0:
+            _check(rc, "tutu_hip_work_ready")
+        return rc == 0
 
     def get_option(self, name):
         v = C.c_int(0)
@@ -371,6 +378,20 @@ class Context:
         for c, s_ in zip(ctxs, st):
             c.last_stats = s_.as_dict()
         return out
+
+    @staticmethod
+    def render_multi_device(ctxs, d_out_ptr, spp, key0, key1, pixels=None, rect=None, spp_per_pass=0, max_paths=0, stream=None):
+        """tutu_hip_render_multi_device: the frame (compact (n,3) rows in work-item order) is left in device memory of ctxs[0]'s
+        device at d_out_ptr; the pieces are gathered there by peer copies and one un-tiling kernel"""
+        c0 = ctxs[0]
+        rp, n, keep, rect = c0._params(spp, key0, key1, pixels, rect, spp_per_pass, max_paths)
+        arr = (C.c_void_p * len(ctxs))(*[c.h for c in ctxs])
+        st = (Stats * len(ctxs))()
+        _check(c0.lib.tutu_hip_render_multi_device(arr, C.c_int32(len(ctxs)), C.byref(c0.cam), C.byref(rp), C.c_void_p(int(d_out_ptr)),
+                                                   C.c_void_p(int(stream)) if stream else None, st), "tutu_hip_render_multi_device")
+        for c, s_ in zip(ctxs, st):
+            c.last_stats = s_.as_dict()
+        return n
 
     def render_device(self, d_out_ptr, spp, key0, key1, pixels=None, rect=None, spp_per_pass=0, max_paths=0, stream=None):
         """Same, writing the compact (n,3) result to device memory at d_out_ptr (e.g. torch_tensor.data_ptr())."""

@@ -915,7 +915,7 @@ TUTU_DEV void trace_persistent(const S& ss, const TraceParams& tp, int* stack, c
 				pend = TUTU_TRAV_IDLE;
 				cur = TUTU_TRAV_DONE;
 				if (sc.root_ref != INT_MIN) {
-					if (!ray_is_plain(r) || (WIDE && !ray_fits_wide(sc, r))) {
+					if (sc.exact || !ray_is_plain(r) || (WIDE && !ray_fits_wide(sc, r))) {
 						// the reference's own tree with the reference's own slab: after the main loop.  The lane stays DONE for
 						// this round and goes idle in its finish step (its write there -- a miss, or nothing for a shadow ray marked
 						// blocked -- is replaced by the exact walk's): if it went idle at once, a refill that serves nothing but
@@ -1149,6 +1149,8 @@ TUTU_DEV void trace_persistent(const S& ss, const TraceParams& tp, int* stack, c
 	if (n_def != 0u) {
 		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // the list positions were written by other lanes of this wave
 		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+		// force_exact: these rays walk the REFERENCE's tree whatever they are (a plain ray with an origin outside the wide
+		// tree's region would otherwise pick the SAH tree, which is fast_depth deep and need not fit the LDS tier), unpruned.
 		int* xstack = stack;  // (the reference's tree always fits the LDS tier: host, tutu_hip_create)
 		for (uint32_t j = (uint32_t)lane; j < n_def; j += 64u) {
 			const uint32_t i = tp.defer[begin + j];
@@ -1157,14 +1159,14 @@ TUTU_DEV void trace_persistent(const S& ss, const TraceParams& tp, int* stack, c
 				const float4 A = tp.rec.A[s], B = tp.rec.B[s];
 				float t, u, v;
 				int tri;
-				trace_closest(ss, sc, mk(A.x, A.y, A.z), mk(B.x, B.y, B.z), xstack, 256, t, u, v, tri);
+				trace_closest(ss, sc, mk(A.x, A.y, A.z), mk(B.x, B.y, B.z), xstack, 256, t, u, v, tri, true);
 				tp.hitC[i] = make_float4(t, u, v, __int_as_float(tri));
 				tp.hitK[i] = tri >= 0 ? tri_class[tri] : (uint8_t)TUTU_CLASS_MISS;
 			} else {
 				const uint32_t f = tp.rec.key[s];
 				const float4 e0 = (f & TUTU_KEY_ALT) ? tp.rec.S2[s] : tp.rec.A[s];
 				const float4 e1 = tp.rec.S[s];
-				const bool blk = trace_any(ss, sc, mk(e0.x, e0.y, e0.z), mk(e1.x, e1.y, e1.z), xstack, 256);
+				const bool blk = trace_any(ss, sc, mk(e0.x, e0.y, e0.z), mk(e1.x, e1.y, e1.z), xstack, 256, true);
 				if (f & TUTU_KEY_FINAL) {
 					const float4 Lp = tp.rec.L[s], e2 = tp.rec.P[s];
 					float4 F = make_float4(Lp.x, Lp.y, Lp.z, 0.f);

@@ -74,6 +74,9 @@ struct SceneDev {
 	const float4* wnodes;      // 4 x float4 per node; node 0 = root
 	int has_wide;
 	float wide_lo[3], wide_hi[3];  // ray origins the quantisation margin was sized for
+	// knob "exact" (TUTU_EXACT): EVERY ray takes the exact walk -- the reference's own tree, the reference's own slab, no
+	// distance pruning: BVH.hpp:145-194 as written, visit for visit.  The strict form of the library.
+	int exact;
 };
 
 struct SceneGlobal {
@@ -304,9 +307,13 @@ TUTU_DEV ChildTest test_children(const S& sc, int node, const RayPre& r, float l
 }
 
 // getIntersection, BVH.hpp:145-167.  stack = this lane's column of the LDS stack, `stride` ints between entries.
+// force_exact (or the scene's `exact` knob): the reference's own tree, no candidate validation (that tree's boxes ARE the
+// reference's), no distance pruning -- every object whose chain of boxes the ray hits is tested, the smallest t wins, ties
+// go to the leftmost leaf: the reference's recursion by construction, for any ray (zero / non-finite components included).
+// The stack then holds at most ref_depth entries, which the host keeps inside the LDS tier (tutu_hip_create).
 template <typename S>
 TUTU_DEV void trace_closest(const S& ss, const SceneDev& sc, V3 o, V3 d, int* stack, int stride, float& best_t, float& best_u,
-                            float& best_v, int& best_tri) {
+                            float& best_v, int& best_tri, bool force_exact = false) {
 	best_t = FLT_MAX;
 	best_u = 0.f;
 	best_v = 0.f;
@@ -315,12 +322,13 @@ TUTU_DEV void trace_closest(const S& ss, const SceneDev& sc, V3 o, V3 d, int* st
 	const RayPre r = make_ray(o, d);
 	float te;
 	if (!slab(r, sc.root_min[0], sc.root_min[1], sc.root_min[2], sc.root_max[0], sc.root_max[1], sc.root_max[2], te)) return;
-	const bool validate = sc.has_fast && ray_is_plain(r);
+	const bool exact = force_exact || sc.exact != 0;
+	const bool validate = !exact && sc.has_fast && ray_is_plain(r);
 	int cur = validate ? sc.root_ref : sc.root_ref_exact;
 	int sp = 0;
 	for (;;) {
 		while (cur >= 0) {
-			const float lim = best_tri >= 0 ? best_t * TUTU_PRUNE_SLACK_CLOSEST : FLT_MAX;
+			const float lim = (best_tri >= 0 && !exact) ? best_t * TUTU_PRUNE_SLACK_CLOSEST : FLT_MAX;
 			const ChildTest ct = test_children(ss, cur, r, lim);
 			if (ct.hl && ct.hr) {
 				const bool right_first = ct.tr < ct.tl;
@@ -367,15 +375,16 @@ TUTU_DEV void trace_closest(const S& ss, const SceneDev& sc, V3 o, V3 d, int* st
 
 // isShadowRayBlocked -> hasIntersection, IIntegrator.hpp:135-153 + BVH.hpp:170-194
 template <typename S>
-TUTU_DEV bool trace_any(const S& ss, const SceneDev& sc, V3 orig, V3 lightPos, int* stack, int stride) {
+TUTU_DEV bool trace_any(const S& ss, const SceneDev& sc, V3 orig, V3 lightPos, int* stack, int stride, bool force_exact = false) {
 	if (sc.root_ref == INT_MIN) return false;
 	const V3 raydir = normalized(lightPos - orig);
 	const float dis = norm(lightPos - orig);
 	const RayPre r = make_ray(orig, raydir);
 	float te;
 	if (!slab(r, sc.root_min[0], sc.root_min[1], sc.root_min[2], sc.root_max[0], sc.root_max[1], sc.root_max[2], te)) return false;
-	const float lim = dis * TUTU_PRUNE_SLACK;
-	const bool validate = sc.has_fast && ray_is_plain(r);
+	const bool exact = force_exact || sc.exact != 0;
+	const float lim = exact ? FLT_MAX : dis * TUTU_PRUNE_SLACK;
+	const bool validate = !exact && sc.has_fast && ray_is_plain(r);
 	int cur = validate ? sc.root_ref : sc.root_ref_exact;
 	int sp = 0;
 	bool blocked = false;

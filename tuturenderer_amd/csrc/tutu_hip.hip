@@ -5,11 +5,13 @@
 #include <hipcub/hipcub.hpp>
 
 #include <algorithm>
+#include <atomic>
 #include <climits>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <chrono>
 #include <thread>
 #include <vector>
 
@@ -84,6 +86,7 @@ struct TutuCtx {
 	int device = 0;
 	hipStream_t stream = nullptr;
 	int n_cu = 256;
+	size_t max_lds_per_block = 64 * 1024;  // hipDeviceProp_t::sharedMemPerBlock
 	// traversal kernels: dynamic LDS = per-lane stacks (+ a copy of the BVH when it fits)
 	int stack_entries = TUTU_STACK_DEPTH;   // full-depth stack of the one-ray-per-lane walkers (k_primary, bidirectional kernels)
 	unsigned trace_lds_bytes = TUTU_STACK_DEPTH * 256 * sizeof(int);
@@ -128,6 +131,9 @@ struct TutuCtx {
 		int kernel_events = 0;    // TUTU_KERNEL_EVENTS  a HIP event pair around every launch (per-kernel times in TutuStats; 2.7 % of a frame)  {0, 1}
 		int any_near_first = 1;   // TUTU_ANY_NEAR_FIRST any-hit: nearer child first              {0, 1}
 		int util_stats = 0;       // TUTU_UTIL_STATS     phase counters of the traversal kernels  {0, 1}
+		int exact = 0;            // TUTU_EXACT          every ray takes the exact walk: reference tree, reference slab, no pruning  {0, 1}
+		int cold_paths_mi = 12;   // TUTU_COLD_PATHS_MI  Mi path slots (all work sets together) a context's FIRST default-sized render allocates itself;
+		                          //                     the rest of the default 168 Mi arrives from a background thread (0 = allocate everything at once)  [0, 4096]
 		int bidir_units = 1 << 23;  // TUTU_BIDIR_UNITS  LightTracing / NaivePT / BDPT: (pixel, sample) units per batch  [64, 2^24]  (2 -> 8 Mi: LightTracing +8 %, NaivePT +20 %, BDPT flat; 3.8 GB of BDPT lists)
 	} knobs;
 	int shade_mode_all = SHADE_ANY;  // the kernel of that launch: the scene's only scattering class, or SHADE_ANY
@@ -150,6 +156,30 @@ struct TutuCtx {
 		DevBuf<unsigned long long> part;  // [2 kinds][TUTU_PART_BLOCKS][2] traversal work counters
 		hipEvent_t ev_resolved = nullptr;
 	} ws[TUTU_MAX_SETS];
+	// Work sets on their way (cold start, render_impl): a context's first default-sized render allocates only
+	// knobs.cold_paths_mi path slots itself -- a device allocation costs time in proportion to its size whenever the driver has
+	// to hand out memory another process left dirty (measured: 0.0 to 1.7 s for the default 67 GB on one box type) -- and a
+	// host thread allocates the full-size sets meanwhile; the first render that finds them ready adopts them.
+	struct Grow {
+		std::thread th;
+		std::atomic<int> state{0};  // 0 none, 1 the thread is allocating, 2 ready to be adopted, 3 failed (the context stays on its small sets)
+		size_t cap = 0;             // slots per set
+		int n_sets = 0;
+		size_t gstack_entries = 0;
+		WorkSet ws[TUTU_MAX_SETS];
+		double seconds = 0.0;       // how long the allocation took (get_option "grow_ms")
+		// Pacing.  A device allocation that has to wait for memory another context just released (the driver clears it first:
+		// 17-27 GB/s measured, profiles/allocbench) STALLS the kernels that run meanwhile -- 16 x fewer launches per second while a
+		// second thread allocates (allocbench part 3), a 0.12 s frame took 2.6 s next to a 2.5 s allocation.  So the thread times
+		// every buffer it allocates; once one was slow it allocates only while the context is idle (no render in flight, none
+		// for the last 30 ms): a caller that renders back to back keeps its small sets until it asks (tutu_hip_work_ready).
+		std::atomic<int> slow{0};
+		std::atomic<int> stop{0};   // tutu_hip_destroy: give up
+		std::atomic<int> hurry{0};  // tutu_hip_work_ready(wait): the caller waits for it, no pacing
+	} grow;
+	std::atomic<int> rendering{0};        // a render of this context is in flight (render_impl)
+	std::atomic<long long> idle_since_us{0};  // steady-clock time the last one ended
+	WorkSet retired[TUTU_MAX_SETS];       // the small cold-start sets after the switch: kept until destroy (a hipFree waits for the device)
 	hipStream_t extra_streams[TUTU_MAX_SETS - 1] = {};  // work set k > 0 runs on extra_streams[k - 1]
 	hipEvent_t ev_fork = nullptr;
 	DevBuf<float4> prim_dir, prim_hit, accum;
@@ -157,6 +187,8 @@ struct TutuCtx {
 	DevBuf<int32_t> pixels;
 	DevBuf<uint32_t> u32a, u32b;
 	DevBuf<float> out_stage;
+	DevBuf<float> gathered, frame_stage;  // tutu_hip_render_multi(_device), on the first context: the pieces in context order; the un-tiled frame
+	DevBuf<int32_t> gather_index;         // ... row of `gathered` -> work item
 	// the other integrators (device_bidir.h): per-unit results, frame-buffer events and their sorted order
 	struct Bidir {
 		DevBuf<float4> own, own_list, ev_val;
@@ -178,29 +210,32 @@ struct KnobDesc {
 	const char* env;   // environment variable read at create time
 	int TutuCtx::Knobs::*field;
 	int lo, hi;
+	bool create_only = false;  // consumed by tutu_hip_create (tree choice, LDS carve-up): tutu_hip_set_option refuses it afterwards
 };
 const KnobDesc kKnobs[] = {
     {"sets_default", "TUTU_SETS", &TutuCtx::Knobs::sets, 1, TUTU_MAX_SETS},
     {"one_set", "TUTU_ONE_SET", &TutuCtx::Knobs::one_set, 0, 1},
     {"shade_bpc", "TUTU_SHADE_BPC", &TutuCtx::Knobs::shade_bpc, 0, 16},
-    {"trace_bpc", "TUTU_TRACE_BPC", &TutuCtx::Knobs::trace_bpc, 0, 8},
+    {"trace_bpc", "TUTU_TRACE_BPC", &TutuCtx::Knobs::trace_bpc, 0, 8, true},
     {"refill_min", "TUTU_REFILL_MIN", &TutuCtx::Knobs::refill_min, 1, 64},
     {"inner_steps", "TUTU_INNER_STEPS", &TutuCtx::Knobs::inner_steps, 1, 64},
     {"inner_steps_any", "TUTU_INNER_STEPS_ANY", &TutuCtx::Knobs::inner_steps_any, 1, 64},
-    {"lds_stack_max", "TUTU_LDS_STACK_MAX", &TutuCtx::Knobs::lds_stack_max, 0, 64},
-    {"wide_lds_stack", "TUTU_WIDE_LDS_STACK", &TutuCtx::Knobs::wide_lds_stack, 4, 64},
-    {"wide", "TUTU_WIDE", &TutuCtx::Knobs::wide, 0, 2},
-    {"wide_min_mb", "TUTU_WIDE_MIN_MB", &TutuCtx::Knobs::wide_min_mb, 0, 65536},
+    {"lds_stack_max", "TUTU_LDS_STACK_MAX", &TutuCtx::Knobs::lds_stack_max, 0, 64, true},
+    {"wide_lds_stack", "TUTU_WIDE_LDS_STACK", &TutuCtx::Knobs::wide_lds_stack, 4, 64, true},
+    {"wide", "TUTU_WIDE", &TutuCtx::Knobs::wide, 0, 2, true},
+    {"wide_min_mb", "TUTU_WIDE_MIN_MB", &TutuCtx::Knobs::wide_min_mb, 0, 65536, true},
     {"wide_inner_steps", "TUTU_WIDE_INNER_STEPS", &TutuCtx::Knobs::wide_inner_steps, 1, 64},
     {"wide_inner_steps_any", "TUTU_WIDE_INNER_STEPS_ANY", &TutuCtx::Knobs::wide_inner_steps_any, 1, 64},
-    {"wide_early", "TUTU_WIDE_EARLY", &TutuCtx::Knobs::wide_early, 0, 2},
-    {"wide_early_max_mb", "TUTU_WIDE_EARLY_MAX_MB", &TutuCtx::Knobs::wide_early_max_mb, 0, 65536},
+    {"wide_early", "TUTU_WIDE_EARLY", &TutuCtx::Knobs::wide_early, 0, 2, true},
+    {"wide_early_max_mb", "TUTU_WIDE_EARLY_MAX_MB", &TutuCtx::Knobs::wide_early_max_mb, 0, 65536, true},
     {"any_near_first", "TUTU_ANY_NEAR_FIRST", &TutuCtx::Knobs::any_near_first, 0, 1},
     {"kernel_events", "TUTU_KERNEL_EVENTS", &TutuCtx::Knobs::kernel_events, 0, 1},
     {"leaf_again", "TUTU_LEAF_AGAIN", &TutuCtx::Knobs::leaf_again, 1, 65},
     {"trace_xcd", "TUTU_TRACE_XCD", &TutuCtx::Knobs::trace_xcd, 0, 1},
     {"util_stats", "TUTU_UTIL_STATS", &TutuCtx::Knobs::util_stats, 0, 1},
     {"bidir_units", "TUTU_BIDIR_UNITS", &TutuCtx::Knobs::bidir_units, 64, 1 << 24},
+    {"exact", "TUTU_EXACT", &TutuCtx::Knobs::exact, 0, 1},
+    {"cold_paths_mi", "TUTU_COLD_PATHS_MI", &TutuCtx::Knobs::cold_paths_mi, 0, 4096},
 };
 
 // strict integer parse: the whole string must be a number inside [lo, hi]
@@ -249,21 +284,45 @@ Records records_of(WorkSet& w, int which) {
 
 #define TUTU_META_STRIDE 8  // uint32 per depth in list_meta
 
-int ensure_set(WorkSet& w, size_t want_slots) {
+long long now_us() {
+	return std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+// the growth thread, before and after every buffer it allocates (TutuCtx::Grow: pacing)
+bool pace_before(TutuCtx* c) {
+	if (!c) return true;
+	while (c->grow.slow.load(std::memory_order_relaxed) && !c->grow.hurry.load(std::memory_order_relaxed)) {
+		if (c->grow.stop.load(std::memory_order_relaxed)) return false;
+		if (!c->rendering.load(std::memory_order_acquire) && now_us() - c->idle_since_us.load(std::memory_order_relaxed) > 30000) break;
+		std::this_thread::sleep_for(std::chrono::microseconds(500));
+	}
+	return !c->grow.stop.load(std::memory_order_relaxed);
+}
+void pace_after(TutuCtx* c, long long t0_us) {
+	if (c && now_us() - t0_us > 3000) c->grow.slow.store(1, std::memory_order_relaxed);  // > 3 ms for <= 0.7 GB: memory that has to be cleared first
+}
+
+int ensure_set(WorkSet& w, size_t want_slots, TutuCtx* pace = nullptr) {
 	int rc;
 	const size_t cap = (want_slots + TUTU_LIST_TILE - 1) / TUTU_LIST_TILE * TUTU_LIST_TILE;
+	auto paced = [&](auto& buf, size_t n) {
+		if (!pace_before(pace)) return (int)TUTU_E_OOM;  // given up (destroy)
+		const long long t0 = now_us();
+		const int r = buf.ensure(n);
+		pace_after(pace, t0);
+		return r;
+	};
 	if (cap > w.cap) {
 		for (int k = 0; k < 2; k++) {
 			for (int f = 0; f < 10; f++)
-				if ((rc = w.rec[k][f].ensure(cap)) != TUTU_OK) return rc;
+				if ((rc = paced(w.rec[k][f], cap)) != TUTU_OK) return rc;
 			if ((rc = w.key[k].ensure(cap)) != TUTU_OK) return rc;
 			if ((rc = w.verdict[k].ensure(cap)) != TUTU_OK) return rc;
 		}
-		if ((rc = w.hitC.ensure(cap)) != TUTU_OK) return rc;
+		if ((rc = paced(w.hitC, cap)) != TUTU_OK) return rc;
 		if ((rc = w.hitK.ensure(cap)) != TUTU_OK) return rc;
-		if ((rc = w.F.ensure(cap)) != TUTU_OK) return rc;
-		if ((rc = w.lists.ensure(2 * cap)) != TUTU_OK) return rc;
-		if ((rc = w.defer.ensure(cap)) != TUTU_OK) return rc;
+		if ((rc = paced(w.F, cap)) != TUTU_OK) return rc;
+		if ((rc = paced(w.lists, 2 * cap)) != TUTU_OK) return rc;
+		if ((rc = paced(w.defer, cap)) != TUTU_OK) return rc;
 		if ((rc = w.tile_counts.ensure(2 * (cap / TUTU_LIST_TILE))) != TUTU_OK) return rc;
 		if ((rc = w.tile_offsets.ensure(2 * (cap / TUTU_LIST_TILE))) != TUTU_OK) return rc;
 		w.cap = cap;
@@ -272,6 +331,61 @@ int ensure_set(WorkSet& w, size_t want_slots) {
 	if ((rc = w.part.ensure(2 * TUTU_PART_BLOCKS * 4)) != TUTU_OK) return rc;
 	if (!w.ev_resolved) HIP_TRY(hipEventCreateWithFlags(&w.ev_resolved, hipEventDisableTiming));
 	return TUTU_OK;
+}
+
+void release_set(WorkSet& w) {
+	for (int k2 = 0; k2 < 2; k2++) {
+		for (int f = 0; f < 10; f++) w.rec[k2][f].release();
+		w.key[k2].release();
+		w.verdict[k2].release();
+	}
+	w.hitC.release(); w.hitK.release(); w.F.release(); w.lists.release(); w.tile_counts.release(); w.tile_offsets.release();
+	w.list_meta.release(); w.part.release(); w.defer.release(); w.gstack.release();
+	if (w.ev_resolved) (void)hipEventDestroy(w.ev_resolved);
+	w.ev_resolved = nullptr;
+	w.cap = 0;
+}
+
+// ---- background growth of the work sets (TutuCtx::Grow)
+void grow_join(TutuCtx* c) {
+	if (c->grow.th.joinable()) c->grow.th.join();
+}
+// the full-size sets are ready: they take the place of the sets in use (nothing of this context is in flight: called at the
+// start of a render, after the previous call returned synchronised)
+void grow_adopt(TutuCtx* c) {
+	const int st = c->grow.state.load(std::memory_order_acquire);
+	if (st != 2 && st != 3) return;
+	grow_join(c);
+	if (st == 2)
+		for (int k = 0; k < c->grow.n_sets; k++) {
+			if (c->grow.ws[k].cap <= c->ws[k].cap) continue;
+			std::swap(c->ws[k], c->grow.ws[k]);
+		}
+	for (int k = 0; k < TUTU_MAX_SETS; k++) {
+		// the small sets: parked until destroy when nothing is parked yet (120 hipFree calls, each of which waits for the device,
+		// cost the adopting render 25 ms of a 118 ms frame; 4 GB of 288); what a failed allocation left is released
+		if (st == 2 && c->retired[k].cap == 0 && c->grow.ws[k].cap > 0) std::swap(c->retired[k], c->grow.ws[k]);
+		else release_set(c->grow.ws[k]);
+	}
+	c->grow.state.store(st == 2 ? 0 : 4, std::memory_order_release);      // 4: failed once -- not tried again for this context
+}
+void grow_start(TutuCtx* c, size_t cap, int n_sets, size_t gstack_entries) {
+	grow_join(c);
+	c->grow.cap = cap;
+	c->grow.n_sets = n_sets;
+	c->grow.gstack_entries = gstack_entries;
+	c->grow.slow.store(0);
+	c->grow.state.store(1, std::memory_order_release);
+	c->grow.th = std::thread([c]() {
+		const auto t0 = std::chrono::steady_clock::now();
+		int rc = hipSetDevice(c->device) == hipSuccess ? TUTU_OK : TUTU_E_HIP;
+		for (int k = 0; k < c->grow.n_sets && rc == TUTU_OK; k++) {
+			rc = ensure_set(c->grow.ws[k], c->grow.cap, c);
+			if (rc == TUTU_OK && c->grow.gstack_entries > 0) rc = c->grow.ws[k].gstack.ensure(c->grow.gstack_entries);
+		}
+		c->grow.seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+		c->grow.state.store(rc == TUTU_OK ? 2 : 3, std::memory_order_release);
+	});
 }
 
 int ensure_work(TutuCtx* c, size_t want_slots, size_t nitems, int n_sets) {
@@ -606,39 +720,83 @@ int render_impl(TutuCtx* c, const TutuCameraFrame* cam, const TutuRenderParams* 
 	// as every stream gets the same whole number of passes -- Cornell box 27 passes of 19 spp 2593, 8 x 64 spp 2750, 4 x 128
 	// 2794, but 6 x 86 2618 and 5 x 103 2463; bunny stand-in 24 x 11 spp 1316, 8 x 32 1389; veach room 20 x 26 1235, 8 x 64
 	// 1291; broom stand-in 128 x 8 613, 47 x 22 644.  Hence 42 Mi slots per work set: 16.6 GB each, 67 GB of the 288.)
+	grow_adopt(c);  // full-size work sets a background thread finished since the last call
+	struct InFlight {  // the growth thread allocates memory that has to be cleared only while no render is in flight
+		TutuCtx* c;
+		explicit InFlight(TutuCtx* c_) : c(c_) { c->rendering.store(1, std::memory_order_release); }
+		~InFlight() {
+			c->idle_since_us.store(now_us(), std::memory_order_relaxed);
+			c->rendering.store(0, std::memory_order_release);
+		}
+	} in_flight(c);
 	int64_t max_paths = rp->max_paths > 0 ? rp->max_paths : ((int64_t)168 << 20);
 	if (rp->max_paths <= 0) {
 		// the default must fit the device: at most half of what is free now plus what this context's work sets already hold
 		size_t free_b = 0, total_b = 0, held = 0;
-		for (int k = 0; k < TUTU_MAX_SETS; k++) held += c->ws[k].cap * (size_t)TUTU_BYTES_PER_SLOT;
+		for (int k = 0; k < TUTU_MAX_SETS; k++) held += (c->ws[k].cap + c->grow.ws[k].cap) * (size_t)TUTU_BYTES_PER_SLOT;
 		if (hipMemGetInfo(&free_b, &total_b) == hipSuccess)
 			max_paths = std::max<int64_t>((int64_t)4 << 20, std::min<int64_t>(max_paths, (int64_t)((free_b + held) / 2 / TUTU_BYTES_PER_SLOT)));
 	}
 	const int want_sets = std::max(1, std::min(c->opt_sets > 0 ? c->opt_sets : c->knobs.sets, TUTU_MAX_SETS));
+	const size_t npix_pad = (size_t)((npix + 255) / 256 * 256);  // stage 0 fills one 64-slot chunk per wave
 	// the pass size does not depend on how many passes are in flight (TUTU_SETS / tutu_hip_set_option "sets" are
 	// measuring aids): max_paths is always split into TUTU_MAX_SETS passes' worth of slots, and the passes of a frame are
 	// equal and a multiple of TUTU_MAX_SETS in number (no stream is left alone with a last pass)
-	int spp_pass = rp->spp_per_pass > 0 ? rp->spp_per_pass : (int)std::max<int64_t>(1, (max_paths / TUTU_MAX_SETS) / npix);
-	spp_pass = std::min(spp_pass, rp->spp);
-	spp_pass = std::min(spp_pass, 65535);  // grid.y limit
-	int n_passes = (rp->spp + spp_pass - 1) / spp_pass;
-	if (rp->spp_per_pass <= 0 && n_passes >= TUTU_MAX_SETS) {
-		n_passes = (n_passes + TUTU_MAX_SETS - 1) / TUTU_MAX_SETS * TUTU_MAX_SETS;
-		spp_pass = (rp->spp + n_passes - 1) / n_passes;
-		n_passes = (rp->spp + spp_pass - 1) / spp_pass;
-	}
-	if (rp->spp_per_pass <= 0 && n_passes < want_sets && !c->knobs.one_set) {
-		// a frame that fits fewer passes than there are streams (few spp): smaller passes, so that the stages of several
-		// passes can still overlap -- as long as a pass keeps about 3 Mi paths (800 x 800 x 16 spp: three passes of 6 / 5 / 5 spp
-		// are 5 % faster than four of 4, 1680 vs 1590 Msamples/s; one pass: 1430)
-		const int split = (int)std::min<int64_t>(std::min(want_sets, rp->spp), std::max<int64_t>(1, ((int64_t)npix * rp->spp) / (3 << 20)));
-		if (split > n_passes) {
-			spp_pass = (rp->spp + split - 1) / split;
+	struct Sizing {
+		int spp_pass, n_passes, n_sets;
+		size_t cap;
+	};
+	auto size_passes = [&](int64_t paths, size_t cap_limit) {
+		Sizing z;
+		int spp_pass = rp->spp_per_pass > 0 ? rp->spp_per_pass : (int)std::max<int64_t>(1, (paths / TUTU_MAX_SETS) / npix);
+		if (cap_limit > 0) spp_pass = (int)std::max<size_t>(1, std::min<size_t>((size_t)spp_pass, cap_limit / npix_pad));
+		spp_pass = std::min(spp_pass, rp->spp);
+		spp_pass = std::min(spp_pass, 65535);  // grid.y limit
+		int n_passes = (rp->spp + spp_pass - 1) / spp_pass;
+		if (rp->spp_per_pass <= 0 && n_passes >= TUTU_MAX_SETS) {
+			n_passes = (n_passes + TUTU_MAX_SETS - 1) / TUTU_MAX_SETS * TUTU_MAX_SETS;
+			spp_pass = (rp->spp + n_passes - 1) / n_passes;
 			n_passes = (rp->spp + spp_pass - 1) / spp_pass;
 		}
+		if (rp->spp_per_pass <= 0 && n_passes < want_sets && !c->knobs.one_set) {
+			// a frame that fits fewer passes than there are streams (few spp): smaller passes, so that the stages of several
+			// passes can still overlap -- as long as a pass keeps about 3 Mi paths (800 x 800 x 16 spp: three passes of 6 / 5 / 5 spp
+			// are 5 % faster than four of 4, 1680 vs 1590 Msamples/s; one pass: 1430)
+			const int split = (int)std::min<int64_t>(std::min(want_sets, rp->spp), std::max<int64_t>(1, ((int64_t)npix * rp->spp) / (3 << 20)));
+			if (split > n_passes) {
+				spp_pass = (rp->spp + split - 1) / split;
+				n_passes = (rp->spp + spp_pass - 1) / spp_pass;
+			}
+		}
+		z.spp_pass = spp_pass;
+		z.n_passes = n_passes;
+		z.n_sets = c->knobs.one_set ? 1 : std::min(want_sets, n_passes);  // one_set: profiling aid, no overlap, clean per-kernel times
+		z.cap = npix_pad * (size_t)spp_pass;
+		return z;
+	};
+	Sizing use = size_passes(max_paths, 0);
+	const Sizing full = use;
+	bool want_grow = false;
+	// Cold start.  The reference's mains render ONCE per process (src/main_cornellBox.cpp:75-79), so what the first render of a
+	// context costs is what a drop-in user sees -- and 67 GB of hipMalloc can take 1.7 s where the frame takes 0.12 (round 3:
+	// first render 1.84 s).  With the default sizing a context allocates only `cold_paths_mi` Mi slots itself (smaller, more
+	// numerous passes: a few per cent slower), a host thread allocates the full-size sets meanwhile, and the first render that
+	// finds them ready adopts them (grow_adopt above).  A caller that names max_paths or spp_per_pass gets exactly that, at once.
+	if (rp->max_paths <= 0 && rp->spp_per_pass <= 0 && c->knobs.cold_paths_mi > 0) {
+		size_t have = (size_t)-1;
+		for (int k = 0; k < use.n_sets; k++) have = std::min(have, c->ws[k].cap);
+		if (have < use.cap) {
+			const size_t cold_cap = ((size_t)c->knobs.cold_paths_mi << 20) / TUTU_MAX_SETS;
+			const size_t limit = std::max(have, cold_cap);
+			if (limit < use.cap) {
+				use = size_passes(max_paths, limit);
+				want_grow = c->grow.state.load(std::memory_order_acquire) == 0;  // started when this frame is done (below)
+			}
+		}
 	}
-	const int n_sets = c->knobs.one_set ? 1 : std::min(want_sets, n_passes);  // one_set: profiling aid, no overlap, clean per-kernel times
-	const size_t cap = (size_t)((npix + 255) / 256 * 256) * (size_t)spp_pass;  // stage 0 fills one 64-slot chunk per wave
+	const int spp_pass = use.spp_pass;
+	const int n_sets = use.n_sets;
+	const size_t cap = use.cap;
 	int rc = ensure_work(c, cap, (size_t)npix, n_sets);
 	if (rc != TUTU_OK) return rc;
 	const int32_t* d_pixels = nullptr;
@@ -687,6 +845,8 @@ int render_impl(TutuCtx* c, const TutuCameraFrame* cam, const TutuRenderParams* 
 		st->spp_per_pass = (uint32_t)spp_pass;
 		st->n_sets = (uint32_t)n_sets;
 	}
+	// the frame is done (collect_stats waited for it): now the full-size work sets, on a thread of their own
+	if (rc == TUTU_OK && want_grow) grow_start(c, full.cap, full.n_sets, c->ktrace_deep > 0 ? (size_t)c->ktrace_deep * TUTU_PART_BLOCKS * 256 : 0);
 	return rc;
 }
 
@@ -738,7 +898,10 @@ int tutu_hip_create(const TutuSceneDesc* scene, int device, TutuCtx** out) {
 	};
 	if (hipSetDevice(device) != hipSuccess) return fail(TUTU_E_NO_DEVICE);
 	hipDeviceProp_t prop;
-	if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+	if (hipGetDeviceProperties(&prop, device) == hipSuccess) {
+		c->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+		if (prop.sharedMemPerBlock >= 32 * 1024) c->max_lds_per_block = prop.sharedMemPerBlock;
+	}
 	if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) return fail(TUTU_E_HIP);
 	for (int k = 0; k < TUTU_MAX_SETS - 1; k++)
 		if (hipStreamCreateWithFlags(&c->extra_streams[k], hipStreamNonBlocking) != hipSuccess) return fail(TUTU_E_HIP);
@@ -773,6 +936,7 @@ int tutu_hip_create(const TutuSceneDesc* scene, int device, TutuCtx** out) {
 	sc.pair_leaves = c->hs.pair_leaves ? 1 : 0;
 	sc.wnodes = c->d_wnodes.p;
 	sc.has_wide = 0;  // decided below, with the traversal kernels' LDS budget
+	sc.exact = c->knobs.exact;
 	memcpy(sc.wide_lo, c->hs.wide_origin_lo, 12);
 	memcpy(sc.wide_hi, c->hs.wide_origin_hi, 12);
 	sc.has_tex = c->textured ? 1 : 0;
@@ -873,6 +1037,8 @@ int tutu_hip_create(const TutuSceneDesc* scene, int device, TutuCtx** out) {
 	if (c->knobs.trace_bpc > 0 && c->knobs.trace_bpc < c->trace_blocks_per_cu) {
 		c->trace_blocks_per_cu = c->knobs.trace_bpc;
 		c->ktrace_lds_bytes = std::max<unsigned>(c->ktrace_lds_bytes, (unsigned)((160 * 1024) / (c->knobs.trace_bpc + 1) + 1024));
+		// (never beyond what one work-group may ask for on this device: one block per CU is then a matter of the grid)
+		c->ktrace_lds_bytes = std::min<unsigned>(c->ktrace_lds_bytes, std::max<unsigned>((unsigned)c->max_lds_per_block - 64u, (unsigned)((size_t)c->ktrace_entries * 256 * sizeof(int) + (c->lds_scene ? scene_bytes : 0))));
 	}
 	*out = c;
 	return TUTU_OK;
@@ -890,23 +1056,19 @@ int tutu_hip_destroy(TutuCtx* c) {
 	c->d_tri_class.release(); c->d_nodes.release(); c->d_tri_isect.release(); c->d_tri_shade.release(); c->d_mats.release(); c->d_lights.release();
 	for (int k = 0; k < TUTU_MAX_SETS - 1; k++)
 		if (c->extra_streams[k]) (void)hipStreamSynchronize(c->extra_streams[k]);
+	c->grow.stop.store(1);
+	grow_join(c);  // a background allocation in flight gives up at its next buffer
 	for (int k = 0; k < TUTU_MAX_SETS; k++) {
-		TutuCtx::WorkSet& w = c->ws[k];
-		for (int k2 = 0; k2 < 2; k2++) {
-			for (int f = 0; f < 10; f++) w.rec[k2][f].release();
-			w.key[k2].release();
-			w.verdict[k2].release();
-		}
-		w.hitC.release(); w.hitK.release(); w.F.release(); w.lists.release(); w.tile_counts.release(); w.tile_offsets.release();
-		w.list_meta.release(); w.part.release(); w.defer.release(); w.gstack.release();
-		if (w.ev_resolved) (void)hipEventDestroy(w.ev_resolved);
+		release_set(c->ws[k]);
+		release_set(c->grow.ws[k]);
+		release_set(c->retired[k]);
 	}
 	if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
 	for (int k = 0; k < TUTU_MAX_SETS - 1; k++)
 		if (c->extra_streams[k]) (void)hipStreamDestroy(c->extra_streams[k]);
 	c->prim_dir.release(); c->prim_hit.release(); c->accum.release();
 	c->totals.release(); c->pixels.release(); c->u32a.release(); c->u32b.release();
-	c->out_stage.release();
+	c->out_stage.release(); c->gathered.release(); c->frame_stage.release(); c->gather_index.release();
 	c->bd.own.release(); c->bd.own_list.release(); c->bd.ev_val.release(); c->bd.ev_key.release(); c->bd.ev_key_sorted.release();
 	c->bd.idx.release(); c->bd.idx_sorted.release(); c->bd.sort_tmp.release(); c->bd.frame.release(); c->bd.last_set.release();
 	if (c->bd.t0) (void)hipEventDestroy(c->bd.t0);
@@ -926,7 +1088,13 @@ int tutu_hip_set_option(TutuCtx* c, const char* name, int value) {
 	for (const KnobDesc& k : kKnobs)
 		if (strcmp(name, k.name) == 0) {
 			if (value < k.lo || value > k.hi) return TUTU_E_INVALID;
+			if (k.create_only) {  // tree choice / LDS carve-up were derived from it in tutu_hip_create: changing it now would do nothing
+				if (c->knobs.*(k.field) == value) return TUTU_OK;
+				g_last_error = std::string("option \"") + k.name + "\" is read at tutu_hip_create only (set " + k.env + " before creating the context)";
+				return TUTU_E_INVALID;
+			}
 			c->knobs.*(k.field) = value;
+			if (k.field == &TutuCtx::Knobs::exact) c->sc.exact = value;
 			return TUTU_OK;
 		}
 	return TUTU_E_INVALID;
@@ -986,12 +1154,40 @@ int tutu_hip_get_option(TutuCtx* c, const char* name, int* value) {
 		*value = c->shade_tab;
 		return TUTU_OK;
 	}
+	if (strcmp(name, "work_paths_mi") == 0) {  // path slots the work sets in use hold, all sets together, in Mi
+		size_t n = 0;
+		for (int k = 0; k < TUTU_MAX_SETS; k++) n += c->ws[k].cap;
+		*value = (int)(n >> 20);
+		return TUTU_OK;
+	}
+	if (strcmp(name, "growing") == 0) {  // 1: a background thread is allocating full-size work sets, 2: they wait to be adopted by the next render
+		const int st = c->grow.state.load(std::memory_order_acquire);
+		*value = (st == 1 || st == 2) ? st : 0;
+		return TUTU_OK;
+	}
+	if (strcmp(name, "grow_ms") == 0) {  // how long the last background allocation took
+		*value = (int)(c->grow.seconds * 1e3);
+		return TUTU_OK;
+	}
 	for (const KnobDesc& k : kKnobs)
 		if (strcmp(name, k.name) == 0) {
 			*value = c->knobs.*(k.field);
 			return TUTU_OK;
 		}
 	return TUTU_E_INVALID;
+}
+
+int tutu_hip_work_ready(TutuCtx* c, int wait) {
+	if (!c) return TUTU_E_INVALID;
+	HIP_TRY(hipSetDevice(c->device));
+	if (wait) {
+		c->grow.hurry.store(1);
+		grow_join(c);
+		c->grow.hurry.store(0);
+	}
+	grow_adopt(c);
+	const int st = c->grow.state.load(std::memory_order_acquire);
+	return st == 1 ? 1 : 0;
 }
 
 int tutu_hip_scene_info(TutuCtx* c, TutuBvhInfo* bvh, uint32_t* n_lights) {
@@ -1033,14 +1229,26 @@ int tutu_hip_render(TutuCtx* c, const TutuCameraFrame* cam, const TutuRenderPara
 // The N-device form of tutu_hip_render.  The reference splits image ROWS statically over its 20 threads
 // (PathTracing.hpp:393-429); here the work items are dealt to the contexts in 32x32 pixel tiles, round-robin (rows of
 // a Cornell-like frame differ a lot in cost), pixels inside a tile in 8x8 blocks so that a wavefront covers a compact
-// patch.  One host thread per context (the ABI's threading rule); every context writes its own items of out_rgb.
-// The RNG is keyed by pixel and sample, so the frame is bit-identical to the one-context call for any n.
-int tutu_hip_render_multi(TutuCtx* const* ctxs, int32_t n, const TutuCameraFrame* cam, const TutuRenderParams* rp, float* out_rgb,
-                          TutuStats* stats) {
-	if (!ctxs || n <= 0 || !cam || !rp || !out_rgb) return TUTU_E_INVALID;
+// patch.  One host thread per context (the ABI's threading rule); every context renders its own items into a piece in its
+// own device's memory.  The gather is on the DEVICE side, like bench.py's (tuturenderer_amd/dist.py): the pieces travel to
+// the first context's device by peer copies (xGMI between the GPUs of a node) into one buffer in context order, and ONE
+// kernel un-tiles that buffer into the frame.  The RNG is keyed by pixel and sample, so the frame is bit-identical to the
+// one-context call for any n.
+__global__ void __launch_bounds__(256) k_untile(const float* gathered, const int32_t* item_of_row, float* out, uint32_t n) {
+	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n) return;
+	const size_t o = 3 * (size_t)item_of_row[i];
+	out[o + 0] = gathered[3 * (size_t)i + 0];
+	out[o + 1] = gathered[3 * (size_t)i + 1];
+	out[o + 2] = gathered[3 * (size_t)i + 2];
+}
+
+int tutu_hip_render_multi_device(TutuCtx* const* ctxs, int32_t n, const TutuCameraFrame* cam, const TutuRenderParams* rp, float* d_out_rgb,
+                                 void* stream, TutuStats* stats) {
+	if (!ctxs || n <= 0 || !cam || !rp || !d_out_rgb) return TUTU_E_INVALID;
 	for (int k = 0; k < n; k++)
 		if (!ctxs[k]) return TUTU_E_INVALID;
-	if (n == 1) return tutu_hip_render(ctxs[0], cam, rp, out_rgb, stats);
+	if (n == 1) return tutu_hip_render_device(ctxs[0], cam, rp, d_out_rgb, stream, stats);
 	int64_t n_items;
 	int x0 = 0, y0 = 0, rect_w = 1;
 	if (rp->pixels) {
@@ -1072,6 +1280,9 @@ int tutu_hip_render_multi(TutuCtx* const* ctxs, int32_t n, const TutuCameraFrame
 		const int lx = x % T, ly = y % T;
 		p.order_key.push_back(((uint32_t)tile << 10) | (uint32_t)(((ly / 8) * 4 + lx / 8) << 6) | (uint32_t)((ly % 8) * 8 + lx % 8));
 	}
+	std::vector<size_t> offset((size_t)n + 1, 0);
+	for (int k = 0; k < n; k++) offset[(size_t)k + 1] = offset[(size_t)k] + pieces[(size_t)k].pixels.size();
+	std::vector<int32_t> item_of_row((size_t)n_items);  // row r of the gathered buffer -> work item
 	std::vector<int> rcs((size_t)n, TUTU_OK);
 	std::vector<std::string> errs((size_t)n);
 	std::vector<std::thread> threads;
@@ -1086,18 +1297,20 @@ int tutu_hip_render_multi(TutuCtx* const* ctxs, int32_t n, const TutuCameraFrame
 			for (size_t i = 0; i < perm.size(); i++) perm[i] = (uint32_t)i;
 			std::stable_sort(perm.begin(), perm.end(), [&p](uint32_t a, uint32_t b) { return p.order_key[a] < p.order_key[b]; });
 			std::vector<int32_t> pix(perm.size());
-			for (size_t i = 0; i < perm.size(); i++) pix[i] = p.pixels[perm[i]];
-			std::vector<float> piece(3 * pix.size());
+			for (size_t i = 0; i < perm.size(); i++) {
+				pix[i] = p.pixels[perm[i]];
+				item_of_row[offset[(size_t)k] + i] = p.items[perm[i]];
+			}
 			TutuRenderParams q = *rp;
 			q.pixels = pix.data();
 			q.n_pixels = (int32_t)pix.size();
-			const int rc = tutu_hip_render(ctxs[k], cam, &q, piece.data(), stats ? &stats[k] : nullptr);
+			TutuCtx* c = ctxs[k];
+			int rc = hipSetDevice(c->device) == hipSuccess ? TUTU_OK : TUTU_E_HIP;
+			if (rc == TUTU_OK) rc = c->out_stage.ensure(3 * pix.size());
+			// the piece stays in this context's device memory (render_impl returns with the context's stream synchronised)
+			if (rc == TUTU_OK) rc = render_impl(c, cam, &q, c->out_stage.p, c->stream, stats ? &stats[k] : nullptr);
 			rcs[(size_t)k] = rc;
-			if (rc != TUTU_OK) {
-				errs[(size_t)k] = g_last_error;
-				return;
-			}
-			for (size_t i = 0; i < perm.size(); i++) memcpy(out_rgb + 3 * (size_t)p.items[perm[i]], &piece[3 * i], 12);
+			if (rc != TUTU_OK) errs[(size_t)k] = g_last_error;
 		});
 	}
 	for (auto& t : threads) t.join();
@@ -1106,6 +1319,43 @@ int tutu_hip_render_multi(TutuCtx* const* ctxs, int32_t n, const TutuCameraFrame
 			g_last_error = errs[(size_t)k];
 			return rcs[(size_t)k];
 		}
+	// ---- the gather, on the first context's device: peer copies into one buffer in context order + one un-tiling kernel
+	TutuCtx* root = ctxs[0];
+	HIP_TRY(hipSetDevice(root->device));
+	hipStream_t s = stream ? (hipStream_t)stream : root->stream;
+	int rc = root->gathered.ensure(3 * (size_t)n_items);
+	if (rc != TUTU_OK) return rc;
+	if ((rc = root->gather_index.ensure((size_t)n_items)) != TUTU_OK) return rc;
+	HIP_TRY(hipMemcpyAsync(root->gather_index.p, item_of_row.data(), sizeof(int32_t) * (size_t)n_items, hipMemcpyHostToDevice, s));
+	for (int k = 0; k < n; k++) {
+		const size_t rows = pieces[(size_t)k].pixels.size();
+		if (rows == 0) continue;
+		float* dst = root->gathered.p + 3 * offset[(size_t)k];
+		if (ctxs[k]->device == root->device) HIP_TRY(hipMemcpyAsync(dst, ctxs[k]->out_stage.p, sizeof(float) * 3 * rows, hipMemcpyDeviceToDevice, s));
+		else HIP_TRY(hipMemcpyPeerAsync(dst, root->device, ctxs[k]->out_stage.p, ctxs[k]->device, sizeof(float) * 3 * rows, s));
+	}
+	hipLaunchKernelGGL(k_untile, dim3((unsigned)((n_items + 255) / 256)), dim3(256), 0, s, root->gathered.p, root->gather_index.p, d_out_rgb, (uint32_t)n_items);
+	HIP_TRY(hipGetLastError());
+	HIP_TRY(hipStreamSynchronize(s));
+	return TUTU_OK;
+}
+
+int tutu_hip_render_multi(TutuCtx* const* ctxs, int32_t n, const TutuCameraFrame* cam, const TutuRenderParams* rp, float* out_rgb,
+                          TutuStats* stats) {
+	if (!ctxs || n <= 0 || !cam || !rp || !out_rgb) return TUTU_E_INVALID;
+	for (int k = 0; k < n; k++)
+		if (!ctxs[k]) return TUTU_E_INVALID;
+	if (n == 1) return tutu_hip_render(ctxs[0], cam, rp, out_rgb, stats);
+	int64_t n_items = rp->pixels ? (int64_t)rp->n_pixels : (int64_t)(rp->x1 - rp->x0) * (rp->y1 - rp->y0);
+	if (n_items <= 0) return TUTU_E_INVALID;
+	TutuCtx* root = ctxs[0];
+	HIP_TRY(hipSetDevice(root->device));
+	int rc = root->frame_stage.ensure(3 * (size_t)n_items);
+	if (rc != TUTU_OK) return rc;
+	rc = tutu_hip_render_multi_device(ctxs, n, cam, rp, root->frame_stage.p, nullptr, stats);
+	if (rc != TUTU_OK) return rc;
+	HIP_TRY(hipSetDevice(root->device));
+	HIP_TRY(hipMemcpy(out_rgb, root->frame_stage.p, sizeof(float) * 3 * (size_t)n_items, hipMemcpyDeviceToHost));  // ONE frame-sized D2H
 	return TUTU_OK;
 }
 

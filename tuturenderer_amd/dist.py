@@ -39,17 +39,27 @@ class FrameGather:
     "nccl" = RCCL) straight into one contiguous (W*H, 3) buffer in rank order -- rank 0's own piece IS the
     head of that buffer -- and ONE index_copy (one kernel) un-tiles it into the frame.
 
-    Ordering without host synchronisation: the library is handed torch's current stream (the ABI's `stream` argument),
-    so its kernels are ordered after the previous frame's send / un-tiling, which read `piece`, by stream order alone.
+    Ordering without host synchronisation: FrameGather owns ONE non-default stream.  The library is handed that stream (the
+    ABI's `stream` argument: its first kernel and its last -- the finalize that writes `piece` -- run on it), the collective
+    and the un-tiling are issued on it, so the next frame's render is ordered after this frame's send / un-tiling, which read
+    `piece`, by the stream itself.  (Torch's DEFAULT stream would not do: its handle is 0, which the ABI reads as "the
+    context's own stream" -- a non-blocking stream that is ordered with nothing of torch's.)  A consumer of `frame` on another
+    stream calls wait() (or synchronises the device, as bench.py's fences do).
+
+    self_loop: rehearsal of the collective with ONE rank -- rank 0 sends its piece to ITSELF through the process group (one
+    grouped send + recv, the same batch_isend_irecv call as with N ranks) into a second buffer and un-tiles from there: the
+    RCCL code path on a one-GPU box (tests/test_hip_parity.py).
     """
 
-    def __init__(self, W, H, rank, world, device, tile=TILE, host_staging=False):
+    def __init__(self, W, H, rank, world, device, tile=TILE, host_staging=False, self_loop=False):
         import torch
 
         self.torch = torch
         self.W, self.H, self.rank, self.world = W, H, rank, world
         self.device = device
         self.host_staging = host_staging  # gloo rehearsal on GPUs: the collective runs on CPU copies of the pieces
+        self.self_loop = bool(self_loop) and world == 1
+        self.stream = torch.cuda.Stream(device) if device.type == "cuda" else None
         self.lists = tile_pixel_lists(W, H, world, tile)
         self.mine = self.lists[rank]
         self.sizes = [len(l) for l in self.lists]
@@ -66,18 +76,37 @@ class FrameGather:
             self.piece = torch.zeros((max(self.sizes[rank], 1), 3), dtype=torch.float32, device=device)[: self.sizes[rank]]
             self.frame = None
             self.index = None
+        self.looped = torch.zeros((W * H, 3), dtype=torch.float32, device=device) if self.self_loop else None
+        if self.stream is not None:
+            self.stream.wait_stream(torch.cuda.current_stream(device))  # the buffers' zero fills ran on the caller's stream
 
     def render(self, ctx, spp, key0, key1, pixels=None, **kw):
-        """ctx.render_device into this rank's piece, on torch's current stream: ordered after the previous frame's consumers
+        """ctx.render_device into this rank's piece, on FrameGather's own stream: ordered after the previous frame's consumers
         of `piece` (send / un-tiling) by the stream itself -- no host wait between frames"""
-        stream = None
-        if self.device.type == "cuda":
-            stream = self.torch.cuda.current_stream(self.device).cuda_stream
         return ctx.render_device(self.piece.data_ptr(), spp, key0, key1, pixels=self.mine if pixels is None else pixels,
-                                 stream=stream, **kw)
+                                 stream=self.stream.cuda_stream if self.stream is not None else None, **kw)
+
+    def wait(self):
+        """orders the caller's current stream after everything FrameGather has enqueued (the frame is then safe to read there)"""
+        if self.stream is not None:
+            self.torch.cuda.current_stream(self.device).wait_stream(self.stream)
 
     def assemble(self):
-        """the collective (world > 1) + ONE un-tiling kernel on rank 0"""
+        """the collective (world > 1) + ONE un-tiling kernel on rank 0, on FrameGather's stream"""
+        if self.stream is not None:
+            with self.torch.cuda.stream(self.stream):
+                return self._assemble()
+        return self._assemble()
+
+    def _assemble(self):
+        if self.self_loop:
+            import torch.distributed as dist
+
+            ops = [dist.P2POp(dist.isend, self.gathered, 0), dist.P2POp(dist.irecv, self.looped, 0)]
+            for w in dist.batch_isend_irecv(ops):
+                w.wait()
+            self.frame.index_copy_(0, self.index, self.looped)
+            return self.frame
         if self.world > 1:
             import torch.distributed as dist
 
