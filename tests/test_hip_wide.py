@@ -143,28 +143,85 @@ def test_million_triangle_scene_create_time_and_hits(tr, monkeypatch):
     o = np.stack([r.uniform(0, 500, 200_000), r.uniform(-60, 120, 200_000), r.uniform(0, 500, 200_000)], -1).astype(np.float32)
     dd = r.normal(size=(200_000, 3)).astype(np.float32)
     dd /= np.linalg.norm(dd, axis=1, keepdims=True)
-    hits = {}
-    for tag, env in (("default", {}), ("reference_tree", {"TUTU_NO_SAH": "1"})):
-        monkeypatch.delenv("TUTU_NO_SAH", raising=False)
+    hits, secs = {}, {}
+    # default: the walked tree is built on the DEVICE (Morton codes, radix sort, Karras tree, refit, four-wide collapse:
+    # csrc/device_build.h) while the host builds the reference's tree; host_build: TUTU_DEVICE_BUILD=0, round 3's host SAH build
+    for tag, env in (("default", {}), ("host_build", {"TUTU_DEVICE_BUILD": "0"}), ("reference_tree", {"TUTU_NO_SAH": "1"})):
+        for k in ("TUTU_NO_SAH", "TUTU_DEVICE_BUILD"):
+            monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
-        t0 = time.perf_counter()
-        ctx = tr.Context(sc)
-        dt = time.perf_counter() - t0
-        try:
-            opt = ctx.options()
-            hits[tag] = ctx.trace_closest(o, dd)
-        finally:
-            ctx.close()
-        print(f"\n[create] {n} triangles, {tag}: tutu_hip_create {dt:.2f} s, n_refs {opt['n_refs']}, wide_tree {opt['wide_tree']}, "
-              f"wide_depth {opt['wide_depth']}, fast_depth {opt['fast_depth']}")
+        for rep in range(2):  # (the first create of a process also loads the code objects)
+            t0 = time.perf_counter()
+            ctx = tr.Context(sc)
+            dt = time.perf_counter() - t0
+            try:
+                opt = ctx.options()
+                built = ctx.get_option("device_built")
+                t1 = time.perf_counter()
+                hits[tag] = ctx.trace_closest(o, dd)
+                dt_trace = time.perf_counter() - t1
+            finally:
+                ctx.close()
+        secs[tag] = dt
+        print(f"\n[create] {n} triangles, {tag}: tutu_hip_create {dt:.2f} s, device_built {built}, n_refs {opt['n_refs']}, wide_tree {opt['wide_tree']}, "
+              f"wide_depth {opt['wide_depth']}, fast_depth {opt['fast_depth']}, 200 k rays in {dt_trace * 1e3:.0f} ms (with their host copies)")
         if tag == "default":
-            assert opt["wide_tree"] == 1 and opt["lds_scene"] == 0
-            assert dt < 6.0, dt  # 1.2 s on an idle GPU box; the bound leaves room for a busy host
-    monkeypatch.delenv("TUTU_NO_SAH", raising=False)
+            assert built == 1 and opt["wide_tree"] == 1 and opt["lds_scene"] == 0
+            assert dt < 1.5, dt  # 0.3-0.4 s on an idle GPU box; the bound leaves room for a busy host
+        if tag == "host_build":
+            assert built == 0 and opt["wide_tree"] == 1
+    for k in ("TUTU_NO_SAH", "TUTU_DEVICE_BUILD"):
+        monkeypatch.delenv(k, raising=False)
+    assert secs["default"] < secs["host_build"]
     assert 0.2 < (hits["default"]["tri"] >= 0).mean() < 0.99
-    assert bit_equal(hits["default"]["tri"], hits["reference_tree"]["tri"])
-    assert bit_equal(hits["default"]["t"], hits["reference_tree"]["t"])
+    for tag in ("default", "host_build"):
+        assert bit_equal(hits[tag]["tri"], hits["reference_tree"]["tri"]), tag
+        assert bit_equal(hits[tag]["t"], hits["reference_tree"]["t"]), tag
+
+
+def test_device_built_tree_on_the_mesh_scenes(tr, port, monkeypatch):
+    """TUTU_DEVICE_BUILD=2 forces the device build of the walked tree onto the golden mesh scenes and the broom stand-in: the golden
+    rays, 100 k random rays and shadow segments with the bits of the reference build / the unpruned recursion; a frame equal
+    to the host-built tree's byte for byte."""
+    from tuturenderer_amd import scenes
+
+    monkeypatch.setenv("TUTU_DEVICE_BUILD", "2")
+    for name in ("veach_slight", "cornell_spheres"):
+        sc, _ = _scene(name)
+        z = np.load(golden_path(f"scene_{name}.npz"))
+        S = port.scene(sc)
+        O, D = pc.scene_rays(S)
+        with tr.Context(sc) as ctx:
+            if name == "veach_slight":
+                assert ctx.get_option("device_built") == 1 and ctx.get_option("wide_tree") == 1
+            hits = ctx.trace_closest(O, D)
+            h = hits["tri"] >= 0
+            assert bit_equal(hits["tri"], z["scene.tri"]), name
+            assert bit_equal(np.where(h, hits["t"], 0).astype(np.float32), z["scene.t"]), name
+        S.close()
+    sc = scenes.broom_room(320, 180)
+    S = port.scene(sc)
+    rng = np.random.default_rng(21)
+    n = 100_000
+    O = np.stack([rng.uniform(5, 980, n), rng.uniform(5, 545, n), rng.uniform(5, 555, n)], -1).astype(np.float32)
+    D = rng.normal(size=(n, 3)).astype(np.float32)
+    D /= np.linalg.norm(D, axis=1, keepdims=True)
+    hit, t, tri, pos, _, _ = S.closest(O, D)
+    with tr.Context(sc) as ctx:
+        assert ctx.get_option("device_built") == 1
+        h = ctx.trace_closest(O, D)
+        assert bit_equal(h["tri"], np.where(hit == 1, tri, -1).astype(np.int32))
+        assert bit_equal(h["t"][hit == 1], t[hit == 1])
+        m = hit == 1
+        assert bit_equal(np.asarray(ctx.trace_any(O[m], pos[m][::-1].copy())).astype(np.uint8), S.any_hit(O[m], pos[m][::-1].copy()))
+        dev_frame = ctx.render(8, 0x5EED0001, 4)
+    S.close()
+    monkeypatch.setenv("TUTU_DEVICE_BUILD", "0")
+    with tr.Context(sc) as ctx:
+        assert ctx.get_option("device_built") == 0
+        host_frame = ctx.render(8, 0x5EED0001, 4)
+    assert dev_frame.tobytes() == host_frame.tobytes()
 
 
 def test_pair_leaves_do_not_change_a_frame(tr, monkeypatch):

@@ -503,25 +503,34 @@ int build_reference_tree(uint32_t n_tris, const float* verts, std::vector<BuildN
 // reference's tree): every |. - o| <= 4.01 ext, so m = 6 * 2^-22 * 4.01 ext ~ 5.8e-6 ext covers it with a factor 2 to spare.
 // Exponents are clamped to [-60, 60] and plain rays have 2^-60 <= |inv| <= 2^60, so s is a normal number.
 
+bool wide_frame(const float* pmin, const float* pmax, double* margin, float* origin_lo, float* origin_hi) {
+	double ext = 0;
+	for (int k = 0; k < 3; k++) {
+		if (!std::isfinite(pmin[k]) || !std::isfinite(pmax[k])) return false;
+		ext = std::max(ext, (double)pmax[k] - (double)pmin[k]);
+	}
+	double maxabs = 0;
+	for (int k = 0; k < 3; k++) maxabs = std::max(maxabs, std::max(std::fabs((double)pmin[k]), std::fabs((double)pmax[k])));
+	if (!(ext > 0) || ext > 0x1p60 || ext < 0x1p-40 || maxabs > 0x1p60) return false;  // coordinates the 8-bit frames cannot serve
+	for (int k = 0; k < 3; k++) {
+		origin_lo[k] = (float)((double)pmin[k] - 3.0 * ext);
+		origin_hi[k] = (float)((double)pmax[k] + 3.0 * ext);
+	}
+	*margin = 6.0 * 0x1p-22 * 4.01 * (ext + maxabs * 0x1p-20);
+	return true;
+}
+namespace {
+
 // t: build tree (pre-order, t[0] = root, must be an inner node); leaf_ref(bn) = the device reference of leaf bn
 template <typename LeafRef>
 static bool build_wide(const std::vector<BuildNode>& t, const LeafRef& leaf_ref, HostScene& hs) {
 	hs.wnodes.clear();
 	hs.has_wide = false;
+	hs.n_wide = 0;
 	if (t.empty() || !(t[0].left >= 0 || t[0].right >= 0)) return false;
-	double ext = 0;
-	for (int k = 0; k < 3; k++) {
-		if (!std::isfinite(t[0].pmin[k]) || !std::isfinite(t[0].pmax[k])) return false;
-		ext = std::max(ext, (double)t[0].pmax[k] - (double)t[0].pmin[k]);
-	}
-	double maxabs = 0;
-	for (int k = 0; k < 3; k++) maxabs = std::max(maxabs, std::max(std::fabs((double)t[0].pmin[k]), std::fabs((double)t[0].pmax[k])));
-	if (!(ext > 0) || ext > 0x1p60 || ext < 0x1p-40 || maxabs > 0x1p60) return false;  // coordinates the 8-bit frames cannot serve
-	for (int k = 0; k < 3; k++) {
-		hs.wide_origin_lo[k] = (float)((double)t[0].pmin[k] - 3.0 * ext);
-		hs.wide_origin_hi[k] = (float)((double)t[0].pmax[k] + 3.0 * ext);
-	}
-	const double m = 6.0 * 0x1p-22 * 4.01 * (ext + maxabs * 0x1p-20);
+	double m = 0;
+	if (!wide_frame(t[0].pmin, t[0].pmax, &m, hs.wide_origin_lo, hs.wide_origin_hi)) return false;
+	hs.wide_margin = m;
 	auto is_inner = [&](int32_t bn) { return t[bn].left >= 0 || t[bn].right >= 0; };
 	// breadth-first numbering: a wide node per collapsed group
 	struct Item { int32_t bn; int32_t id; uint32_t level; };
@@ -633,10 +642,13 @@ static bool build_wide(const std::vector<BuildNode>& t, const LeafRef& leaf_ref,
 	}
 	hs.wide_depth = max_level;
 	hs.has_wide = true;
+	hs.n_wide = (uint32_t)hs.wnodes.size();
 	return true;
 }
 
-int build_host_scene(const TutuSceneDesc* d, HostScene& hs) {
+}  // namespace
+
+int build_host_scene(const TutuSceneDesc* d, HostScene& hs, HostBuildHooks* hooks) {
 	if (!d) return TUTU_E_INVALID;
 	// TUTU_BUILD_TIMING: the phases of the host build on stderr
 	const bool timing = getenv("TUTU_BUILD_TIMING") != nullptr;
@@ -701,9 +713,25 @@ int build_host_scene(const TutuSceneDesc* d, HostScene& hs) {
 	for (uint32_t o = 0; o < n; o++)
 		tb[o] = obj_sph[o] >= 0 ? sphere_box(ss->spheres + 4 * (size_t)obj_sph[o]) : triangle_box(d->verts + 9 * (size_t)obj_tri[o]);
 	lap("objects, boxes, materials");
+	// Large scenes: the walked tree is left to the device (device_build.h), which needs the boxes and the scene box only
+	hs.device_walked = false;
+	if (hooks && hooks->device_walked && hooks->on_boxes && n > 2 && !getenv("TUTU_NO_SAH")) {
+		Box all = tb[0];
+		bool finite = true;
+		for (uint32_t o = 0; o < n; o++) {
+			all = box_union(all, tb[o]);
+			for (int k = 0; k < 3; k++) finite = finite && std::isfinite(tb[o].mn[k]) && std::isfinite(tb[o].mx[k]);
+		}
+		if (finite && wide_frame(all.mn, all.mx, &hs.wide_margin, hs.wide_origin_lo, hs.wide_origin_hi)) {
+			hs.device_walked = true;
+			hs.n_refs = n;
+			hooks->on_boxes(tb[0].mn, n, all.mn, all.mx);
+			lap("boxes handed to the device build");
+		}
+	}
 	// The walked tree (references + SAH build) needs the object boxes only: it is built on its own thread(s) BESIDE the
 	// reference's tree, and joined where it is flattened (the leaf references need the reference tree's leaf order).
-	const bool want_sah = n > 2 && !getenv("TUTU_NO_SAH");
+	const bool want_sah = n > 2 && !getenv("TUTU_NO_SAH") && !hs.device_walked;
 	std::vector<Ref> refs;
 	std::vector<BuildNode> sah;
 	uint32_t sah_depth = 0;

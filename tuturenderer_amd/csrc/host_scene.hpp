@@ -2,6 +2,7 @@
 // into the linear arrays the kernels read, light list, camera frame.  Plain C++, no GPU calls.
 #pragma once
 #include <cstdint>
+#include <functional>
 #include <vector>
 
 #include "../../include/tutu_hip.h"
@@ -127,6 +128,9 @@ struct HostScene {
 	std::vector<GpuWideNode> wnodes;   // wnodes[0] is the root
 	bool has_wide = false;
 	uint32_t wide_depth = 0;           // levels of wide nodes on the longest root-to-leaf path
+	uint32_t n_wide = 0;               // wide nodes (= wnodes.size() for the host build; the device build leaves wnodes empty)
+	bool device_walked = false;        // the walked tree was left to the device (tutu_hip.hip: device_build_walked): no SAH tree, no host wide tree
+	double wide_margin = 0;            // quantisation margin of the wide tree's boxes (host_scene.cpp: wide_frame)
 	float wide_origin_lo[3], wide_origin_hi[3];  // ray origins for which the quantisation margin was sized (others are not "plain")
 	uint32_t depth;  // max over both trees: sizes the traversal stack
 	float eta;
@@ -143,6 +147,18 @@ struct BuildNode {
 // the intersection record of n triangles (12 floats each: v0, E1, E2, normalised E1 x E2) from their 9 vertex floats
 void make_tri_isect(uint32_t n, const float* verts9, float* out12);
 int build_reference_tree(uint32_t n_tris, const float* verts, std::vector<BuildNode>& out, uint32_t* depth);
-int build_host_scene(const TutuSceneDesc* d, HostScene& out);
+// Large scenes: the tree the kernels WALK can be built on the device (device_build.h) while the host builds the reference's own
+// tree and the leaf-order tables.  device_walked = leave the references, the SAH tree and the wide tree out; on_boxes is
+// called once, as soon as the object boxes exist (n x 6 floats, object-list order, valid for the duration of the call) with
+// the scene box -- only when every coordinate is finite and the scene box can carry the wide tree's 8-bit frames; else the
+// host builds everything as usual and HostScene::device_walked stays false.
+struct HostBuildHooks {
+	bool device_walked = false;
+	std::function<void(const float* boxes6, uint32_t n, const float* lo, const float* hi)> on_boxes;
+};
+// the wide tree's frame for a scene box: quantisation margin and the region of admissible ray origins; false when the
+// coordinates cannot be served by 8-bit frames (host_scene.cpp: build_wide)
+bool wide_frame(const float* pmin, const float* pmax, double* margin, float* origin_lo, float* origin_hi);
+int build_host_scene(const TutuSceneDesc* d, HostScene& out, HostBuildHooks* hooks = nullptr);
 
 }  // namespace tutu

@@ -5,6 +5,7 @@
 #include <hipcub/hipcub.hpp>
 
 #include <algorithm>
+#include <array>
 #include <atomic>
 #include <climits>
 #include <cstdio>
@@ -19,6 +20,7 @@
 #include "device_shade.h"
 #include "device_post.h"
 #include "device_bidir.h"
+#include "device_build.h"
 #include "host_scene.hpp"
 
 using namespace tutu;
@@ -131,6 +133,8 @@ struct TutuCtx {
 		int kernel_events = 0;    // TUTU_KERNEL_EVENTS  a HIP event pair around every launch (per-kernel times in TutuStats; 2.7 % of a frame)  {0, 1}
 		int any_near_first = 1;   // TUTU_ANY_NEAR_FIRST any-hit: nearer child first              {0, 1}
 		int util_stats = 0;       // TUTU_UTIL_STATS     phase counters of the traversal kernels  {0, 1}
+		int device_build = 1;     // TUTU_DEVICE_BUILD   the walked tree of a large scene is built on the device: 0 never, 1 from device_build_min objects on, 2 always  [0, 2]
+		int device_build_min_k = 384;  // TUTU_DEVICE_BUILD_MIN_K  ... "large" = at least this many thousand objects  [1, 1048576]
 		int exact = 0;            // TUTU_EXACT          every ray takes the exact walk: reference tree, reference slab, no pruning  {0, 1}
 		int cold_paths_mi = 12;   // TUTU_COLD_PATHS_MI  Mi path slots (all work sets together) a context's FIRST default-sized render allocates itself;
 		                          //                     the rest of the default 168 Mi arrives from a background thread (0 = allocate everything at once)  [0, 4096]
@@ -235,6 +239,8 @@ const KnobDesc kKnobs[] = {
     {"util_stats", "TUTU_UTIL_STATS", &TutuCtx::Knobs::util_stats, 0, 1},
     {"bidir_units", "TUTU_BIDIR_UNITS", &TutuCtx::Knobs::bidir_units, 64, 1 << 24},
     {"exact", "TUTU_EXACT", &TutuCtx::Knobs::exact, 0, 1},
+    {"device_build", "TUTU_DEVICE_BUILD", &TutuCtx::Knobs::device_build, 0, 2, true},
+    {"device_build_min_k", "TUTU_DEVICE_BUILD_MIN_K", &TutuCtx::Knobs::device_build_min_k, 1, 1 << 20, true},
     {"cold_paths_mi", "TUTU_COLD_PATHS_MI", &TutuCtx::Knobs::cold_paths_mi, 0, 4096},
 };
 
@@ -850,6 +856,104 @@ int render_impl(TutuCtx* c, const TutuCameraFrame* cam, const TutuRenderParams* 
 	return rc;
 }
 
+
+// ---- the walked tree of a large scene, built on the device (device_build.h) while the host builds the reference's tree
+struct DeviceBuild {
+	std::thread th;
+	int rc = TUTU_OK;
+	std::string err;
+	uint32_t n_wide = 0, wide_depth = 0;
+	double seconds = 0;
+	DevBuf<float> boxes, nbox;
+	DevBuf<unsigned long long> keys, keys_sorted;
+	DevBuf<uint32_t> idx, idx_sorted, cnt;
+	DevBuf<int> child, parent, arrived, frontier[2], failed;
+	DevBuf<uint8_t> tmp;
+	void release() {
+		boxes.release(); nbox.release(); keys.release(); keys_sorted.release(); idx.release(); idx_sorted.release(); cnt.release();
+		child.release(); parent.release(); arrived.release(); frontier[0].release(); frontier[1].release(); failed.release(); tmp.release();
+	}
+};
+
+// boxes6: host, n x 6 floats (valid only during this call: copied at once); the rest runs on stream s of c->device
+int device_build_walked(TutuCtx* c, DeviceBuild& db, const float* boxes6, uint32_t n, const float* lo, const float* hi, double margin, hipStream_t s) {
+	int rc;
+	HIP_TRY(hipSetDevice(c->device));
+	if ((rc = db.boxes.ensure(6 * (size_t)n)) != TUTU_OK) return rc;
+	HIP_TRY(hipMemcpy(db.boxes.p, boxes6, sizeof(float) * 6 * (size_t)n, hipMemcpyHostToDevice));
+	if ((rc = db.keys.ensure(n)) != TUTU_OK || (rc = db.keys_sorted.ensure(n)) != TUTU_OK || (rc = db.idx.ensure(n)) != TUTU_OK ||
+	    (rc = db.idx_sorted.ensure(n)) != TUTU_OK || (rc = db.child.ensure(2 * (size_t)n)) != TUTU_OK || (rc = db.parent.ensure(2 * (size_t)n)) != TUTU_OK ||
+	    (rc = db.nbox.ensure(12 * (size_t)n)) != TUTU_OK || (rc = db.arrived.ensure(n)) != TUTU_OK || (rc = db.frontier[0].ensure(n)) != TUTU_OK ||
+	    (rc = db.frontier[1].ensure(n)) != TUTU_OK || (rc = db.cnt.ensure((size_t)n + 1)) != TUTU_OK || (rc = db.failed.ensure(1)) != TUTU_OK)
+		return rc;
+	if ((rc = c->d_wnodes.ensure(4 * (size_t)n)) != TUTU_OK) return rc;  // a wide node per binary inner node at most
+	BuildDev b;
+	b.n = n;
+	b.boxes = db.boxes.p;
+	for (int k = 0; k < 3; k++) {
+		b.lo[k] = lo[k];
+		const float e = hi[k] - lo[k];
+		b.inv[k] = e > 0.f ? 1.f / e : 0.f;
+	}
+	b.keys = db.keys_sorted.p;  // (the kernels after the sort read the sorted arrays)
+	b.idx = db.idx_sorted.p;
+	b.child = db.child.p;
+	b.parent = db.parent.p;
+	b.nbox = db.nbox.p;
+	b.arrived = db.arrived.p;
+	const dim3 blk(256), grd((n + 255) / 256);
+	hipLaunchKernelGGL(k_build_morton, grd, blk, 0, s, b, db.keys.p, db.idx.p);
+	size_t tmp_sort = 0, tmp_scan = 0;
+	HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_sort, db.keys.p, db.keys_sorted.p, db.idx.p, db.idx_sorted.p, (int)n, 0, 63, s));
+	HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_scan, db.cnt.p, db.cnt.p, (int)n + 1, s));
+	if ((rc = db.tmp.ensure(std::max(tmp_sort, tmp_scan))) != TUTU_OK) return rc;
+	HIP_TRY(hipcub::DeviceRadixSort::SortPairs(db.tmp.p, tmp_sort, db.keys.p, db.keys_sorted.p, db.idx.p, db.idx_sorted.p, (int)n, 0, 63, s));
+	HIP_TRY(hipMemsetAsync(db.arrived.p, 0, sizeof(int) * (size_t)n, s));
+	HIP_TRY(hipMemsetAsync(db.failed.p, 0, sizeof(int), s));
+	hipLaunchKernelGGL(k_build_karras, grd, blk, 0, s, b);
+	hipLaunchKernelGGL(k_build_refit, grd, blk, 0, s, b);
+	HIP_TRY(hipGetLastError());
+	// the collapse, level by level: frontier = the binary inner nodes that become this level's wide nodes
+	const int root = 0;
+	HIP_TRY(hipMemcpyAsync(db.frontier[0].p, &root, sizeof(int), hipMemcpyHostToDevice, s));
+	uint32_t n_front = 1, base = 0, level = 0;
+	while (n_front > 0) {
+		if (base + n_front > n) return TUTU_E_INVALID;  // (cannot happen: every wide node stands for a binary inner node)
+		WideLevel w;
+		w.b = b;
+		w.frontier = db.frontier[level & 1].p;
+		w.n_front = n_front;
+		w.base = base;
+		w.cnt = db.cnt.p;
+		w.next_frontier = db.frontier[(level & 1) ^ 1].p;
+		w.wnodes = c->d_wnodes.p;
+		w.margin = margin;
+		w.failed = db.failed.p;
+		const dim3 g((n_front + 255) / 256);
+		hipLaunchKernelGGL(k_wide_count, g, blk, 0, s, w);
+		HIP_TRY(hipMemsetAsync(db.cnt.p + n_front, 0, sizeof(uint32_t), s));
+		HIP_TRY(hipcub::DeviceScan::ExclusiveSum(db.tmp.p, tmp_scan, db.cnt.p, db.cnt.p, (int)n_front + 1, s));
+		hipLaunchKernelGGL(k_wide_emit, g, blk, 0, s, w);
+		HIP_TRY(hipGetLastError());
+		uint32_t next = 0;
+		HIP_TRY(hipMemcpyAsync(&next, db.cnt.p + n_front, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+		HIP_TRY(hipStreamSynchronize(s));
+		base += n_front;
+		n_front = next;
+		level++;
+		if (level > 4096) return TUTU_E_BVH_DEPTH;
+	}
+	int failed = 0;
+	HIP_TRY(hipMemcpy(&failed, db.failed.p, sizeof(int), hipMemcpyDeviceToHost));
+	if (failed) {
+		g_last_error = "device tree build: a quantised box failed its containment check";
+		return TUTU_E_UNSUPPORTED;
+	}
+	db.n_wide = base;
+	db.wide_depth = level;
+	return TUTU_OK;
+}
+
 template <typename T>
 int upload(DevBuf<float4>& buf, const std::vector<T>& v, hipStream_t s) {
 	const size_t bytes = v.size() * sizeof(T);
@@ -886,7 +990,6 @@ int tutu_hip_create(const TutuSceneDesc* scene, int device, TutuCtx** out) {
 	if (device < 0 || device >= ndev) return TUTU_E_NO_DEVICE;
 	TutuCtx* c = new TutuCtx();
 	rc = read_env_knobs(c);
-	if (rc == TUTU_OK) rc = build_host_scene(scene, c->hs);
 	if (rc != TUTU_OK) {
 		delete c;
 		return rc;
@@ -907,6 +1010,58 @@ int tutu_hip_create(const TutuSceneDesc* scene, int device, TutuCtx** out) {
 		if (hipStreamCreateWithFlags(&c->extra_streams[k], hipStreamNonBlocking) != hipSuccess) return fail(TUTU_E_HIP);
 	if (hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess) return fail(TUTU_E_HIP);
 	hipStream_t s = c->stream;
+	// Host build: the reference's tree, the leaf-order tables and -- for all but large scenes -- the walked tree.  A large
+	// scene's walked tree is built on the DEVICE meanwhile (device_build.h), on a thread of its own that drives the second stream.
+	{
+		const uint64_t n_obj = (uint64_t)scene->n_tris + (scene->spheres ? scene->spheres->n_spheres : 0);
+		const bool on_device = c->knobs.device_build == 2 ? n_obj >= 1024 : (c->knobs.device_build == 1 && n_obj >= (uint64_t)c->knobs.device_build_min_k * 1000u);
+		DeviceBuild db;
+		HostBuildHooks hooks;
+		hooks.device_walked = on_device;
+		hooks.on_boxes = [&](const float* boxes6, uint32_t n, const float* lo, const float* hi) {
+			// the copy of the boxes happens here (the caller's array lives only as long as this call); the rest on the thread
+			std::vector<float> keep(boxes6, boxes6 + 6 * (size_t)n);
+			const float l3[3] = {lo[0], lo[1], lo[2]}, h3[3] = {hi[0], hi[1], hi[2]};
+			const double margin = c->hs.wide_margin;
+			db.th = std::thread([&db, c, n, margin, keep = std::move(keep), l3 = std::array<float, 3>{l3[0], l3[1], l3[2]}, h3 = std::array<float, 3>{h3[0], h3[1], h3[2]}]() {
+				const auto t0 = std::chrono::steady_clock::now();
+				db.rc = device_build_walked(c, db, keep.data(), n, l3.data(), h3.data(), margin, c->extra_streams[0]);
+				if (db.rc != TUTU_OK) db.err = g_last_error;
+				db.seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+			});
+		};
+		rc = build_host_scene(scene, c->hs, on_device ? &hooks : nullptr);
+		if (db.th.joinable()) db.th.join();
+		if (rc == TUTU_OK && c->hs.device_walked) {
+			if (getenv("TUTU_BUILD_TIMING")) fprintf(stderr, "[tutu build] %-28s %8.3f s (its own thread, beside the host build)\n", "device: walked tree", db.seconds);
+			if (db.rc == TUTU_OK) {
+				// leaf references: ~object -> the reference tree's leaf order (+ the sphere bit)
+				const uint32_t n = (uint32_t)c->hs.leaf_of_orig.size();
+				std::vector<int> ref(n);
+				for (uint32_t o = 0; o < n; o++) {
+					const int32_t leaf = c->hs.leaf_of_orig[o];
+					ref[o] = (c->hs.tri_shade[(size_t)leaf].cls & TUTU_CLS_SPHERE) ? ~(leaf | TUTU_SPHERE_BIT) : ~leaf;
+				}
+				DevBuf<int> d_ref;
+				rc = d_ref.ensure(n);
+				if (rc == TUTU_OK && hipMemcpy(d_ref.p, ref.data(), sizeof(int) * (size_t)n, hipMemcpyHostToDevice) != hipSuccess) rc = TUTU_E_HIP;
+				if (rc == TUTU_OK) {
+					hipLaunchKernelGGL(k_wide_remap, dim3((db.n_wide + 255) / 256), dim3(256), 0, s, c->d_wnodes.p, db.n_wide, d_ref.p);
+					if (hipStreamSynchronize(s) != hipSuccess) rc = TUTU_E_HIP;
+				}
+				d_ref.release();
+				c->hs.has_wide = true;
+				c->hs.n_wide = db.n_wide;
+				c->hs.wide_depth = db.wide_depth;
+			} else {
+				// the device build gave up (a box that cannot be quantised, a tree deeper than the stack): the host builds everything
+				c->d_wnodes.release();
+				rc = build_host_scene(scene, c->hs, nullptr);
+			}
+		}
+		db.release();
+	}
+	if (rc != TUTU_OK) return fail(rc);
 	if ((rc = upload(c->d_nodes, c->hs.nodes, s)) != TUTU_OK) return fail(rc);
 	if ((rc = upload(c->d_tri_isect, c->hs.tri_isect, s)) != TUTU_OK) return fail(rc);
 	if ((rc = upload(c->d_tri_shade, c->hs.tri_shade, s)) != TUTU_OK) return fail(rc);
@@ -916,7 +1071,7 @@ int tutu_hip_create(const TutuSceneDesc* scene, int device, TutuCtx** out) {
 	if (!c->hs.tri_class.empty() && hipMemcpyAsync(c->d_tri_class.p, c->hs.tri_class.data(), c->hs.tri_class.size(), hipMemcpyHostToDevice, s) != hipSuccess)
 		return fail(TUTU_E_HIP);
 	if ((rc = upload(c->d_leaf_boxes, c->hs.leaf_boxes, s)) != TUTU_OK) return fail(rc);
-	if ((rc = upload(c->d_wnodes, c->hs.wnodes, s)) != TUTU_OK) return fail(rc);
+	if (!c->hs.device_walked && (rc = upload(c->d_wnodes, c->hs.wnodes, s)) != TUTU_OK) return fail(rc);  // (the device build wrote d_wnodes itself)
 	c->textured = !c->hs.tri_tex.empty();
 	if (c->textured) {
 		if ((rc = upload(c->d_tri_tex, c->hs.tri_tex, s)) != TUTU_OK) return fail(rc);
@@ -1029,7 +1184,7 @@ int tutu_hip_create(const TutuSceneDesc* scene, int device, TutuCtx** out) {
 	// Wide tree, leaf box requested with the triangle record (device_shade.h: EARLY): for trees that fit the L2s (TUTU_WIDE_EARLY:
 	// 0 never, 1 below TUTU_WIDE_EARLY_MAX_MB of wide nodes, 2 always).  Those kernels are built for 7 waves per SIMD -- 72
 	// registers -- so 7 blocks of 4 waves is what a CU holds.
-	const size_t wide_mb = (c->hs.wnodes.size() * sizeof(GpuWideNode)) >> 20;
+	const size_t wide_mb = ((size_t)c->hs.n_wide * sizeof(GpuWideNode)) >> 20;
 	c->wide_early = sc.has_wide && (c->knobs.wide_early == 2 || (c->knobs.wide_early == 1 && wide_mb < (size_t)c->knobs.wide_early_max_mb));
 	if (c->wide_early) c->trace_blocks_per_cu = std::min(c->trace_blocks_per_cu, 7);
 	// Fewer resident blocks than the LDS use allows (TUTU_TRACE_BPC): the request is padded so that exactly that many FIT --
@@ -1124,6 +1279,10 @@ int tutu_hip_get_option(TutuCtx* c, const char* name, int* value) {
 	}
 	if (strcmp(name, "wide_tree") == 0) {  // the persistent kernels walk the four-wide quantised tree
 		*value = c->sc.has_wide;
+		return TUTU_OK;
+	}
+	if (strcmp(name, "device_built") == 0) {  // the walked tree was built on the device (device_build.h)
+		*value = c->hs.device_walked ? 1 : 0;
 		return TUTU_OK;
 	}
 	if (strcmp(name, "wide_depth") == 0) {
