@@ -177,17 +177,30 @@ def test_multi_context_render_is_the_single_context_frame(built):
         b = tr.Context.render_multi(ctxs, 5, 1, 2, pixels=pixels)
         assert a.tobytes() == b.tobytes()
         assert all(c.last_stats["samples"] > 0 for c in ctxs)
-        # the device-side gather by itself (tutu_hip_render_multi_device): the frame stays in device memory -- a torch tensor
-        # here --, pieces gathered by peer copies in context order, ONE un-tiling kernel, on a stream of the caller's
-        import torch
+        # the device-side gather by itself (tutu_hip_render_multi_device): the frame stays in DEVICE memory, pieces gathered by peer
+        # copies in context order, ONE un-tiling kernel, on a stream of the caller's.  (Device memory and the stream come straight
+        # from the HIP runtime the library itself is linked with: torch brings a runtime of its own, and the second runtime to
+        # initialise in a process finds no GPU.)
+        import ctypes as C
 
-        d = torch.full((200 * 136, 3), -1.0, dtype=torch.float32, device="cuda:0")
-        s = torch.cuda.Stream()
-        n = tr.Context.render_multi_device(ctxs, d.data_ptr(), 12, 0x5EED0001, 3, stream=s.cuda_stream)
-        assert n == 200 * 136 and d.cpu().numpy().tobytes() == one.tobytes()
-        d5 = torch.zeros((5000, 3), dtype=torch.float32, device="cuda:0")
-        tr.Context.render_multi_device(ctxs, d5.data_ptr(), 5, 1, 2, pixels=pixels)
-        assert d5.cpu().numpy().tobytes() == a.tobytes()
+        hip = C.CDLL("libamdhip64.so")
+        d, d5, stream = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        assert hip.hipMalloc(C.byref(d), C.c_size_t(200 * 136 * 12)) == 0 and hip.hipMalloc(C.byref(d5), C.c_size_t(5000 * 12)) == 0
+        assert hip.hipStreamCreateWithFlags(C.byref(stream), C.c_uint(1)) == 0  # hipStreamNonBlocking
+        try:
+            assert hip.hipMemset(d, 0xFF, C.c_size_t(200 * 136 * 12)) == 0 and hip.hipDeviceSynchronize() == 0
+            n = tr.Context.render_multi_device(ctxs, d.value, 12, 0x5EED0001, 3, stream=stream.value)
+            got = np.empty((200 * 136, 3), np.float32)
+            assert hip.hipMemcpy(got.ctypes.data_as(C.c_void_p), d, C.c_size_t(got.nbytes), C.c_int(2)) == 0  # hipMemcpyDeviceToHost
+            assert n == 200 * 136 and got.tobytes() == one.tobytes()
+            tr.Context.render_multi_device(ctxs, d5.value, 5, 1, 2, pixels=pixels)
+            got5 = np.empty((5000, 3), np.float32)
+            assert hip.hipMemcpy(got5.ctypes.data_as(C.c_void_p), d5, C.c_size_t(got5.nbytes), C.c_int(2)) == 0
+            assert got5.tobytes() == a.tobytes()
+        finally:
+            hip.hipFree(d)
+            hip.hipFree(d5)
+            hip.hipStreamDestroy(stream)
     finally:
         for c in ctxs:
             c.close()
