@@ -237,8 +237,10 @@ int tutu_hip_render(TutuCtx* ctx, const TutuCameraFrame* cam, const TutuRenderPa
  * steady state from the first one sets "cold_paths_mi" to 0 before its first render (bench.py's timed context does). */
 int tutu_hip_work_ready(TutuCtx* ctx, int wait);
 
-/* Same, but out_rgb is a DEVICE pointer on ctx's device (e.g. a torch tensor's data_ptr); work is enqueued on
- * `stream` (a hipStream_t, NULL = the context's own stream) and the call returns after the work is complete (it ends with a hipStreamSynchronize of that stream: the ray counters of TutuStats
+/* Same, but out_rgb is a DEVICE pointer on ctx's device (e.g. a torch tensor's data_ptr).  The frame is ORDERED with `stream` (a
+ * hipStream_t of that device; NULL = no ordering with anything of the caller's): its first kernel waits for what is enqueued on
+ * `stream` at the time of the call, and `stream` waits for its last kernel -- the kernels themselves run on the context's own four
+ * streams (one hardware queue each; a pass on a fifth stream of the caller's would share a queue with another pass).  The call returns after the work is complete (it ends with a hipStreamSynchronize of that stream: the ray counters of TutuStats
  * are read back then; stats == NULL skips the read-back, not the wait). */
 int tutu_hip_render_device(TutuCtx* ctx, const TutuCameraFrame* cam, const TutuRenderParams* params,
                            float* d_out_rgb, void* stream, TutuStats* stats);

@@ -483,3 +483,57 @@ def test_far_origin_ray_batch_on_the_broom_stand_in(tr, port):
         m = hit == 1
         assert bit_equal(np.asarray(ctx.trace_any(O[m], pos[m][::-1].copy())).astype(np.uint8), S.any_hit(O[m], pos[m][::-1].copy()))
     S.close()
+
+
+def test_flat_scan_of_tiny_scenes_is_the_tree_walk(tr, port, monkeypatch):
+    """Scenes of at most 24 leaves (the Cornell box: 16 quads) are not walked as a tree: every lane tests its ray against every
+    leaf box -- kernel arguments, scalar loads -- and then against the leaves behind the boxes it hit (device_shade.h:
+    k_trace_flat).  TUTU_FLAT=0 walks the tree as before.  Golden rays of the reference build, 300 k random + 60 k degenerate
+    rays and shadow segments against the unpruned recursion, and a frame: the same bits either way."""
+    from tuturenderer_amd import scenes
+
+    frames = {}
+    for tag, env in (("flat", {}), ("tree", {"TUTU_FLAT": "0"})):
+        monkeypatch.delenv("TUTU_FLAT", raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        for name in ("cornell", "cornell_ggxT_mirror", "cornell_degenerate"):
+            sc, _ = _scene(name)
+            z = np.load(golden_path(f"scene_{name}.npz"))
+            S = port.scene(sc)
+            O, D = pc.scene_rays(S)
+            with tr.Context(sc) as ctx:
+                assert ctx.get_option("lds_scene") == 1
+                if name != "cornell_degenerate":  # (that scene's extra slivers make more than 24 leaves: it keeps the tree walk)
+                    assert (ctx.get_option("flat_leaves") > 0) == (tag == "flat"), (name, ctx.get_option("flat_leaves"))
+                hits = ctx.trace_closest(O, D)
+                h = hits["tri"] >= 0
+                assert bit_equal(hits["tri"], z["scene.tri"]), (tag, name)
+                assert bit_equal(np.where(h, hits["t"], 0).astype(np.float32), z["scene.t"]), (tag, name)
+                if name == "cornell":
+                    r = pc._rng(4242)
+                    V = S.verts.reshape(-1, 3)
+                    lo, hi = V.min(0), V.max(0)
+                    n, m = 300_000, 60_000
+                    o = (lo + (hi - lo) * r.random((n + m, 3))).astype(np.float32)
+                    d = pc.unit(r, n + m)
+                    kind = r.integers(0, 3, m)
+                    axis = r.integers(0, 3, m)
+                    for k in range(3):
+                        d[n:][(kind == 0) & (axis == k), k] = 0.0     # zero components: not plain, the exact walk
+                    snap = (kind == 1)[:, None] & (r.random((m, 3)) < 0.5)  # origins ON box planes
+                    o[n:] = np.where(snap, V[r.integers(0, len(V), (m, 3)), np.arange(3)], o[n:]).astype(np.float32)
+                    hit, t, tri, pos, _, _ = S.closest(o, d)
+                    g = ctx.trace_closest(o, d)
+                    assert count_diff(g["tri"], np.where(hit == 1, tri, -1)) == 0, tag
+                    assert count_diff(np.where(tri >= 0, g["t"], 0), np.where(tri >= 0, t, 0)) == 0, tag
+                    a = (lo + (hi - lo) * r.random((100_000, 3))).astype(np.float32)
+                    b = (lo + (hi - lo) * r.random((100_000, 3))).astype(np.float32)
+                    assert bit_equal(np.asarray(ctx.trace_any(a, b)).astype(np.uint8), S.any_hit(a, b)), tag
+            S.close()
+        with tr.Context(scenes.cornell_box(160, 160)) as ctx:
+            frames[tag] = ctx.render(48, 0x5EED0001, 2)
+            st = dict(ctx.last_stats)
+        print(f"\n[{tag}] boxes / nodes entered per closest-hit ray {(st['nodes_closest'] + st['leaves_closest']) / max(st['closest_rays'] - 160 * 160, 1):.1f}, "
+              f"leaf tests {st['leaves_closest'] / max(st['closest_rays'] - 160 * 160, 1):.2f}")
+    assert frames["flat"].tobytes() == frames["tree"].tobytes()

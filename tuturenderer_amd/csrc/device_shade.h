@@ -1203,6 +1203,198 @@ TUTU_DEV void trace_persistent(const S& ss, const TraceParams& tp, int* stack, c
 	}
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// Tiny scenes: the FLAT scan (round 4).  A ray through the Cornell box visits 7.5 inner nodes of the walked tree -- 15 box
+// tests -- to reach 2-3 of its 16 leaves (the quads), at 61 % of a wave's lanes, with a stack, rounds, parked leaves and
+// refills around it.  Sixteen box tests in a row cost no more than those fifteen, need none of that, and run on ALL lanes:
+//   phase 1   every lane tests its ray against every leaf box of the walked tree (FlatScene: kernel arguments, read by
+//             scalar loads -- the boxes are wave-uniform) and keeps a bit per box hit
+//   phase 2   while any lane has a bit left: the lane's next leaf -- one object, or the two triangles of a quad -- is tested
+//             with the reference's triangle test; a candidate is validated against the reference's leaf box (device_trace.h)
+// No distance pruning at all on the closest-hit side (the minimum over every candidate whose boxes are hit: the
+// reference's recursion, BVH.hpp:145-167, for a plain ray -- boxes that contain a leaf box are hit whenever it is);
+// shadow rays keep the limit dis * (1 + 1e-4) on the box test, as in the tree walk.  One ray per lane and iteration: every
+// wave owns a contiguous range of the list; rays that are not plain go to the exact walk after the loop (as in
+// trace_persistent).  Counters: a "node entered" is a box tested, a node step one box test of the wave.
+template <bool ANY, bool SPH>
+__global__ void __launch_bounds__(256, 8) k_trace_flat(TraceParams tp, FlatScene fs) {
+	extern __shared__ int lds[];  // [stack entries of the exact walk][256 lanes] | scene copy | class table
+	const SceneLds ss = stage_scene_lds(tp.sc, lds, tp.stack_entries);
+	uint8_t* cls = reinterpret_cast<uint8_t*>(ss.end());
+	__shared__ int s_ref[TUTU_FLAT_MAX];
+	for (int k = 0; k < fs.n; k++)
+		if ((int)threadIdx.x == k) s_ref[k] = __float_as_int(fs.box[k][3]);
+	if (!ANY)
+		for (int i = threadIdx.x; i < tp.sc.n_tris; i += blockDim.x) cls[i] = tp.tri_class[i];
+	__syncthreads();
+	const SceneDev& sc = tp.sc;
+	const int lane = __lane_id();
+	const unsigned long long lt_mask = (1ull << lane) - 1ull;
+	const uint32_t n = *tp.n_ptr;
+	const uint32_t n_waves = (gridDim.x * blockDim.x) >> 6;
+	const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+	const uint32_t per = (n + n_waves - 1) / n_waves;
+	const uint32_t begin = min(n, wave * per), end = min(n, begin + per);
+	const float inf = __builtin_inff();
+	uint32_t n_nodes = 0, n_leaves = 0, w_node_steps = 0, w_leaf_steps = 0, n_def = 0;
+	for (uint32_t i0 = begin; i0 < end; i0 += 64u) {
+		const uint32_t i = i0 + (uint32_t)lane;
+		const bool act = i < end;
+		uint32_t slot = 0, fl = 0, mask = 0;
+		RayPre r = make_ray(mk1(0.f), mk1(1.f));
+		float best_t = FLT_MAX, best_u = 0.f, best_v = 0.f, dis = 0.f, lim = inf;
+		int best_tri = -1;
+		float4 Lpre = make_float4(0.f, 0.f, 0.f, 0.f);
+		V3 contrib = mk1(0.f);
+		bool blocked = false, exact = false;
+		if (act) {
+			slot = tp.list[i];
+			if (!ANY) {
+				const float4 A = tp.rec.A[slot], B = tp.rec.B[slot];
+				slot = i;
+				r = make_ray(mk(A.x, A.y, A.z), mk(B.x, B.y, B.z));
+			} else {
+				fl = tp.rec.key[slot];
+				const float4 e0 = (fl & TUTU_KEY_ALT) ? tp.rec.S2[slot] : tp.rec.A[slot];
+				const float4 e1 = tp.rec.S[slot];
+				if (fl & TUTU_KEY_FINAL) {  // nobody else touches this path's record any more
+					Lpre = tp.rec.L[slot];
+					const float4 e2 = tp.rec.P[slot];
+					contrib = mk(e2.x, e2.y, e2.z);
+				}
+				const V3 so = mk(e0.x, e0.y, e0.z), lo = mk(e1.x, e1.y, e1.z);
+				const V3 raydir = normalized(lo - so);  // isShadowRayBlocked, IIntegrator.hpp:135-137
+				dis = norm(lo - so);
+				r = make_ray(so, raydir);
+				lim = dis * TUTU_PRUNE_SLACK;
+			}
+			exact = sc.exact || !ray_is_plain(r);
+			if (exact && ANY) blocked = true;  // (its verdict comes from the exact walk below)
+		}
+		const unsigned long long em = __ballot(exact);
+		if (em != 0ull) {
+			if (exact) tp.defer[begin + n_def + (uint32_t)__popcll(em & lt_mask)] = i;
+			n_def += (uint32_t)__popcll(em);
+		}
+		// ---- phase 1: every leaf box of the walked tree
+		const bool scan = act && !exact;
+		// (a rolled loop over a wave-uniform index: the box of leaf k arrives by one scalar load while the boxes before it are
+		// tested; fully unrolled, the compiler loads all of them first and spills the scalar registers they do not fit into)
+#pragma unroll 4
+		for (int k = 0; k < fs.n; k++) {
+			float te;
+			const bool h = slab_plain(r, fs.box[k][0], fs.box[k][1], fs.box[k][2], fs.box[k][4], fs.box[k][5], fs.box[k][6], lim, te);
+			mask |= (h && scan) ? (1u << k) : 0u;
+		}
+		n_nodes += scan ? (uint32_t)fs.n : 0u;
+		w_node_steps += (uint32_t)fs.n;
+		// ---- phase 2: the leaves behind the boxes that were hit
+		while (__ballot(mask != 0u) != 0ull) {
+			w_leaf_steps++;
+			if (mask != 0u) {
+				const int k = __ffs((int)mask) - 1;
+				mask &= mask - 1u;
+				int item = ~s_ref[k], second = 0;
+				if (!SPH && sc.pair_leaves) {
+					second = item >> TUTU_PAIR_BITS;
+					item &= (1 << TUTU_PAIR_BITS) - 1;
+				}
+				for (;;) {
+					n_leaves++;
+					int ti;
+					float t, u, v;
+					const bool h = leaf_test<SPH>(ss, item, r, ti, t, u, v);
+					bool cand;
+					if (ANY) cand = h && t < dis && !float_equal(t, dis);  // BVH.hpp:186
+					else cand = h && (t < best_t || (t == best_t && ti < best_tri));
+					if (cand) {  // validated against the reference's leaf box (BVH.hpp:150; device_trace.h)
+						float4 lo, hi;
+						ss.lbox(ti, lo, hi);
+						float te;
+						if (slab_plain(r, lo.x, lo.y, lo.z, hi.x, hi.y, hi.z, inf, te)) {
+							if (ANY) blocked = true;
+							else {
+								best_t = t; best_u = u; best_v = v; best_tri = ti;
+							}
+						}
+					}
+					if (second == 0 || (ANY && blocked)) break;
+					item = second - 1;
+					second = 0;
+				}
+				if (ANY && blocked) mask = 0u;
+			}
+		}
+		// ---- finish
+		if (act) {
+			if (!ANY) {
+				tp.hitC[slot] = make_float4(best_t, best_u, best_v, __int_as_float(best_tri));
+				tp.hitK[slot] = best_tri >= 0 ? cls[best_tri] : (uint8_t)TUTU_CLASS_MISS;
+			} else if (fl & TUTU_KEY_FINAL) {  // the path ended with this request: its sample is finished
+				float4 F = make_float4(Lpre.x, Lpre.y, Lpre.z, 0.f);
+				if (!blocked) {
+					F.x = F.x + contrib.x; F.y = F.y + contrib.y; F.z = F.z + contrib.z;
+				}
+				tp.F[__float_as_uint(Lpre.w)] = F;
+			} else if (!blocked) {
+				// KILL: the hit of the (speculative) extension ray is void; else shade(depth + 1) adds the contribution
+				tp.rec.V[slot] = (uint8_t)((fl & TUTU_KEY_KILL) ? TUTU_V_KILLED : TUTU_V_ADD);
+			}
+		}
+	}
+	// ---- the rays that are not plain (or all of them: knob "exact"): the reference's tree, the reference's slab, no pruning
+	if (n_def != 0u) {
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+		int* xstack = lds + threadIdx.x;
+		for (uint32_t j = (uint32_t)lane; j < n_def; j += 64u) {
+			const uint32_t i = tp.defer[begin + j];
+			const uint32_t s = tp.list[i];
+			if (!ANY) {
+				const float4 A = tp.rec.A[s], B = tp.rec.B[s];
+				float t, u, v;
+				int tri;
+				trace_closest(ss, sc, mk(A.x, A.y, A.z), mk(B.x, B.y, B.z), xstack, 256, t, u, v, tri, true);
+				tp.hitC[i] = make_float4(t, u, v, __int_as_float(tri));
+				tp.hitK[i] = tri >= 0 ? cls[tri] : (uint8_t)TUTU_CLASS_MISS;
+			} else {
+				const uint32_t f = tp.rec.key[s];
+				const float4 e0 = (f & TUTU_KEY_ALT) ? tp.rec.S2[s] : tp.rec.A[s];
+				const float4 e1 = tp.rec.S[s];
+				const bool blk = trace_any(ss, sc, mk(e0.x, e0.y, e0.z), mk(e1.x, e1.y, e1.z), xstack, 256, true);
+				if (f & TUTU_KEY_FINAL) {
+					const float4 Lp = tp.rec.L[s], e2 = tp.rec.P[s];
+					float4 F = make_float4(Lp.x, Lp.y, Lp.z, 0.f);
+					if (!blk) {
+						F.x = F.x + e2.x; F.y = F.y + e2.y; F.z = F.z + e2.z;
+					}
+					tp.F[__float_as_uint(Lp.w)] = F;
+				} else if (!blk) {
+					tp.rec.V[s] = (uint8_t)((f & TUTU_KEY_KILL) ? TUTU_V_KILLED : TUTU_V_ADD);
+				}
+			}
+		}
+	}
+	if (tp.part) {
+		unsigned long long a = n_nodes, b = n_leaves;
+		for (int off = 32; off > 0; off >>= 1) {
+			a += __shfl_xor(a, off);
+			b += __shfl_xor(b, off);
+		}
+		__shared__ unsigned long long acc[4];
+		if (threadIdx.x < 4) acc[threadIdx.x] = 0ull;
+		__syncthreads();
+		if (lane == 0) {
+			atomicAdd(&acc[0], a);
+			atomicAdd(&acc[1], b);
+			atomicAdd(&acc[2], (unsigned long long)w_node_steps);
+			atomicAdd(&acc[3], (unsigned long long)w_leaf_steps);
+		}
+		__syncthreads();
+		if (threadIdx.x < 4) tp.part[4 * blockIdx.x + threadIdx.x] += acc[threadIdx.x];
+	}
+}
+
 // LDS carve-up with the per-triangle class table appended to the staged scene
 // SPH: the scene has sphere leaves (the triangle-only instantiations do not contain the sphere test)
 // DEEP: the stack has a second tier in HBM (memory-resident scenes with deep trees)

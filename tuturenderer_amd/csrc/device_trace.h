@@ -79,6 +79,15 @@ struct SceneDev {
 	int exact;
 };
 
+// Tiny scenes (at most TUTU_FLAT_MAX leaves in the walked tree -- the Cornell box: 16, its quads): the leaf boxes of the walked
+// tree as a FLAT list, passed to the traversal kernel BY VALUE (kernel arguments: the slab tests read them through scalar
+// loads, no LDS, no vector memory).  device_shade.h: k_trace_flat.
+#define TUTU_FLAT_MAX 24
+struct FlatScene {
+	float box[TUTU_FLAT_MAX][8];  // min xyz | the leaf reference (int bits: ~object, ~(a | (b + 1) << TUTU_PAIR_BITS), sphere bit), max xyz | -
+	int n;                        //   (32 B per leaf: one s_load_dwordx8)
+};
+
 struct SceneGlobal {
 	const float4* nodes;
 	const float4* tris;

@@ -648,6 +648,21 @@ static bool build_wide(const std::vector<BuildNode>& t, const LeafRef& leaf_ref,
 
 }  // namespace
 
+// independent iterations [0, n) on several host threads (large scenes only; the same results as one thread: every
+// iteration writes its own elements)
+template <typename F>
+static void parallel_ranges(size_t n, const F& body) {
+	const uint32_t n_thr = (n >= 65536 && !getenv("TUTU_BUILD_SERIAL")) ? std::min<uint32_t>(16, std::max<uint32_t>(1, std::thread::hardware_concurrency())) : 1;
+	if (n_thr <= 1) {
+		body((size_t)0, n);
+		return;
+	}
+	std::vector<std::thread> pool;
+	for (uint32_t t = 1; t < n_thr; t++) pool.emplace_back([&body, n, t, n_thr] { body(n * t / n_thr, n * (t + 1) / n_thr); });
+	body((size_t)0, n / n_thr);
+	for (std::thread& th : pool) th.join();
+}
+
 int build_host_scene(const TutuSceneDesc* d, HostScene& hs, HostBuildHooks* hooks) {
 	if (!d) return TUTU_E_INVALID;
 	// TUTU_BUILD_TIMING: the phases of the host build on stderr
@@ -710,8 +725,10 @@ int build_host_scene(const TutuSceneDesc* d, HostScene& hs, HostBuildHooks* hook
 	std::vector<BuildNode> tree;
 	int rc;
 	std::vector<Box> tb(n);
-	for (uint32_t o = 0; o < n; o++)
-		tb[o] = obj_sph[o] >= 0 ? sphere_box(ss->spheres + 4 * (size_t)obj_sph[o]) : triangle_box(d->verts + 9 * (size_t)obj_tri[o]);
+	parallel_ranges(n, [&](size_t o0, size_t o1) {
+		for (size_t o = o0; o < o1; o++)
+			tb[o] = obj_sph[o] >= 0 ? sphere_box(ss->spheres + 4 * (size_t)obj_sph[o]) : triangle_box(d->verts + 9 * (size_t)obj_tri[o]);
+	});
 	lap("objects, boxes, materials");
 	// Large scenes: the walked tree is left to the device (device_build.h), which needs the boxes and the scene box only
 	hs.device_walked = false;
@@ -866,19 +883,21 @@ int build_host_scene(const TutuSceneDesc* d, HostScene& hs, HostBuildHooks* hook
 			const int32_t leaf = hs.leaf_of_orig[t[bn].tri];
 			return obj_sph[t[bn].tri] >= 0 ? ~(leaf | kSphereBit) : ~leaf;  // device_trace.h: TUTU_SPHERE_BIT
 		};
-		for (size_t i = 0; i < t.size(); i++) {
-			if (inner_id[i] < 0) continue;
-			GpuNode& g = hs.nodes[inner_id[i]];
-			const BuildNode& l = t[t[i].left];
-			const BuildNode& r = t[t[i].right];
-			memcpy(g.lmin, l.pmin, 12);
-			memcpy(g.lmax, l.pmax, 12);
-			memcpy(g.rmin, r.pmin, 12);
-			memcpy(g.rmax, r.pmax, 12);
-			g.left = ref_of(t[i].left);
-			g.right = ref_of(t[i].right);
-			g.pad0 = g.pad1 = 0;
-		}
+		parallel_ranges(t.size(), [&](size_t i0, size_t i1) {
+			for (size_t i = i0; i < i1; i++) {
+				if (inner_id[i] < 0) continue;
+				GpuNode& g = hs.nodes[inner_id[i]];
+				const BuildNode& l = t[t[i].left];
+				const BuildNode& r = t[t[i].right];
+				memcpy(g.lmin, l.pmin, 12);
+				memcpy(g.lmax, l.pmax, 12);
+				memcpy(g.rmin, r.pmin, 12);
+				memcpy(g.rmax, r.pmax, 12);
+				g.left = ref_of(t[i].left);
+				g.right = ref_of(t[i].right);
+				g.pad0 = g.pad1 = 0;
+			}
+		});
 		return ref_of(0);
 	};
 	hs.nodes.clear();
@@ -927,10 +946,12 @@ int build_host_scene(const TutuSceneDesc* d, HostScene& hs, HostBuildHooks* hook
 	}
 	// the reference's leaf boxes, in leaf order: what a candidate hit is validated against when the fast tree is walked
 	hs.leaf_boxes.assign((size_t)n * 8, 0.f);
-	for (uint32_t li = 0; li < n; li++) {
-		memcpy(&hs.leaf_boxes[(size_t)li * 8], tb[order[li]].mn, 12);
-		memcpy(&hs.leaf_boxes[(size_t)li * 8 + 4], tb[order[li]].mx, 12);
-	}
+	parallel_ranges(n, [&](size_t l0, size_t l1) {
+		for (size_t li = l0; li < l1; li++) {
+			memcpy(&hs.leaf_boxes[(size_t)li * 8], tb[order[li]].mn, 12);
+			memcpy(&hs.leaf_boxes[(size_t)li * 8 + 4], tb[order[li]].mx, 12);
+		}
+	});
 
 	// lights: PPMGenerator::initializeLights order = object-list order (PPMGenerator.hpp:317-324)
 	std::vector<int32_t> light_orig;
@@ -943,7 +964,8 @@ int build_host_scene(const TutuSceneDesc* d, HostScene& hs, HostBuildHooks* hook
 	hs.tri_shade.resize(n);
 	hs.tri_class.assign(n, 0);
 	std::vector<float> area(n, 0.f);
-	for (uint32_t li = 0; li < n; li++) {
+	parallel_ranges(n, [&](size_t l0, size_t l1) {
+	for (size_t li = l0; li < l1; li++) {
 		const int32_t o = order[li];
 		if (obj_sph[o] >= 0) {
 			// sphere leaf: centre | radius | radius*radius in the intersection record, centre | radius in the shading record
@@ -996,6 +1018,7 @@ int build_host_scene(const TutuSceneDesc* d, HostScene& hs, HostBuildHooks* hook
 			s.cls = cls;
 		}
 	}
+	});
 	// textures: the per-triangle data PPMGenerator::loadObj stores (PPMGenerator.hpp:182-201) and the map lists
 	hs.tri_tex.clear();
 	hs.texels.clear();

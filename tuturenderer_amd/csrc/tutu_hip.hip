@@ -98,6 +98,7 @@ struct TutuCtx {
 	bool wide_early = false;                // wide tree: leaf box fetched with the triangle record (7 waves per SIMD)
 	unsigned ktrace_lds_bytes = TUTU_STACK_DEPTH * 256 * sizeof(int);
 	bool lds_scene = false;
+	FlatScene flat = {};     // flat.n > 0: the traversal stages run k_trace_flat (tiny scenes)
 	uint32_t type_mask = 0;  // MaterialType values present among the non-emissive materials
 	int shade_tab = 0;       // 0: shade tables in HBM, 1: materials+lights in LDS, 2: + per-triangle shading records
 	unsigned shade_lds_bytes = 0;
@@ -135,6 +136,7 @@ struct TutuCtx {
 		int util_stats = 0;       // TUTU_UTIL_STATS     phase counters of the traversal kernels  {0, 1}
 		int device_build = 1;     // TUTU_DEVICE_BUILD   the walked tree of a large scene is built on the device: 0 never, 1 from device_build_min objects on, 2 always  [0, 2]
 		int device_build_min_k = 384;  // TUTU_DEVICE_BUILD_MIN_K  ... "large" = at least this many thousand objects  [1, 1048576]
+		int flat = 1;             // TUTU_FLAT           tiny LDS-resident scenes (<= TUTU_FLAT_MAX leaves): the flat scan instead of the tree walk  {0, 1}
 		int exact = 0;            // TUTU_EXACT          every ray takes the exact walk: reference tree, reference slab, no pruning  {0, 1}
 		int cold_paths_mi = 12;   // TUTU_COLD_PATHS_MI  Mi path slots (all work sets together) a context's FIRST default-sized render allocates itself;
 		                          //                     the rest of the default 168 Mi arrives from a background thread (0 = allocate everything at once)  [0, 4096]
@@ -185,7 +187,7 @@ struct TutuCtx {
 	std::atomic<long long> idle_since_us{0};  // steady-clock time the last one ended
 	WorkSet retired[TUTU_MAX_SETS];       // the small cold-start sets after the switch: kept until destroy (a hipFree waits for the device)
 	hipStream_t extra_streams[TUTU_MAX_SETS - 1] = {};  // work set k > 0 runs on extra_streams[k - 1]
-	hipEvent_t ev_fork = nullptr;
+	hipEvent_t ev_fork = nullptr, ev_user = nullptr;
 	DevBuf<float4> prim_dir, prim_hit, accum;
 	DevBuf<Totals> totals;
 	DevBuf<int32_t> pixels;
@@ -239,6 +241,7 @@ const KnobDesc kKnobs[] = {
     {"util_stats", "TUTU_UTIL_STATS", &TutuCtx::Knobs::util_stats, 0, 1},
     {"bidir_units", "TUTU_BIDIR_UNITS", &TutuCtx::Knobs::bidir_units, 64, 1 << 24},
     {"exact", "TUTU_EXACT", &TutuCtx::Knobs::exact, 0, 1},
+    {"flat", "TUTU_FLAT", &TutuCtx::Knobs::flat, 0, 1, true},
     {"device_build", "TUTU_DEVICE_BUILD", &TutuCtx::Knobs::device_build, 0, 2, true},
     {"device_build_min_k", "TUTU_DEVICE_BUILD_MIN_K", &TutuCtx::Knobs::device_build_min_k, 1, 1 << 20, true},
     {"cold_paths_mi", "TUTU_COLD_PATHS_MI", &TutuCtx::Knobs::cold_paths_mi, 0, 4096},
@@ -462,6 +465,11 @@ void launch_trace(TutuCtx* c, hipStream_t s, int grid, const TraceParams& tp) {
 	}
 	const dim3 g((unsigned)grid), b(256);
 	const unsigned lds = c->ktrace_lds_bytes;
+	if (c->flat.n > 0) {  // tiny scene: the flat scan
+		if (c->has_spheres) k_trace_flat<ANY, true><<<g, b, lds, s>>>(tp, c->flat);
+		else k_trace_flat<ANY, false><<<g, b, lds, s>>>(tp, c->flat);
+		return;
+	}
 	if (c->has_spheres) {
 		if (c->lds_scene) k_trace<true, ANY, true, false, false><<<g, b, lds, s>>>(tp);
 		else k_trace<false, ANY, true, false, false><<<g, b, lds, s>>>(tp);
@@ -701,8 +709,13 @@ int collect_stats(TutuCtx* c, hipStream_t s, TutuStats* st, uint64_t samples, ui
 	return TUTU_OK;
 }
 
-int render_impl(TutuCtx* c, const TutuCameraFrame* cam, const TutuRenderParams* rp, float* d_out, hipStream_t s, TutuStats* st) {
+int render_impl(TutuCtx* c, const TutuCameraFrame* cam, const TutuRenderParams* rp, float* d_out, hipStream_t s_user, TutuStats* st) {
 	if (!c || !cam || !rp || !d_out) return TUTU_E_INVALID;
+	// The frame's kernels always run on the context's OWN four streams (created together: four hardware queues).  A stream of
+	// the caller's only orders the frame: the first kernel waits for what is enqueued on it now, and it waits for the frame's
+	// last kernel.  (Running a pass on the caller's stream itself cost 19 % of the Cornell frame with a torch stream: the
+	// runtime maps streams to a handful of hardware queues, and a fifth stream shares one with another pass's.)
+	hipStream_t s = c->stream;
 	if (rp->spp <= 0 || rp->spp > (1 << 24) || cam->width <= 0 || cam->height <= 0) return TUTU_E_INVALID;  // sample index: 24 bits of the record
 	int npix, x0 = 0, y0 = 0, rect_w = 1;
 	if (rp->pixels) {
@@ -719,6 +732,10 @@ int render_impl(TutuCtx* c, const TutuCameraFrame* cam, const TutuRenderParams* 
 		npix = rect_w * (rp->y1 - rp->y0);
 	}
 	HIP_TRY(hipSetDevice(c->device));
+	if (s_user && s_user != s) {
+		HIP_TRY(hipEventRecord(c->ev_user, s_user));
+		HIP_TRY(hipStreamWaitEvent(s, c->ev_user, 0));
+	}
 	c->want_stats = st != nullptr;
 	// Paths in flight: max_paths in total, split over the work sets whose passes run concurrently, one stream each
 	// (round 1, Cornell box, 512 spp: 2 sets x 8 Mi 1518 Msamples/s, 3 x 8 Mi 1619, 4 x 8 Mi 1645; 4 x 12 Mi 1753, 4 x 16 Mi
@@ -846,6 +863,10 @@ int render_impl(TutuCtx* c, const TutuCameraFrame* cam, const TutuRenderParams* 
 	}
 	const float spp_inv = 1.f / rp->spp;  // SPP_inv, global.hpp:20
 	TIMED(EV_OTHER, k_finalize<<<dim3((npix + 255) / 256), dim3(256), 0, s>>>(c->accum.p, d_out, npix, spp_inv));
+	if (s_user && s_user != s) {  // what the caller enqueues on its stream next sees the finished frame
+		HIP_TRY(hipEventRecord(c->ev_user, s));
+		HIP_TRY(hipStreamWaitEvent(s_user, c->ev_user, 0));
+	}
 	rc = collect_stats(c, s, st, (uint64_t)npix * (uint64_t)rp->spp, passes, trace_launches);
 	if (rc == TUTU_OK && st) {
 		st->spp_per_pass = (uint32_t)spp_pass;
@@ -1009,6 +1030,7 @@ int tutu_hip_create(const TutuSceneDesc* scene, int device, TutuCtx** out) {
 	for (int k = 0; k < TUTU_MAX_SETS - 1; k++)
 		if (hipStreamCreateWithFlags(&c->extra_streams[k], hipStreamNonBlocking) != hipSuccess) return fail(TUTU_E_HIP);
 	if (hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess) return fail(TUTU_E_HIP);
+	if (hipEventCreateWithFlags(&c->ev_user, hipEventDisableTiming) != hipSuccess) return fail(TUTU_E_HIP);
 	hipStream_t s = c->stream;
 	// Host build: the reference's tree, the leaf-order tables and -- for all but large scenes -- the walked tree.  A large
 	// scene's walked tree is built on the DEVICE meanwhile (device_build.h), on a thread of its own that drives the second stream.
@@ -1151,6 +1173,32 @@ int tutu_hip_create(const TutuSceneDesc* scene, int device, TutuCtx** out) {
 	                           ((c->hs.tri_class.size() + 15) / 16) * 16;  // + class table
 	c->lds_scene = scene_bytes > 0 && scene_bytes <= 24 * 1024;
 	c->trace_lds_bytes = (unsigned)(stack_bytes + (c->lds_scene ? scene_bytes : 0));
+	// Tiny scenes: the leaves of the walked tree as a flat list (device_shade.h: k_trace_flat).  Collected from the flattened
+	// nodes: every child reference that is a leaf, with the box its parent holds for it.
+	c->flat.n = 0;
+	if (c->lds_scene && c->knobs.flat && c->hs.root_ref != INT_MIN) {
+		std::vector<std::pair<const float*, int32_t>> leaves;  // (min xyz, max xyz at +3) , reference
+		bool ok = true;
+		if (c->hs.root_ref < 0) {
+			ok = false;  // a scene of one object: the tree walk's special case serves it
+		} else {
+			for (int32_t i = 0; i < c->hs.n_fast_inner && ok; i++) {
+				const GpuNode& g = c->hs.nodes[(size_t)i];
+				if (g.left < 0) leaves.push_back({g.lmin, g.left});
+				if (g.right < 0) leaves.push_back({g.rmin, g.right});
+				ok = leaves.size() <= (size_t)TUTU_FLAT_MAX;
+			}
+		}
+		if (ok && !leaves.empty()) {
+			for (size_t k = 0; k < leaves.size(); k++) {
+				memcpy(&c->flat.box[k][0], leaves[k].first, 12);
+				memcpy(&c->flat.box[k][4], leaves[k].first + 3, 12);  // GpuNode: lmin[3], lmax[3] (rmin[3], rmax[3]) are adjacent
+				memcpy(&c->flat.box[k][3], &leaves[k].second, 4);
+				c->flat.box[k][7] = 0.f;
+			}
+			c->flat.n = (int)leaves.size();
+		}
+	}
 	// k_trace (persistent waves): 8 blocks per CU leave 20 KB of LDS per block.  A memory-resident scene whose worst-case
 	// stack is deeper keeps the first `ktrace_entries` entries in LDS and the rest in HBM (device_shade.h: DEEP) -- few rays
 	// ever reach them -- so that the tree's depth does not cost resident waves.  The reference's own tree (depth ceil(log2 n),
@@ -1219,6 +1267,7 @@ int tutu_hip_destroy(TutuCtx* c) {
 		release_set(c->retired[k]);
 	}
 	if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+	if (c->ev_user) (void)hipEventDestroy(c->ev_user);
 	for (int k = 0; k < TUTU_MAX_SETS - 1; k++)
 		if (c->extra_streams[k]) (void)hipStreamDestroy(c->extra_streams[k]);
 	c->prim_dir.release(); c->prim_hit.release(); c->accum.release();
@@ -1279,6 +1328,10 @@ int tutu_hip_get_option(TutuCtx* c, const char* name, int* value) {
 	}
 	if (strcmp(name, "wide_tree") == 0) {  // the persistent kernels walk the four-wide quantised tree
 		*value = c->sc.has_wide;
+		return TUTU_OK;
+	}
+	if (strcmp(name, "flat_leaves") == 0) {  // > 0: the traversal stages scan that many leaf boxes instead of walking a tree (k_trace_flat)
+		*value = c->flat.n;
 		return TUTU_OK;
 	}
 	if (strcmp(name, "device_built") == 0) {  // the walked tree was built on the device (device_build.h)
