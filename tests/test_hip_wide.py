@@ -230,6 +230,7 @@ def test_pair_leaves_do_not_change_a_frame(tr, monkeypatch):
     from tuturenderer_amd import scenes
 
     out = {}
+    monkeypatch.setenv("TUTU_FLAT", "0")  # (the tree WALK is what pair leaves shorten; with the flat scan the pairs are the boxes it tests)
     for tag, env in (("pairs", {}), ("single", {"TUTU_NO_PAIRS": "1"})):
         monkeypatch.delenv("TUTU_NO_PAIRS", raising=False)
         for k, v in env.items():
@@ -537,3 +538,26 @@ def test_flat_scan_of_tiny_scenes_is_the_tree_walk(tr, port, monkeypatch):
         print(f"\n[{tag}] boxes / nodes entered per closest-hit ray {(st['nodes_closest'] + st['leaves_closest']) / max(st['closest_rays'] - 160 * 160, 1):.1f}, "
               f"leaf tests {st['leaves_closest'] / max(st['closest_rays'] - 160 * 160, 1):.2f}")
     assert frames["flat"].tobytes() == frames["tree"].tobytes()
+
+
+def test_flat_scan_on_needles_is_the_unpruned_recursion(tr, port, monkeypatch):
+    """The flat scan prunes nothing on the closest-hit side, so unlike the tree walks it must return the unpruned recursion's
+    object and t bits on the adversarial geometry too: ten needle quads of aspect 1000 : 1 (20 triangles, unclipped: a scene of
+    at most 24 leaves) and 300 k rays that graze them at |cos| down to 1e-4, 100 k oblique.  (A version that skipped boxes where
+    the rounding-error bound of the reference's triangle test PROVES no nearer hit passed this test too; it was slower.)"""
+    monkeypatch.setenv("TUTU_SPLIT_MAX", "1")  # (clipped references would make more than 24 leaves: the tree walk)
+    sc = pc.needle_scene(n=10, seed=17)
+    S = port.scene(sc)
+    with tr.Context(sc) as ctx:
+        assert ctx.get_option("flat_leaves") > 0 and ctx.get_option("lds_scene") == 1
+        for name, (O, D) in {"grazing": pc.grazing_rays(sc, 300_000, seed=3), "oblique": pc.grazing_rays(sc, 100_000, seed=4, cmin=1e-2, cmax=1.0)}.items():
+            hit, t, tri, *_ = S.closest(O, D)
+            h = ctx.trace_closest(O, D)
+            want = np.where(hit == 1, tri, -1).astype(np.int32)
+            m = want >= 0
+            rel, kappa, inside = pc.hit_conditioning(sc, O[m], D[m], want[m], t[m])
+            print(f"\n[flat scan, needles, {name}] rays {len(O)}, hits {int(m.sum())}, of which the pruning hypothesis of the tree walks fails for "
+                  f"{int((~(inside & (rel <= 2.0 ** -8 * 0.999))).sum())}; differ from the reference: {int((h['tri'] != want).sum())}")
+            assert bit_equal(h["tri"], want), name
+            assert bit_equal(h["t"][m], t[m]), name
+    S.close()

@@ -8,6 +8,7 @@
 #include <array>
 #include <atomic>
 #include <climits>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
