@@ -169,7 +169,10 @@ def main():
     ctx = tr.Context(scene, device=local_rank)
     # steady state from the first frame: this context allocates its full-size work sets in its first render (the cold path --
     # small sets first, the rest from a background thread -- is what `drop_in` below measures on a context of its own)
-    ctx.set_option("cold_paths_mi", 0)
+    try:
+        ctx.set_option("cold_paths_mi", 0)
+    except tr.TutuError:  # an older build loaded through TUTU_HIP_LIB (profiles/ab.sh): it allocates everything at once anyway
+        pass
     fg = FrameGather(W, H, rank, world, dev, host_staging=(distributed and args.backend != "nccl"), self_loop=self_loop)
     mine = fg.mine
     if args.emulate_shard > 1:

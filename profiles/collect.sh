@@ -16,9 +16,16 @@ mkdir -p $O
 cd $R
 export TMPDIR=/tmp
 if [ "$STAGE" = "pmc" ]; then
-  timeout -k 10 900 python -m pytest tests -m gpu -q > $O/gpu_tests.log 2>&1; echo "tests rc=$?" | tee -a $O/gpu_tests.log
+  # PMC_CONFIGS="c4 c5" restricts the stage to those configs and skips the tests (a gpurun call is 20 minutes at most: two calls)
+  if [ -z "$PMC_CONFIGS" ]; then
+    timeout -k 10 900 python -m pytest tests -m gpu -q -s > $O/gpu_tests.log 2>&1; echo "tests rc=$?" | tee -a $O/gpu_tests.log
+  fi
   # <config> <spp> <spp per pass, as bench.py sizes it at the config's full spp: bench.py refuses counters of another pass size>
-  for a in "c2 256 64" "c3 128 32" "c4 116 29" "c5 256 64"; do set -- $a; bash profiles/run_pmc.sh $TAG $1 $2 $3 > $O/pmc_$1.log 2>&1; echo "pmc $1 rc=$?"; done
+  for a in "c2 256 64" "c3 128 32" "c4 116 29" "c5 256 64"; do
+    set -- $a
+    if [ -n "$PMC_CONFIGS" ] && ! echo " $PMC_CONFIGS " | grep -q " $1 "; then continue; fi
+    bash profiles/run_pmc.sh $TAG $1 $2 $3 > $O/pmc_$1.log 2>&1; echo "pmc $1 rc=$?"
+  done
 else
   # (the rocprofv3 runs sit in THIS stage so that their per-kernel averages and the bench lines' avg_launch_ms come from one box)
   (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $O/rocprof -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras > $O/bench_under_rocprof.log 2>&1); echo "rocprof rc=$?"

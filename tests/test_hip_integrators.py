@@ -190,3 +190,34 @@ def test_larger_frame_batches_and_argument_checks(tr, port):
     rel = l2 / np.maximum(np.sqrt((want.astype(np.float64) ** 2).sum(-1)), 1.0)
     print(f"160x120x8 bdpt: pixels off by > 1e-3 relative {(rel > 1e-3).mean():.4f}, mean L2 of the rest {l2[rel <= 1e-3].mean():.3e}")
     assert (rel > 1e-3).mean() < 2e-2 and l2[rel <= 1e-3].mean() < 1e-3
+
+
+@pytest.mark.parametrize("name", CASES + ["spheres"])
+def test_bdpt_stages_are_the_unit_kernel_frame(tr, name, monkeypatch):
+    """tutu_hip_render_integrator renders BDPT as stages (round 4): k_bd_walks streams both random walks' vertices to memory,
+    k_bd_connect evaluates the strategies with four lanes per unit and files one shadow request per strategy that could
+    contribute, the path tracer's any-hit traversal answers them, k_bd_finish adds what got through in the reference's loop order.
+    TUTU_BDPT_UNIT_KERNEL=1 selects the one-lane-per-unit kernel (what tutu_hip_integrator_samples runs, pinned against the
+    restatement above).  Same functions, same operands, same order of additions: the same frame, bit for bit, NaNs included,
+    whatever the batch size."""
+    from tuturenderer_amd import scenes
+
+    sc = scenes.cornell_spheres(64, 48) if name == "spheres" else integrator_cases()[name][0]()
+    monkeypatch.delenv("TUTU_BDPT_UNIT_KERNEL", raising=False)
+    with tr.Context(sc) as ctx:
+        a = ctx.render_integrator("bdpt", 6, pc.KEY0, 91)
+        ctx.set_option("bidir_units", 700)
+        a_small = ctx.render_integrator("bdpt", 6, pc.KEY0, 91)
+        assert ctx.last_stats["passes"] > 3
+    monkeypatch.setenv("TUTU_BDPT_UNIT_KERNEL", "1")
+    with tr.Context(sc) as ctx:
+        b = ctx.render_integrator("bdpt", 6, pc.KEY0, 91)
+    monkeypatch.delenv("TUTU_BDPT_UNIT_KERNEL", raising=False)
+    monkeypatch.setenv("TUTU_BDPT_LANE_WALKS", "1")  # the stages with the walks done by one lane per unit (k_bd_walks) instead of as queue stages
+    with tr.Context(sc) as ctx:
+        a_lane = ctx.render_integrator("bdpt", 6, pc.KEY0, 91)
+    monkeypatch.delenv("TUTU_BDPT_LANE_WALKS", raising=False)
+    assert bit_equal(a, a_lane), int((a.view(np.uint32) != a_lane.view(np.uint32)).any(-1).sum())
+    assert bit_equal(a, a_small)
+    assert bit_equal(a, b), (int((a.view(np.uint32) != b.view(np.uint32)).any(-1).sum()), a.shape)
+    assert np.nanmean(np.minimum(a, 10.0)) > 0.01

@@ -802,6 +802,38 @@ struct TraceParams {
 	uint32_t* defer;     // >= *n_ptr entries: list positions of the rays that are not plain, per wave range (below)
 };
 
+// The exact walk of ONE list position: the reference's own tree, the reference's own slab, no validation, no pruning
+// (device_trace.h: force_exact) -- used for the rays the persistent kernels set aside (not plain, or outside the wide tree's
+// region) and, with the knob "exact", for every ray (k_trace_exact).  xstack: this lane's column of the LDS stack.
+template <typename S, bool ANY>
+TUTU_DEV void exact_walk_entry(const S& ss, const TraceParams& tp, uint32_t i, int* xstack, const uint8_t* tri_class) {
+	const SceneDev& sc = tp.sc;
+	const uint32_t s = tp.list[i];
+	if (!ANY) {
+		const float4 A = tp.rec.A[s], B = tp.rec.B[s];
+		float t, u, v;
+		int tri;
+		trace_closest(ss, sc, mk(A.x, A.y, A.z), mk(B.x, B.y, B.z), xstack, 256, t, u, v, tri, true);
+		tp.hitC[i] = make_float4(t, u, v, __int_as_float(tri));
+		tp.hitK[i] = tri >= 0 ? tri_class[tri] : (uint8_t)TUTU_CLASS_MISS;
+	} else {
+		const uint32_t f = tp.rec.key[s];
+		const float4 e0 = (f & TUTU_KEY_ALT) ? tp.rec.S2[s] : tp.rec.A[s];
+		const float4 e1 = tp.rec.S[s];
+		const bool blk = trace_any(ss, sc, mk(e0.x, e0.y, e0.z), mk(e1.x, e1.y, e1.z), xstack, 256, true);
+		if (f & TUTU_KEY_FINAL) {
+			const float4 Lp = tp.rec.L[s], e2 = tp.rec.P[s];
+			float4 F = make_float4(Lp.x, Lp.y, Lp.z, 0.f);
+			if (!blk) {
+				F.x = F.x + e2.x; F.y = F.y + e2.y; F.z = F.z + e2.z;
+			}
+			tp.F[__float_as_uint(Lp.w)] = F;
+		} else if (!blk) {
+			tp.rec.V[s] = (uint8_t)((f & TUTU_KEY_KILL) ? TUTU_V_KILLED : TUTU_V_ADD);
+		}
+	}
+}
+
 // leaf references are negative and above the two markers: (unsigned)ref > 0x80000001
 TUTU_DEV bool ref_is_leaf(int ref) { return (uint32_t)ref > (uint32_t)TUTU_TRAV_IDLE; }
 
@@ -915,7 +947,7 @@ TUTU_DEV void trace_persistent(const S& ss, const TraceParams& tp, int* stack, c
 				pend = TUTU_TRAV_IDLE;
 				cur = TUTU_TRAV_DONE;
 				if (sc.root_ref != INT_MIN) {
-					if (sc.exact || !ray_is_plain(r) || (WIDE && !ray_fits_wide(sc, r))) {
+					if (!ray_is_plain(r) || (WIDE && !ray_fits_wide(sc, r))) {
 						// the reference's own tree with the reference's own slab: after the main loop.  The lane stays DONE for
 						// this round and goes idle in its finish step (its write there -- a miss, or nothing for a shadow ray marked
 						// blocked -- is replaced by the exact walk's): if it went idle at once, a refill that serves nothing but
@@ -1152,33 +1184,7 @@ TUTU_DEV void trace_persistent(const S& ss, const TraceParams& tp, int* stack, c
 		// force_exact: these rays walk the REFERENCE's tree whatever they are (a plain ray with an origin outside the wide
 		// tree's region would otherwise pick the SAH tree, which is fast_depth deep and need not fit the LDS tier), unpruned.
 		int* xstack = stack;  // (the reference's tree always fits the LDS tier: host, tutu_hip_create)
-		for (uint32_t j = (uint32_t)lane; j < n_def; j += 64u) {
-			const uint32_t i = tp.defer[begin + j];
-			const uint32_t s = tp.list[i];
-			if (!ANY) {
-				const float4 A = tp.rec.A[s], B = tp.rec.B[s];
-				float t, u, v;
-				int tri;
-				trace_closest(ss, sc, mk(A.x, A.y, A.z), mk(B.x, B.y, B.z), xstack, 256, t, u, v, tri, true);
-				tp.hitC[i] = make_float4(t, u, v, __int_as_float(tri));
-				tp.hitK[i] = tri >= 0 ? tri_class[tri] : (uint8_t)TUTU_CLASS_MISS;
-			} else {
-				const uint32_t f = tp.rec.key[s];
-				const float4 e0 = (f & TUTU_KEY_ALT) ? tp.rec.S2[s] : tp.rec.A[s];
-				const float4 e1 = tp.rec.S[s];
-				const bool blk = trace_any(ss, sc, mk(e0.x, e0.y, e0.z), mk(e1.x, e1.y, e1.z), xstack, 256, true);
-				if (f & TUTU_KEY_FINAL) {
-					const float4 Lp = tp.rec.L[s], e2 = tp.rec.P[s];
-					float4 F = make_float4(Lp.x, Lp.y, Lp.z, 0.f);
-					if (!blk) {
-						F.x = F.x + e2.x; F.y = F.y + e2.y; F.z = F.z + e2.z;
-					}
-					tp.F[__float_as_uint(Lp.w)] = F;
-				} else if (!blk) {
-					tp.rec.V[s] = (uint8_t)((f & TUTU_KEY_KILL) ? TUTU_V_KILLED : TUTU_V_ADD);
-				}
-			}
-		}
+		for (uint32_t j = (uint32_t)lane; j < n_def; j += 64u) exact_walk_entry<S, ANY>(ss, tp, tp.defer[begin + j], xstack, tri_class);
 	}
 	// work counters: wave sum, then one plain add per block into this block's own slots (no global atomics: a counter word
 	// shared by all waves sustains ~88 atomics/us and would cost more than the traversal).  [0] nodes entered, [1] leaf
@@ -1272,7 +1278,7 @@ __global__ void __launch_bounds__(256, 8) k_trace_flat(TraceParams tp, FlatScene
 				r = make_ray(so, raydir);
 				lim = dis * TUTU_PRUNE_SLACK;
 			}
-			exact = sc.exact || !ray_is_plain(r);
+			exact = !ray_is_plain(r);
 			if (exact && ANY) blocked = true;  // (its verdict comes from the exact walk below)
 		}
 		const unsigned long long em = __ballot(exact);
@@ -1356,33 +1362,7 @@ __global__ void __launch_bounds__(256, 8) k_trace_flat(TraceParams tp, FlatScene
 		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
 		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 		int* xstack = lds + threadIdx.x;
-		for (uint32_t j = (uint32_t)lane; j < n_def; j += 64u) {
-			const uint32_t i = tp.defer[begin + j];
-			const uint32_t s = tp.list[i];
-			if (!ANY) {
-				const float4 A = tp.rec.A[s], B = tp.rec.B[s];
-				float t, u, v;
-				int tri;
-				trace_closest(ss, sc, mk(A.x, A.y, A.z), mk(B.x, B.y, B.z), xstack, 256, t, u, v, tri, true);
-				tp.hitC[i] = make_float4(t, u, v, __int_as_float(tri));
-				tp.hitK[i] = tri >= 0 ? cls[tri] : (uint8_t)TUTU_CLASS_MISS;
-			} else {
-				const uint32_t f = tp.rec.key[s];
-				const float4 e0 = (f & TUTU_KEY_ALT) ? tp.rec.S2[s] : tp.rec.A[s];
-				const float4 e1 = tp.rec.S[s];
-				const bool blk = trace_any(ss, sc, mk(e0.x, e0.y, e0.z), mk(e1.x, e1.y, e1.z), xstack, 256, true);
-				if (f & TUTU_KEY_FINAL) {
-					const float4 Lp = tp.rec.L[s], e2 = tp.rec.P[s];
-					float4 F = make_float4(Lp.x, Lp.y, Lp.z, 0.f);
-					if (!blk) {
-						F.x = F.x + e2.x; F.y = F.y + e2.y; F.z = F.z + e2.z;
-					}
-					tp.F[__float_as_uint(Lp.w)] = F;
-				} else if (!blk) {
-					tp.rec.V[s] = (uint8_t)((f & TUTU_KEY_KILL) ? TUTU_V_KILLED : TUTU_V_ADD);
-				}
-			}
-		}
+		for (uint32_t j = (uint32_t)lane; j < n_def; j += 64u) exact_walk_entry<SceneLds, ANY>(ss, tp, tp.defer[begin + j], xstack, cls);
 	}
 	if (tp.part) {
 		unsigned long long a = n_nodes, b = n_leaves;
@@ -1401,6 +1381,24 @@ __global__ void __launch_bounds__(256, 8) k_trace_flat(TraceParams tp, FlatScene
 		}
 		__syncthreads();
 		if (threadIdx.x < 4) tp.part[4 * blockIdx.x + threadIdx.x] += acc[threadIdx.x];
+	}
+}
+
+// Knob "exact" (TUTU_EXACT): every ray of a traversal stage takes the exact walk -- one ray per lane, no refill, no rounds; the
+// strict form is not a fast one.  LDS: [stack entries][256 lanes] (+ the scene copy of an LDS scene).
+template <bool LDS_SCENE, bool ANY>
+__global__ void __launch_bounds__(256) k_trace_exact(TraceParams tp) {
+	extern __shared__ int lds[];
+	const uint32_t n = *tp.n_ptr;
+	if (LDS_SCENE) {
+		const SceneLds sl = stage_scene_lds(tp.sc, lds, tp.stack_entries);
+		for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) exact_walk_entry<SceneLds, ANY>(sl, tp, i, lds + threadIdx.x, tp.tri_class);
+	} else {
+		SceneGlobal sg;
+		sg.nodes = tp.sc.nodes;
+		sg.tris = tp.sc.tri_isect;
+		sg.lboxes = tp.sc.leaf_boxes;
+		for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) exact_walk_entry<SceneGlobal, ANY>(sg, tp, i, lds + threadIdx.x, tp.tri_class);
 	}
 }
 

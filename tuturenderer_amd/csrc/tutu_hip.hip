@@ -203,6 +203,8 @@ struct TutuCtx {
 		DevBuf<uint32_t> idx, idx_sorted, last_set;
 		DevBuf<uint8_t> sort_tmp;
 		DevBuf<float> frame;
+		DevBuf<float4> verts, chain, hdr;  // BDPT as stages: the batch's path vertices (device_bidir.h: k_bd_*)
+		DevBuf<uint32_t> ev_count;         // ... and how many events its units left (written densely)
 		hipEvent_t t0 = nullptr, t1 = nullptr;
 	} bd;
 	std::vector<EvPair> ev_pool;
@@ -447,6 +449,12 @@ int ev_end(TutuCtx* c, hipStream_t s, size_t idx) {
 // the traversal kernel for this scene: BVH in LDS or HBM, closest- or any-hit, with or without sphere leaves
 template <bool ANY>
 void launch_trace(TutuCtx* c, hipStream_t s, int grid, const TraceParams& tp) {
+	if (c->sc.exact) {  // knob "exact": every ray takes the exact walk (device_shade.h: k_trace_exact)
+		const dim3 g(grid), b(256);
+		if (c->lds_scene) k_trace_exact<true, ANY><<<g, b, c->ktrace_lds_bytes, s>>>(tp);
+		else k_trace_exact<false, ANY><<<g, b, c->ktrace_lds_bytes, s>>>(tp);
+		return;
+	}
 	if (c->sc.has_wide) {  // memory-resident scene: the four-wide quantised tree, two-tier stack
 		dim3 g(grid), b(256);
 		if (c->wide_early) {
@@ -1276,6 +1284,7 @@ int tutu_hip_destroy(TutuCtx* c) {
 	c->out_stage.release(); c->gathered.release(); c->frame_stage.release(); c->gather_index.release();
 	c->bd.own.release(); c->bd.own_list.release(); c->bd.ev_val.release(); c->bd.ev_key.release(); c->bd.ev_key_sorted.release();
 	c->bd.idx.release(); c->bd.idx_sorted.release(); c->bd.sort_tmp.release(); c->bd.frame.release(); c->bd.last_set.release();
+	c->bd.verts.release(); c->bd.chain.release(); c->bd.hdr.release(); c->bd.ev_count.release();
 	if (c->bd.t0) (void)hipEventDestroy(c->bd.t0);
 	if (c->bd.t1) (void)hipEventDestroy(c->bd.t1);
 	if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -1636,6 +1645,9 @@ int bidir_params(TutuCtx* c, int type, const TutuCameraDesc* cam, int spp, uint3
 	p->smp_list = nullptr;
 	p->first_pix = 0;
 	p->own_list = nullptr;
+	p->bd_verts = p->bd_chain = p->bd_hdr = nullptr;
+	p->bd_stride = 0;
+	p->ev_count = nullptr;
 	return TUTU_OK;
 }
 
@@ -1710,6 +1722,93 @@ int lt_wavefront_batch(TutuCtx* c, hipStream_t s, BidirParams p) {
 	return TUTU_OK;
 }
 
+// BDPT as stages (device_bidir.h: k_bd_walks / k_bd_connect / any-hit traversal / k_bd_finish), one batch of units; leaves the
+// batch's own-pixel contributions in p.own / p.own_list and its events in p.ev_key / p.ev_val like k_bidir<3> does
+int bdpt_staged_batch(TutuCtx* c, hipStream_t s, BidirParams p) {
+	WorkSet& w = c->ws[0];
+	const uint32_t stride = (p.n_units + 255u) / 256u * 256u;
+	const uint32_t n_slots = stride * (uint32_t)TUTU_BD_STRATEGIES;  // slot = strategy * stride + unit
+	const uint32_t n_pad = (n_slots + TUTU_LIST_TILE - 1) / TUTU_LIST_TILE * TUTU_LIST_TILE;
+	int rc = ensure_set(w, n_pad);
+	if (rc != TUTU_OK) return rc;
+	if (c->ktrace_deep > 0 && (rc = w.gstack.ensure((size_t)c->ktrace_deep * TUTU_PART_BLOCKS * 256)) != TUTU_OK) return rc;
+	TutuCtx::Bidir& b = c->bd;
+	if ((rc = b.verts.ensure((size_t)2 * TUTU_BD_VERTS * TUTU_BD_FIELDS * stride)) != TUTU_OK) return rc;
+	if ((rc = b.chain.ensure((size_t)2 * TUTU_BD_VERTS * stride)) != TUTU_OK) return rc;
+	if ((rc = b.hdr.ensure((size_t)3 * stride)) != TUTU_OK) return rc;
+	c->ev_used = 0;
+	p.rec = records_of(w, 0);
+	p.n_pad = n_pad;
+	p.bd_verts = b.verts.p;
+	p.bd_chain = b.chain.p;
+	p.bd_hdr = b.hdr.p;
+	p.bd_stride = stride;
+	const dim3 blk(256), g_units((p.n_units + 255) / 256);
+	uint32_t* meta = w.list_meta.p;
+	TraceParams tp;
+	tp.sc = c->sc;
+	tp.rec = p.rec;
+	tp.hitC = w.hitC.p;
+	tp.hitK = w.hitK.p;
+	tp.F = w.F.p;
+	tp.tri_class = c->d_tri_class.p;
+	tp.stack_entries = c->ktrace_entries;
+	tp.gstack = w.gstack.p;
+	tp.refill_min = c->knobs.refill_min;
+	tp.any_near_first = c->knobs.any_near_first;
+	tp.leaf_again = c->knobs.leaf_again;
+	tp.xcd_map = 0;
+	tp.part = nullptr;
+	tp.defer = w.defer.p;
+	if (getenv("TUTU_BDPT_LANE_WALKS")) {  // the one-lane-per-unit walks (k_bd_walks): for A/B runs and tests
+		if (c->lds_scene) k_bd_walks<true><<<g_units, blk, c->trace_lds_bytes, s>>>(p);
+		else k_bd_walks<false><<<g_units, blk, c->trace_lds_bytes, s>>>(p);
+	} else {
+		// the walks as queue stages: a record per unit (slot = unit), the path tracer's list and closest-hit kernels
+		const uint32_t units_pad = (p.n_units + TUTU_LIST_TILE - 1) / TUTU_LIST_TILE * TUTU_LIST_TILE;
+		p.n_pad = units_pad;
+		p.list = w.lists.p;
+		p.n_list = meta;
+		p.hitC = w.hitC.p;
+		const int trace_grid = persistent_grid(p.n_units, c->n_cu, c->trace_blocks_per_cu);
+		auto extend = [&]() -> int {  // the rays of the walks that go on
+			int r = build_lists(c, w, s, p.rec.key, units_pad, nullptr, units_pad, meta, nullptr, nullptr);
+			if (r != TUTU_OK) return r;
+			tp.list = w.lists.p;
+			tp.n_ptr = meta + 0;
+			tp.inner_steps = c->sc.has_wide ? c->knobs.wide_inner_steps : c->knobs.inner_steps;
+			launch_trace<false>(c, s, trace_grid, tp);
+			return TUTU_OK;
+		};
+		k_bdw_eye_gen<<<dim3(units_pad / 256), blk, 0, s>>>(p);
+		for (int k = 0; k < TUTU_BIDIR_MAXLEN; k++) {  // eye vertices 1 .. 7
+			if ((rc = extend()) != TUTU_OK) return rc;
+			k_bdw_step<false><<<g_units, blk, 0, s>>>(p);
+		}
+		k_bdw_light_gen<<<g_units, blk, 0, s>>>(p);
+		for (int k = 0; k < TUTU_BIDIR_MAXLEN - 1; k++) {  // light vertices 1 .. 6
+			if ((rc = extend()) != TUTU_OK) return rc;
+			k_bdw_step<true><<<g_units, blk, 0, s>>>(p);
+		}
+		HIP_TRY(hipGetLastError());
+	}
+	p.n_pad = n_pad;  // (k_bd_connect writes the key and verdict byte of every request slot: no memset)
+	k_bd_connect<<<dim3(((stride / 256u + 7u) / 8u) * 64u), blk, 0, s>>>(p);  // 8 blocks (t = 1..8) per group of 256 units, groups of 8 groups
+	HIP_TRY(hipGetLastError());
+	if ((rc = build_lists(c, w, s, p.rec.key, n_pad, nullptr, n_slots, meta, nullptr, nullptr)) != TUTU_OK) return rc;  // (slots beyond n_slots are never read)
+	tp.list = w.lists.p + w.cap;  // the shadow requests
+	tp.n_ptr = meta + 1;
+	tp.inner_steps = c->sc.has_wide ? c->knobs.wide_inner_steps_any : c->knobs.inner_steps_any;
+	launch_trace<true>(c, s, persistent_grid(n_slots, c->n_cu, c->trace_blocks_per_cu), tp);
+	if ((rc = b.ev_count.ensure(1)) != TUTU_OK) return rc;
+	HIP_TRY(hipMemsetAsync(b.ev_count.p, 0, sizeof(uint32_t), s));
+	p.ev_count = getenv("TUTU_BDPT_SPARSE_EVENTS") ? nullptr : b.ev_count.p;
+	k_bd_finish<<<g_units, blk, 0, s>>>(p);
+	HIP_TRY(hipGetLastError());
+	c->ev_used = 0;
+	return TUTU_OK;
+}
+
 int bidir_check(TutuCtx* c, int type, const TutuCameraDesc* cam, int spp) {
 	if (!c || !cam) return TUTU_E_INVALID;
 	if (type != TUTU_INTEGRATOR_LIGHT && type != TUTU_INTEGRATOR_NAIVEPT && type != TUTU_INTEGRATOR_BDPT) return TUTU_E_INVALID;
@@ -1734,7 +1833,9 @@ int tutu_hip_render_integrator(TutuCtx* c, int32_t type, const TutuCameraDesc* c
 	if ((rc = bidir_params(c, type, cam, spp, key0, key1, &p)) != TUTU_OK) return rc;
 	const uint32_t npix = (uint32_t)cam->width * (uint32_t)cam->height;
 	// batches of whole pixels, in pixel order: the events of a batch all come before those of the next
-	const uint32_t unit_budget = (uint32_t)c->knobs.bidir_units;
+	// (BDPT as stages keeps 2.6 KB of path vertices and 35 request slots per unit: batches of at most 512 Ki units)
+	const uint32_t unit_budget = (type == TUTU_INTEGRATOR_BDPT && !getenv("TUTU_BDPT_UNIT_KERNEL")) ? std::min<uint32_t>((uint32_t)c->knobs.bidir_units, 1u << 19)
+	                                                                                                  : (uint32_t)c->knobs.bidir_units;
 	uint32_t pix_per_batch = unit_budget / (uint32_t)spp;
 	if (pix_per_batch == 0) pix_per_batch = 1;
 	if (pix_per_batch > npix) pix_per_batch = npix;
@@ -1765,17 +1866,29 @@ int tutu_hip_render_integrator(TutuCtx* c, int32_t type, const TutuCameraDesc* c
 	p.ev_key = b.ev_key.p;
 	p.ev_val = b.ev_val.p;
 	const bool lt_wavefront = type == TUTU_INTEGRATOR_LIGHT && !getenv("TUTU_LT_UNIT_KERNEL");
+	const bool bdpt_staged = type == TUTU_INTEGRATOR_BDPT && !getenv("TUTU_BDPT_UNIT_KERNEL");
 	for (uint32_t pix0 = 0; pix0 < npix; pix0 += pix_per_batch) {
 		const uint32_t np = std::min(pix_per_batch, npix - pix0);
 		p.n_units = np * (uint32_t)spp;
 		p.first_pix = pix0;
 		if (lt_wavefront) {
 			if ((rc = lt_wavefront_batch(c, s, p)) != TUTU_OK) return rc;
+		} else if (bdpt_staged) {
+			if ((rc = bdpt_staged_batch(c, s, p)) != TUTU_OK) return rc;
 		} else if ((rc = bidir_launch(c, s, p)) != TUTU_OK) return rc;
 		size_t n_ev = (size_t)p.n_units * (size_t)p.ev_stride;
-		if (type != TUTU_INTEGRATOR_LIGHT) {
+		if (bdpt_staged && !getenv("TUTU_BDPT_SPARSE_EVENTS")) {
+			// the stages write a unit's events densely (most of the 8 slots per unit stay empty and the sort is paid per slot): the
+			// own-pixel events go behind them, and the host reads the count
+			hipLaunchKernelGGL(k_bidir_own, dim3((np + 255) / 256), dim3(256), 0, s, b.own.p, p.own_list, type, spp, p.spp_inv, pix0, np, b.ev_key.p, b.ev_val.p,
+			                   b.ev_count.p);
+			uint32_t dense = 0;
+			HIP_TRY(hipMemcpyAsync(&dense, b.ev_count.p, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+			HIP_TRY(hipStreamSynchronize(s));
+			n_ev = (size_t)dense + np;
+		} else if (type != TUTU_INTEGRATOR_LIGHT) {
 			hipLaunchKernelGGL(k_bidir_own, dim3((np + 255) / 256), dim3(256), 0, s, b.own.p, p.own_list, type, spp, p.spp_inv, pix0, np, b.ev_key.p + n_ev,
-			                   b.ev_val.p + n_ev);
+			                   b.ev_val.p + n_ev, (const uint32_t*)nullptr);
 			n_ev += np;
 		}
 		HIP_TRY(hipcub::DeviceRadixSort::SortPairs(b.sort_tmp.p, tmp_bytes, b.ev_key.p, b.ev_key_sorted.p, b.idx.p, b.idx_sorted.p, (int)n_ev, 0, 64, s));
