@@ -163,6 +163,7 @@ struct TutuCtx {
 		DevBuf<unsigned long long> part;  // [2 kinds][TUTU_PART_BLOCKS][2] traversal work counters
 		hipEvent_t ev_resolved = nullptr;
 	} ws[TUTU_MAX_SETS];
+	WorkSet bdws;  // BDPT as stages: a lean set of its own (ensure_set_bd: 73 B per request slot instead of a path slot's 400)
 	// Work sets on their way (cold start, render_impl): a context's first default-sized render allocates only
 	// knobs.cold_paths_mi path slots itself -- a device allocation costs time in proportion to its size whenever the driver has
 	// to hand out memory another process left dirty (measured: 0.0 to 1.7 s for the default 67 GB on one box type) -- and a
@@ -356,6 +357,29 @@ void release_set(WorkSet& w) {
 	if (w.ev_resolved) (void)hipEventDestroy(w.ev_resolved);
 	w.ev_resolved = nullptr;
 	w.cap = 0;
+}
+
+// The work set of the staged BDPT: `cap` request slots (35 per unit: origin A, target S, value P, key and verdict bytes, the
+// two lists) and `units` walk records (A B D G H) with their hits -- not the twenty 16-B fields of a path slot.
+int ensure_set_bd(WorkSet& w, size_t want_slots, size_t want_units) {
+	int rc;
+	const size_t cap = (want_slots + TUTU_LIST_TILE - 1) / TUTU_LIST_TILE * TUTU_LIST_TILE;
+	const size_t units = (want_units + TUTU_LIST_TILE - 1) / TUTU_LIST_TILE * TUTU_LIST_TILE;
+	if (cap > w.cap || units > w.hitC.n) {
+		const size_t c2 = std::max(cap, w.cap), u2 = std::max(units, w.hitC.n);
+		const int big[3] = {0, 7, 8}, small[4] = {1, 2, 4, 5};  // A S P | B D G H (records_of)
+		for (int f : big)
+			if ((rc = w.rec[0][f].ensure(c2)) != TUTU_OK) return rc;
+		for (int f : small)
+			if ((rc = w.rec[0][f].ensure(u2)) != TUTU_OK) return rc;
+		if ((rc = w.key[0].ensure(c2)) != TUTU_OK || (rc = w.verdict[0].ensure(c2)) != TUTU_OK) return rc;
+		if ((rc = w.hitC.ensure(u2)) != TUTU_OK || (rc = w.hitK.ensure(u2)) != TUTU_OK) return rc;
+		if ((rc = w.lists.ensure(2 * c2)) != TUTU_OK || (rc = w.defer.ensure(c2)) != TUTU_OK) return rc;
+		if ((rc = w.tile_counts.ensure(2 * (c2 / TUTU_LIST_TILE))) != TUTU_OK || (rc = w.tile_offsets.ensure(2 * (c2 / TUTU_LIST_TILE))) != TUTU_OK) return rc;
+		w.cap = c2;
+	}
+	if ((rc = w.list_meta.ensure(TUTU_META_STRIDE * (TUTU_MAX_DEPTH + 3))) != TUTU_OK) return rc;
+	return TUTU_OK;
 }
 
 // ---- background growth of the work sets (TutuCtx::Grow)
@@ -1275,6 +1299,7 @@ int tutu_hip_destroy(TutuCtx* c) {
 		release_set(c->grow.ws[k]);
 		release_set(c->retired[k]);
 	}
+	release_set(c->bdws);
 	if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
 	if (c->ev_user) (void)hipEventDestroy(c->ev_user);
 	for (int k = 0; k < TUTU_MAX_SETS - 1; k++)
@@ -1725,11 +1750,11 @@ int lt_wavefront_batch(TutuCtx* c, hipStream_t s, BidirParams p) {
 // BDPT as stages (device_bidir.h: k_bd_walks / k_bd_connect / any-hit traversal / k_bd_finish), one batch of units; leaves the
 // batch's own-pixel contributions in p.own / p.own_list and its events in p.ev_key / p.ev_val like k_bidir<3> does
 int bdpt_staged_batch(TutuCtx* c, hipStream_t s, BidirParams p) {
-	WorkSet& w = c->ws[0];
+	WorkSet& w = c->bdws;
 	const uint32_t stride = (p.n_units + 255u) / 256u * 256u;
 	const uint32_t n_slots = stride * (uint32_t)TUTU_BD_STRATEGIES;  // slot = strategy * stride + unit
 	const uint32_t n_pad = (n_slots + TUTU_LIST_TILE - 1) / TUTU_LIST_TILE * TUTU_LIST_TILE;
-	int rc = ensure_set(w, n_pad);
+	int rc = ensure_set_bd(w, n_pad, stride);
 	if (rc != TUTU_OK) return rc;
 	if (c->ktrace_deep > 0 && (rc = w.gstack.ensure((size_t)c->ktrace_deep * TUTU_PART_BLOCKS * 256)) != TUTU_OK) return rc;
 	TutuCtx::Bidir& b = c->bd;
@@ -1833,8 +1858,8 @@ int tutu_hip_render_integrator(TutuCtx* c, int32_t type, const TutuCameraDesc* c
 	if ((rc = bidir_params(c, type, cam, spp, key0, key1, &p)) != TUTU_OK) return rc;
 	const uint32_t npix = (uint32_t)cam->width * (uint32_t)cam->height;
 	// batches of whole pixels, in pixel order: the events of a batch all come before those of the next
-	// (BDPT as stages keeps 2.6 KB of path vertices and 35 request slots per unit: batches of at most 512 Ki units)
-	const uint32_t unit_budget = (type == TUTU_INTEGRATOR_BDPT && !getenv("TUTU_BDPT_UNIT_KERNEL")) ? std::min<uint32_t>((uint32_t)c->knobs.bidir_units, 1u << 19)
+	// (BDPT as stages keeps 2.6 KB of path vertices and 35 request slots per unit: batches of at most 2 Mi units: 203 Msamples/s on the Cornell box with 512 Ki, 233 with 1 Mi, 251 with 2 Mi, 256 with 4 Mi)
+	const uint32_t unit_budget = (type == TUTU_INTEGRATOR_BDPT && !getenv("TUTU_BDPT_UNIT_KERNEL")) ? std::min<uint32_t>((uint32_t)c->knobs.bidir_units, 1u << 21)
 	                                                                                                  : (uint32_t)c->knobs.bidir_units;
 	uint32_t pix_per_batch = unit_budget / (uint32_t)spp;
 	if (pix_per_batch == 0) pix_per_batch = 1;
