@@ -45,6 +45,20 @@ FRAMES = {
 NATIVE = dict(mk=lambda: scenes.cornell_box(128, 128), spp=4096)
 
 
+def _ggx_mirror():
+    from oracle.pyoracle import MICROFACET_T, PERFECT_REFLECTIVE, make_material
+
+    return scenes.cornell_box(128, 128, tall=make_material(MICROFACET_T, (0.725, 0.71, 0.68), eta=1.5, roughness=0.2),
+                              short=make_material(PERFECT_REFLECTIVE, (0.725, 0.71, 0.68)))
+
+
+# more native-RNG frames (SURVEY.md 8c's list): name -> (scene, spp); written to tests/golden/frame_<name>.npz
+NATIVE_MORE = {
+    "native_veach": dict(mk=lambda: scenes.veach_room(160, 120, small_light=False), spp=2048),
+    "native_ggxT_mirror": dict(mk=_ggx_mirror, spp=2048),
+}
+
+
 def scene_crc(sc):
     return pc.checksum(np.ascontiguousarray(sc["verts"], np.float32), np.ascontiguousarray(sc["normals"], np.float32),
                        np.ascontiguousarray(sc["mat_id"], np.int32))
@@ -54,16 +68,18 @@ def main(which):
     os.makedirs(GOLD, exist_ok=True)
     R = None
     for name in which:
-        if name == "native":
+        if name == "native" or name in NATIVE_MORE:
             RN = Oracle("reference_native")
-            sc = NATIVE["mk"]()
+            cfgn = NATIVE if name == "native" else NATIVE_MORE[name]
+            sc = cfgn["mk"]()
             S = RN.scene(sc)
             t0 = time.time()
-            rgb = S.render(NATIVE["spp"], 0, 0)  # the key is not consumed: the reference's thread_local mt19937 draws
+            rgb = S.render(cfgn["spp"], 0, 0)  # the key is not consumed: the reference's thread_local mt19937 draws
             dt = time.time() - t0
             S.close()
-            np.savez_compressed(os.path.join(GOLD, "frame_native_cornell.npz"), rgb=rgb, spp=np.int32(NATIVE["spp"]), scene_crc=scene_crc(sc))
-            print(f"native: 128x128x{NATIVE['spp']} in {dt:.1f} s, mean {rgb.mean():.5f}", flush=True)
+            out = "frame_native_cornell.npz" if name == "native" else f"frame_{name}.npz"
+            np.savez_compressed(os.path.join(GOLD, out), rgb=rgb, spp=np.int32(cfgn["spp"]), scene_crc=scene_crc(sc))
+            print(f"{name}: {sc['width']}x{sc['height']}x{cfgn['spp']} in {dt:.1f} s, mean {rgb.mean():.5f}", flush=True)
             continue
         if R is None:
             R = Oracle("reference")

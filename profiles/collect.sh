@@ -40,5 +40,9 @@ else
   timeout -k 10 300 python bench.py --config c2 --emulate-shard 8 --shard -1 --steps 2 --warmup 1 2> /dev/null | grep "^{" > $O/shard_balance_c2.json; echo "shards c2 rc=$?"
   timeout -k 10 600 python bench.py --config c4 --emulate-shard 8 --shard -1 --steps 1 --warmup 1 2> /dev/null | grep "^{" > $O/shard_balance_c4.json; echo "shards c4 rc=$?"
   timeout -k 10 300 python profiles/bench_integrators.py --steps 3 2> /dev/null | grep "^{" > $O/integrators_bench.jsonl; echo "integrators rc=$?"
+  # (round 4) the same on the veach room, and BDPT through the one-lane-per-unit kernel the stages replaced
+  timeout -k 10 300 python profiles/bench_integrators.py --steps 3 --no-cpu --scene veach_room --width 800 --height 600 2> /dev/null | grep "^{" | sed 's/^{/{"scene": "veach_room", /' >> $O/integrators_bench.jsonl
+  TUTU_BDPT_UNIT_KERNEL=1 timeout -k 10 300 python profiles/bench_integrators.py --steps 3 --no-cpu 2> /dev/null | grep '"bdpt"' | sed 's/^{/{"bdpt_form": "unit kernel (TUTU_BDPT_UNIT_KERNEL=1)", /' >> $O/integrators_bench.jsonl
+  TUTU_BDPT_UNIT_KERNEL=1 timeout -k 10 300 python profiles/bench_integrators.py --steps 3 --no-cpu --scene veach_room --width 800 --height 600 2> /dev/null | grep '"bdpt"' | sed 's/^{/{"scene": "veach_room", "bdpt_form": "unit kernel (TUTU_BDPT_UNIT_KERNEL=1)", /' >> $O/integrators_bench.jsonl
   python profiles/summarize_bench.py $O/bench_c*.log
 fi
