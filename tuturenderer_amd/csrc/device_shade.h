@@ -800,6 +800,7 @@ struct TraceParams {
 	int leaf_again;      // lanes that must still hold a leaf for a second leaf step in the round (65: never)
 	int xcd_map;         // 1: the blocks of one XCD (blockIdx mod 8) take adjacent ranges of the list
 	uint32_t* defer;     // >= *n_ptr entries: list positions of the rays that are not plain, per wave range (below)
+	int flat_share;      // k_trace_flat, closest hit: deal the wave's (ray, leaf) pairs to its lanes (knob "flat_share")
 };
 
 // The exact walk of ONE list position: the reference's own tree, the reference's own slab, no validation, no pruning
@@ -1226,12 +1227,16 @@ TUTU_DEV void trace_persistent(const S& ss, const TraceParams& tp, int* stack, c
 // Shadow rays keep the limit dis * (1 + 1e-4) on the box test, as in the tree walk.  One ray per lane and iteration: every
 // wave owns a contiguous range of the list; rays that are not plain go to the exact walk after the loop (as in
 // trace_persistent).  Counters: a "node entered" is a box tested, a node step one box test of the wave.
+#define TUTU_FLAT_SHARE 192  // (ray, leaf) pairs a wave deals out per round
 template <bool ANY, bool SPH>
 __global__ void __launch_bounds__(256, 8) k_trace_flat(TraceParams tp, FlatScene fs) {
 	extern __shared__ int lds[];  // [stack entries of the exact walk][256 lanes] | scene copy | class table
 	const SceneLds ss = stage_scene_lds(tp.sc, lds, tp.stack_entries);
 	uint8_t* cls = reinterpret_cast<uint8_t*>(ss.end());
 	__shared__ int s_ref[TUTU_FLAT_MAX];
+	// closest hit: the tables through which a wave deals its (ray, leaf) pairs to its lanes (phase 2)
+	__shared__ float4 s_ray[ANY ? 1 : 4 * 3 * 64], s_res[ANY ? 1 : 4 * TUTU_FLAT_SHARE];
+	__shared__ uint16_t s_item[ANY ? 1 : 4 * TUTU_FLAT_SHARE];
 	for (int k = 0; k < fs.n; k++)
 		if ((int)threadIdx.x == k) s_ref[k] = __float_as_int(fs.box[k][3]);
 	if (!ANY)
@@ -1330,6 +1335,90 @@ __global__ void __launch_bounds__(256, 8) k_trace_flat(TraceParams tp, FlatScene
 				second = 0;
 			}
 		};
+		if (!ANY && tp.flat_share) {
+			// Closest hit: the wave's (ray, leaf) pairs are dealt to its lanes.  A ray hits 1.7 boxes on average and 4-5 at most:
+			// with every lane walking its own bits the loop runs as long as the busiest lane needs -- 41 % of the lanes at work.
+			// Here the lanes list their pairs in LDS (a prefix sum over the bit counts), every lane takes every 64th pair with
+			// that ray's data from LDS, leaves its candidate there, and the ray's own lane picks the nearest of its pairs'
+			// candidates -- the same minimum over the same candidates, whoever tested them.
+			const int wv = threadIdx.x >> 6;
+			float4* const w_ray = s_ray + wv * (3 * 64);
+			uint16_t* const w_item = s_item + wv * TUTU_FLAT_SHARE;
+			float4* const w_res = s_res + wv * TUTU_FLAT_SHARE;
+			w_ray[lane] = make_float4(r.o.x, r.o.y, r.o.z, 0.f);
+			w_ray[64 + lane] = make_float4(r.d.x, r.d.y, r.d.z, 0.f);
+			w_ray[128 + lane] = make_float4(r.inv.x, r.inv.y, r.inv.z, 0.f);
+			while (__ballot(mask != 0u) != 0ull) {
+				const uint32_t cnt = (uint32_t)__popc(mask);
+				uint32_t incl = cnt;
+				for (int off = 1; off < 64; off <<= 1) {
+					const uint32_t up = (uint32_t)__shfl_up((int)incl, off);
+					if (lane >= off) incl += up;
+				}
+				const uint32_t total = (uint32_t)__shfl((int)incl, 63), first = incl - cnt;
+				uint32_t n_mine = 0;
+				while (mask != 0u && first + n_mine < (uint32_t)TUTU_FLAT_SHARE) {  // (pairs beyond the table wait for the next round)
+					const int k = __ffs((int)mask) - 1;
+					mask &= mask - 1u;
+					w_item[first + n_mine] = (uint16_t)((lane << 5) | k);
+					n_mine++;
+				}
+				const uint32_t n_items = min(total, (uint32_t)TUTU_FLAT_SHARE);
+				__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+				__builtin_amdgcn_wave_barrier();
+				__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+				for (uint32_t j = (uint32_t)lane; j < ((n_items + 63u) & ~63u); j += 64u) {
+					w_leaf_steps++;
+					if (j < n_items) {
+						const uint32_t it = w_item[j];
+						const int src = (int)(it >> 5), k = (int)(it & 31u);
+						const float4 ro = w_ray[src], rd = w_ray[64 + src], ri = w_ray[128 + src];
+						RayPre q;
+						q.o = mk(ro.x, ro.y, ro.z);
+						q.d = mk(rd.x, rd.y, rd.z);
+						q.inv = mk(ri.x, ri.y, ri.z);
+						q.nx = q.d.x < 0;
+						q.ny = q.d.y < 0;
+						q.nz = q.d.z < 0;
+						float bt = FLT_MAX, bu = 0.f, bv = 0.f;
+						int btri = -1;
+						int item = ~s_ref[k], second = 0;
+						if (!SPH && sc.pair_leaves) {
+							second = item >> TUTU_PAIR_BITS;
+							item &= (1 << TUTU_PAIR_BITS) - 1;
+						}
+						for (;;) {
+							n_leaves++;
+							int ti;
+							float t, u, v;
+							if (leaf_test<SPH>(ss, item, q, ti, t, u, v) && (t < bt || (t == bt && ti < btri))) {
+								float4 lo, hi;
+								ss.lbox(ti, lo, hi);
+								float te;
+								if (slab_plain(q, lo.x, lo.y, lo.z, hi.x, hi.y, hi.z, inf, te)) {  // validated (BVH.hpp:150)
+									bt = t; bu = u; bv = v; btri = ti;
+								}
+							}
+							if (second == 0) break;
+							item = second - 1;
+							second = 0;
+						}
+						w_res[j] = make_float4(bt, bu, bv, __int_as_float(btri));
+					}
+				}
+				__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+				__builtin_amdgcn_wave_barrier();
+				__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+				for (uint32_t qi = 0; qi < n_mine; qi++) {
+					const float4 c = w_res[first + qi];
+					const int ti = __float_as_int(c.w);
+					if (ti >= 0 && (c.x < best_t || (c.x == best_t && ti < best_tri))) {
+						best_t = c.x; best_u = c.y; best_v = c.z; best_tri = ti;
+					}
+				}
+				__builtin_amdgcn_wave_barrier();  // the tables are rewritten by the next round
+			}
+		}
 		// every box that was hit (shadow rays: every box within the limit, until the first blocker)
 		while (__ballot(mask != 0u) != 0ull) {
 			w_leaf_steps++;

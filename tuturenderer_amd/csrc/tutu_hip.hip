@@ -137,6 +137,7 @@ struct TutuCtx {
 		int util_stats = 0;       // TUTU_UTIL_STATS     phase counters of the traversal kernels  {0, 1}
 		int device_build = 1;     // TUTU_DEVICE_BUILD   the walked tree of a large scene is built on the device: 0 never, 1 from device_build_min objects on, 2 always  [0, 2]
 		int device_build_min_k = 384;  // TUTU_DEVICE_BUILD_MIN_K  ... "large" = at least this many thousand objects  [1, 1048576]
+		int flat_share = 1;       // TUTU_FLAT_SHARE     flat scan, closest hit: the wave's (ray, leaf) pairs dealt to its lanes through LDS  {0, 1}
 		int flat = 1;             // TUTU_FLAT           tiny LDS-resident scenes (<= TUTU_FLAT_MAX leaves): the flat scan instead of the tree walk  {0, 1}
 		int exact = 0;            // TUTU_EXACT          every ray takes the exact walk: reference tree, reference slab, no pruning  {0, 1}
 		int cold_paths_mi = 12;   // TUTU_COLD_PATHS_MI  Mi path slots (all work sets together) a context's FIRST default-sized render allocates itself;
@@ -246,6 +247,7 @@ const KnobDesc kKnobs[] = {
     {"bidir_units", "TUTU_BIDIR_UNITS", &TutuCtx::Knobs::bidir_units, 64, 1 << 24},
     {"exact", "TUTU_EXACT", &TutuCtx::Knobs::exact, 0, 1},
     {"flat", "TUTU_FLAT", &TutuCtx::Knobs::flat, 0, 1, true},
+    {"flat_share", "TUTU_FLAT_SHARE", &TutuCtx::Knobs::flat_share, 0, 1},
     {"device_build", "TUTU_DEVICE_BUILD", &TutuCtx::Knobs::device_build, 0, 2, true},
     {"device_build_min_k", "TUTU_DEVICE_BUILD_MIN_K", &TutuCtx::Knobs::device_build_min_k, 1, 1 << 20, true},
     {"cold_paths_mi", "TUTU_COLD_PATHS_MI", &TutuCtx::Knobs::cold_paths_mi, 0, 4096},
@@ -499,8 +501,10 @@ void launch_trace(TutuCtx* c, hipStream_t s, int grid, const TraceParams& tp) {
 	const dim3 g((unsigned)grid), b(256);
 	const unsigned lds = c->ktrace_lds_bytes;
 	if (c->flat.n > 0) {  // tiny scene: the flat scan
-		if (c->has_spheres) k_trace_flat<ANY, true><<<g, b, lds, s>>>(tp, c->flat);
-		else k_trace_flat<ANY, false><<<g, b, lds, s>>>(tp, c->flat);
+		TraceParams tf = tp;
+		tf.flat_share = c->knobs.flat_share;
+		if (c->has_spheres) k_trace_flat<ANY, true><<<g, b, lds, s>>>(tf, c->flat);
+		else k_trace_flat<ANY, false><<<g, b, lds, s>>>(tf, c->flat);
 		return;
 	}
 	if (c->has_spheres) {
