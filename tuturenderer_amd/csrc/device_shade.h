@@ -775,6 +775,13 @@ __global__ void __launch_bounds__(256) k_shade(PassParams pp) {
 //     depends on the tree's depth (round 2: bunny stand-in 7 blocks per CU, broom stand-in 5).
 //   * The reference's leaf boxes (candidate validation) and the class table are part of the LDS scene copy.
 #define TUTU_INNER_STEPS 6
+#ifdef TUTU_CENSUS
+// Lane census (a build with -DTUTU_CENSUS; profiles/README.md): what the 64 lanes of a wave are doing at every node step and
+// leaf step of trace_persistent, summed over all waves.  [8 * ANY + k], k = 0 walking an inner node, 1 idle (awaiting the
+// refill), 2 done (awaiting the finish), 3 sitting on a leaf, 4 done with a leaf still parked | per leaf step: 5 holding a
+// leaf, 6 idle, 7 holding two.  Read and zeroed by collect_stats (tutu_hip.hip).
+__device__ unsigned long long g_census[16];
+#endif
 #define TUTU_TRAV_IDLE (INT_MIN + 1)
 #define TUTU_STACK_SENTINELS 1
 
@@ -903,6 +910,9 @@ TUTU_DEV void trace_persistent(const S& ss, const TraceParams& tp, int* stack, c
 	uint32_t n_nodes = 0, n_leaves = 0;  // work counters of this lane
 	uint32_t w_node_steps = 0, w_leaf_steps = 0;  // wave-uniform: how often each phase ran
 	uint32_t n_def = 0;  // wave-uniform: rays set aside for the exact walk
+#ifdef TUTU_CENSUS
+	uint32_t cz[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
 	// any-hit only
 	float dis = 0.f;
 	float4 Lpre = make_float4(0.f, 0.f, 0.f, 0.f);  // TUTU_KEY_FINAL requests: the path's radiance | home slot and the
@@ -985,6 +995,13 @@ TUTU_DEV void trace_persistent(const S& ss, const TraceParams& tp, int* stack, c
 		for (int k = 0; k < tp.inner_steps; k++) {
 			if (__ballot(cur >= 0) == 0ull) break;
 			w_node_steps++;
+#ifdef TUTU_CENSUS
+			cz[0] += (uint32_t)__popcll(__ballot(cur >= 0));
+			cz[1] += (uint32_t)__popcll(__ballot(cur == TUTU_TRAV_IDLE));
+			cz[2] += (uint32_t)__popcll(__ballot(cur == TUTU_TRAV_DONE));
+			cz[3] += (uint32_t)__popcll(__ballot(ref_is_leaf(cur)));
+			cz[4] += (uint32_t)__popcll(__ballot(cur == TUTU_TRAV_DONE && pend != TUTU_TRAV_IDLE));
+#endif
 			if (WIDE) {
 				if (cur >= 0) {
 					// ---- one node of the WIDE tree: four quantised child boxes in one 64-B fetch (host_scene.hpp: GpuWideNode).
@@ -1091,6 +1108,11 @@ TUTU_DEV void trace_persistent(const S& ss, const TraceParams& tp, int* stack, c
 			// (making the round's FIRST leaf step wait until several lanes hold a leaf, while others still walk nodes, was
 			// measured on all scenes: neutral on the Cornell box, monotonically slower on the memory-resident ones)
 			w_leaf_steps++;
+#ifdef TUTU_CENSUS
+			cz[5] += (uint32_t)__popcll(m_leaf);
+			cz[6] += (uint32_t)__popcll(__ballot(cur == TUTU_TRAV_IDLE));
+			cz[7] += (uint32_t)__popcll(__ballot(has_pend && on_leaf));
+#endif
 			if (has_pend || on_leaf) {
 				n_leaves++;
 				const int p1 = entry_read(sp - 1);
@@ -1190,6 +1212,10 @@ TUTU_DEV void trace_persistent(const S& ss, const TraceParams& tp, int* stack, c
 	// work counters: wave sum, then one plain add per block into this block's own slots (no global atomics: a counter word
 	// shared by all waves sustains ~88 atomics/us and would cost more than the traversal).  [0] nodes entered, [1] leaf
 	// tests, [2] how often a wave ran its inner-node step, [3] its leaf step.
+#ifdef TUTU_CENSUS
+	if (lane == 0)
+		for (int k = 0; k < 8; k++) atomicAdd(&g_census[8 * (ANY ? 1 : 0) + k], (unsigned long long)cz[k]);
+#endif
 	if (tp.part) {
 		unsigned long long a = n_nodes, b = n_leaves;
 		for (int off = 32; off > 0; off >>= 1) {

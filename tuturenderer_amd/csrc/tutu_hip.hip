@@ -82,7 +82,9 @@ struct DevBuf {
 
 }  // namespace
 
-#define TUTU_MAX_SETS 4  // work sets = passes in flight, one stream each
+#ifndef TUTU_MAX_SETS
+#define TUTU_MAX_SETS 4  // work sets = passes in flight, one stream each (round 4: eight, with GPU_MAX_HW_QUEUES=8, are not faster)
+#endif
 #define TUTU_BYTES_PER_SLOT 400  // device memory of a work set per path slot (two record sets of ten 16-B fields, hits, lists, ...)
 
 struct TutuCtx {
@@ -714,6 +716,20 @@ int collect_stats(TutuCtx* c, hipStream_t s, TutuStats* st, uint64_t samples, ui
 				st->wave_leaf_steps_any += h[4 * TUTU_PART_BLOCKS + 4 * b + 3];
 			}
 		}
+#ifdef TUTU_CENSUS
+		{
+			unsigned long long z[16];
+			HIP_TRY(hipMemcpyFromSymbol(z, HIP_SYMBOL(g_census), sizeof(z)));
+			for (int a = 0; a < 2; a++) {
+				const unsigned long long* q = z + 8 * a;
+				const double ns = a ? st->wave_node_steps_any : st->wave_node_steps_closest, ls = a ? st->wave_leaf_steps_any : st->wave_leaf_steps_closest;
+				fprintf(stderr, "[tutu census %s] per node step: walking %.1f, idle %.1f, done %.1f (of which with a parked leaf %.1f), on a leaf %.1f | per leaf step: with a leaf %.1f, idle %.1f, two leaves %.1f | node steps %.3g leaf steps %.3g\n",
+				        a ? "any" : "closest", q[0] / ns, q[1] / ns, q[2] / ns, q[4] / ns, q[3] / ns, q[5] / ls, q[6] / ls, q[7] / ls, ns, ls);
+			}
+			memset(z, 0, sizeof(z));
+			HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_census), z, sizeof(z)));
+		}
+#endif
 		if (c->knobs.util_stats)
 			fprintf(stderr, "[tutu util] closest: lanes/node-step %.1f lanes/leaf-step %.1f | any: %.1f %.1f\n",
 			        st->wave_node_steps_closest ? (double)st->nodes_closest / st->wave_node_steps_closest : 0.0,
