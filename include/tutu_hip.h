@@ -365,6 +365,8 @@ int tutu_hip_quantise(TutuCtx* ctx, uint32_t n, const float* values, int32_t* le
  *   "exact" TUTU_EXACT {0,1} (1: EVERY ray takes the exact walk -- the reference's own tree, the reference's own slab test, no distance
  *   pruning, BVH.hpp:145-194 visit for visit: the strict form, several times slower on big scenes; DESIGN.md section 4 says what the default
  *   walk assumes instead) | "cold_paths_mi" TUTU_COLD_PATHS_MI [0,4096] (see tutu_hip_work_ready; 0 = allocate everything in the first render) |
+ *   "flat" TUTU_FLAT {0,1} (create-only; 1: a scene of at most 24 leaves is scanned flat instead of walked, device_shade.h: k_trace_flat; read-only
+ *   fact "flat_leaves") | "flat_share" TUTU_FLAT_SHARE {0,1} (1: the closest-hit scan deals its (ray, leaf) pairs to the wave's lanes through LDS) |
  *   "util_stats" TUTU_UTIL_STATS {0,1} | "bidir_units" TUTU_BIDIR_UNITS [64, 2^24] ((pixel, sample) units per batch of
  *   tutu_hip_render_integrator; batches are whole pixels) |
  *   "wide" TUTU_WIDE [0,2] (memory-resident scenes: 0 walk the binary SAH tree, 1 the four-wide quantised tree when the binary

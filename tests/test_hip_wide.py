@@ -490,12 +490,15 @@ def test_flat_scan_of_tiny_scenes_is_the_tree_walk(tr, port, monkeypatch):
     """Scenes of at most 24 leaves (the Cornell box: 16 quads) are not walked as a tree: every lane tests its ray against every
     leaf box -- kernel arguments, scalar loads -- and then against the leaves behind the boxes it hit (device_shade.h:
     k_trace_flat).  TUTU_FLAT=0 walks the tree as before.  Golden rays of the reference build, 300 k random + 60 k degenerate
-    rays and shadow segments against the unpruned recursion, and a frame: the same bits either way."""
+    rays and shadow segments against the unpruned recursion, and a frame: the same bits either way.  The closest-hit scan
+    deals its (ray, leaf) pairs to the lanes of the wave through LDS (knob flat_share, default on): "flat_own" is the scan
+    with every lane testing its own leaves."""
     from tuturenderer_amd import scenes
 
     frames = {}
-    for tag, env in (("flat", {}), ("tree", {"TUTU_FLAT": "0"})):
+    for tag, env in (("flat", {}), ("flat_own", {"TUTU_FLAT_SHARE": "0"}), ("tree", {"TUTU_FLAT": "0"})):
         monkeypatch.delenv("TUTU_FLAT", raising=False)
+        monkeypatch.delenv("TUTU_FLAT_SHARE", raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         for name in ("cornell", "cornell_ggxT_mirror", "cornell_degenerate"):
@@ -506,7 +509,8 @@ def test_flat_scan_of_tiny_scenes_is_the_tree_walk(tr, port, monkeypatch):
             with tr.Context(sc) as ctx:
                 assert ctx.get_option("lds_scene") == 1
                 if name != "cornell_degenerate":  # (that scene's extra slivers make more than 24 leaves: it keeps the tree walk)
-                    assert (ctx.get_option("flat_leaves") > 0) == (tag == "flat"), (name, ctx.get_option("flat_leaves"))
+                    assert (ctx.get_option("flat_leaves") > 0) == (tag != "tree"), (name, ctx.get_option("flat_leaves"))
+                    assert ctx.get_option("flat_share") == (0 if tag == "flat_own" else 1)
                 hits = ctx.trace_closest(O, D)
                 h = hits["tri"] >= 0
                 assert bit_equal(hits["tri"], z["scene.tri"]), (tag, name)
@@ -538,6 +542,7 @@ def test_flat_scan_of_tiny_scenes_is_the_tree_walk(tr, port, monkeypatch):
         print(f"\n[{tag}] boxes / nodes entered per closest-hit ray {(st['nodes_closest'] + st['leaves_closest']) / max(st['closest_rays'] - 160 * 160, 1):.1f}, "
               f"leaf tests {st['leaves_closest'] / max(st['closest_rays'] - 160 * 160, 1):.2f}")
     assert frames["flat"].tobytes() == frames["tree"].tobytes()
+    assert frames["flat_own"].tobytes() == frames["tree"].tobytes()
 
 
 def test_flat_scan_on_needles_is_the_unpruned_recursion(tr, port, monkeypatch):
