@@ -814,21 +814,21 @@ struct TraceParams {
 // (device_trace.h: force_exact) -- used for the rays the persistent kernels set aside (not plain, or outside the wide tree's
 // region) and, with the knob "exact", for every ray (k_trace_exact).  xstack: this lane's column of the LDS stack.
 template <typename S, bool ANY>
-TUTU_DEV void exact_walk_entry(const S& ss, const TraceParams& tp, uint32_t i, int* xstack, const uint8_t* tri_class) {
+TUTU_DEV void exact_walk_entry(const S& ss, const TraceParams& tp, uint32_t i, int* xstack, const uint8_t* tri_class, int stride = 256) {
 	const SceneDev& sc = tp.sc;
 	const uint32_t s = tp.list[i];
 	if (!ANY) {
 		const float4 A = tp.rec.A[s], B = tp.rec.B[s];
 		float t, u, v;
 		int tri;
-		trace_closest(ss, sc, mk(A.x, A.y, A.z), mk(B.x, B.y, B.z), xstack, 256, t, u, v, tri, true);
+		trace_closest(ss, sc, mk(A.x, A.y, A.z), mk(B.x, B.y, B.z), xstack, stride, t, u, v, tri, true);
 		tp.hitC[i] = make_float4(t, u, v, __int_as_float(tri));
 		tp.hitK[i] = tri >= 0 ? tri_class[tri] : (uint8_t)TUTU_CLASS_MISS;
 	} else {
 		const uint32_t f = tp.rec.key[s];
 		const float4 e0 = (f & TUTU_KEY_ALT) ? tp.rec.S2[s] : tp.rec.A[s];
 		const float4 e1 = tp.rec.S[s];
-		const bool blk = trace_any(ss, sc, mk(e0.x, e0.y, e0.z), mk(e1.x, e1.y, e1.z), xstack, 256, true);
+		const bool blk = trace_any(ss, sc, mk(e0.x, e0.y, e0.z), mk(e1.x, e1.y, e1.z), xstack, stride, true);
 		if (f & TUTU_KEY_FINAL) {
 			const float4 Lp = tp.rec.L[s], e2 = tp.rec.P[s];
 			float4 F = make_float4(Lp.x, Lp.y, Lp.z, 0.f);
@@ -1254,6 +1254,7 @@ TUTU_DEV void trace_persistent(const S& ss, const TraceParams& tp, int* stack, c
 // wave owns a contiguous range of the list; rays that are not plain go to the exact walk after the loop (as in
 // trace_persistent).  Counters: a "node entered" is a box tested, a node step one box test of the wave.
 #define TUTU_FLAT_SHARE 192  // (ray, leaf) pairs a wave deals out per round
+#define TUTU_FLAT_OWN_STACK 12  // entries of the exact walk's stack that fit a wave's ray table (3 x 64 float4 = [12][64] ints)
 template <bool ANY, bool SPH>
 __global__ void __launch_bounds__(256, 8) k_trace_flat(TraceParams tp, FlatScene fs) {
 	extern __shared__ int lds[];  // [stack entries of the exact walk][256 lanes] | scene copy | class table
@@ -1476,8 +1477,12 @@ __global__ void __launch_bounds__(256, 8) k_trace_flat(TraceParams tp, FlatScene
 	if (n_def != 0u) {
 		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
 		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-		int* xstack = lds + threadIdx.x;
-		for (uint32_t j = (uint32_t)lane; j < n_def; j += 64u) exact_walk_entry<SceneLds, ANY>(ss, tp, tp.defer[begin + j], xstack, cls);
+		// closest hit with stack_entries = 0 (host: launch_trace): no stack in the dynamic LDS -- the wave's own share tables are
+		// free now (its loop is over) and hold the exact walk's stack, [entry][64 lanes], TUTU_FLAT_OWN_STACK entries: 8 KB less
+		// LDS per block, five blocks per CU instead of four
+		const bool own = !ANY && tp.stack_entries == 0;
+		int* xstack = own ? reinterpret_cast<int*>(s_ray + (threadIdx.x >> 6) * (3 * 64)) + lane : lds + threadIdx.x;
+		for (uint32_t j = (uint32_t)lane; j < n_def; j += 64u) exact_walk_entry<SceneLds, ANY>(ss, tp, tp.defer[begin + j], xstack, cls, own ? 64 : 256);
 	}
 	if (tp.part) {
 		unsigned long long a = n_nodes, b = n_leaves;

@@ -505,8 +505,21 @@ void launch_trace(TutuCtx* c, hipStream_t s, int grid, const TraceParams& tp) {
 	if (c->flat.n > 0) {  // tiny scene: the flat scan
 		TraceParams tf = tp;
 		tf.flat_share = c->knobs.flat_share;
-		if (c->has_spheres) k_trace_flat<ANY, true><<<g, b, lds, s>>>(tf, c->flat);
-		else k_trace_flat<ANY, false><<<g, b, lds, s>>>(tf, c->flat);
+		dim3 gf = g;
+		unsigned ldsf = lds;
+		if (!ANY) {
+			// closest hit: the kernel's share tables (26 KB of static LDS) decide how many blocks a CU holds; the exact walk's
+			// stack moves into them when it fits (device_shade.h: TUTU_FLAT_OWN_STACK), and the grid is what is resident at once
+			if (c->ktrace_entries <= TUTU_FLAT_OWN_STACK) {
+				tf.stack_entries = 0;
+				ldsf = lds - (unsigned)((size_t)c->ktrace_entries * 256 * sizeof(int));
+			}
+			const unsigned per_block = ldsf + 26240u + 64u;
+			const int bpc = (int)std::max(1u, std::min(5u, (160u * 1024u) / per_block));  // (92 registers: five waves per SIMD)
+			gf = dim3((unsigned)std::min(grid, c->n_cu * bpc));
+		}
+		if (c->has_spheres) k_trace_flat<ANY, true><<<gf, b, ldsf, s>>>(tf, c->flat);
+		else k_trace_flat<ANY, false><<<gf, b, ldsf, s>>>(tf, c->flat);
 		return;
 	}
 	if (c->has_spheres) {
