@@ -1254,15 +1254,15 @@ TUTU_DEV void trace_persistent(const S& ss, const TraceParams& tp, int* stack, c
 // wave owns a contiguous range of the list; rays that are not plain go to the exact walk after the loop (as in
 // trace_persistent).  Counters: a "node entered" is a box tested, a node step one box test of the wave.
 #define TUTU_FLAT_SHARE 192  // (ray, leaf) pairs a wave deals out per round
-#define TUTU_FLAT_OWN_STACK 12  // entries of the exact walk's stack that fit a wave's ray table (3 x 64 float4 = [12][64] ints)
+#define TUTU_FLAT_OWN_STACK 12  // entries of the exact walk's stack that fit a wave's table of candidates (192 float4 = [12][64] ints)
 template <bool ANY, bool SPH>
-__global__ void __launch_bounds__(256, 8) k_trace_flat(TraceParams tp, FlatScene fs) {
+__global__ void __launch_bounds__(256, ANY ? 8 : 5) k_trace_flat(TraceParams tp, FlatScene fs) {
 	extern __shared__ int lds[];  // [stack entries of the exact walk][256 lanes] | scene copy | class table
 	const SceneLds ss = stage_scene_lds(tp.sc, lds, tp.stack_entries);
 	uint8_t* cls = reinterpret_cast<uint8_t*>(ss.end());
 	__shared__ int s_ref[TUTU_FLAT_MAX];
 	// closest hit: the tables through which a wave deals its (ray, leaf) pairs to its lanes (phase 2)
-	__shared__ float4 s_ray[ANY ? 1 : 4 * 3 * 64], s_res[ANY ? 1 : 4 * TUTU_FLAT_SHARE];
+	__shared__ float4 s_res[ANY ? 1 : 4 * TUTU_FLAT_SHARE];
 	__shared__ uint16_t s_item[ANY ? 1 : 4 * TUTU_FLAT_SHARE];
 	for (int k = 0; k < fs.n; k++)
 		if ((int)threadIdx.x == k) s_ref[k] = __float_as_int(fs.box[k][3]);
@@ -1369,12 +1369,8 @@ __global__ void __launch_bounds__(256, 8) k_trace_flat(TraceParams tp, FlatScene
 			// that ray's data from LDS, leaves its candidate there, and the ray's own lane picks the nearest of its pairs'
 			// candidates -- the same minimum over the same candidates, whoever tested them.
 			const int wv = threadIdx.x >> 6;
-			float4* const w_ray = s_ray + wv * (3 * 64);
 			uint16_t* const w_item = s_item + wv * TUTU_FLAT_SHARE;
 			float4* const w_res = s_res + wv * TUTU_FLAT_SHARE;
-			w_ray[lane] = make_float4(r.o.x, r.o.y, r.o.z, 0.f);
-			w_ray[64 + lane] = make_float4(r.d.x, r.d.y, r.d.z, 0.f);
-			w_ray[128 + lane] = make_float4(r.inv.x, r.inv.y, r.inv.z, 0.f);
 			while (__ballot(mask != 0u) != 0ull) {
 				const uint32_t cnt = (uint32_t)__popc(mask);
 				uint32_t incl = cnt;
@@ -1396,14 +1392,19 @@ __global__ void __launch_bounds__(256, 8) k_trace_flat(TraceParams tp, FlatScene
 				__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 				for (uint32_t j = (uint32_t)lane; j < ((n_items + 63u) & ~63u); j += 64u) {
 					w_leaf_steps++;
+					// the pair's ray: from the registers of the lane that owns it (ds_bpermute, every lane of the wave taking part --
+					// no table in LDS: the blocks of the other stages in flight need the room, see k_trace_flat's header)
+					const uint32_t it = j < n_items ? (uint32_t)w_item[j] : 0u;
+					const int src = (int)(it >> 5), k = (int)(it & 31u);
+					auto from = [&](float x) { return __int_as_float(__builtin_amdgcn_ds_bpermute(src << 2, __float_as_int(x))); };
+					const V3 qo = mk(from(r.o.x), from(r.o.y), from(r.o.z));
+					const V3 qd = mk(from(r.d.x), from(r.d.y), from(r.d.z));
+					const V3 qi = mk(from(r.inv.x), from(r.inv.y), from(r.inv.z));
 					if (j < n_items) {
-						const uint32_t it = w_item[j];
-						const int src = (int)(it >> 5), k = (int)(it & 31u);
-						const float4 ro = w_ray[src], rd = w_ray[64 + src], ri = w_ray[128 + src];
 						RayPre q;
-						q.o = mk(ro.x, ro.y, ro.z);
-						q.d = mk(rd.x, rd.y, rd.z);
-						q.inv = mk(ri.x, ri.y, ri.z);
+						q.o = qo;
+						q.d = qd;
+						q.inv = qi;
 						q.nx = q.d.x < 0;
 						q.ny = q.d.y < 0;
 						q.nz = q.d.z < 0;
@@ -1477,11 +1478,11 @@ __global__ void __launch_bounds__(256, 8) k_trace_flat(TraceParams tp, FlatScene
 	if (n_def != 0u) {
 		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
 		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-		// closest hit with stack_entries = 0 (host: launch_trace): no stack in the dynamic LDS -- the wave's own share tables are
-		// free now (its loop is over) and hold the exact walk's stack, [entry][64 lanes], TUTU_FLAT_OWN_STACK entries: 8 KB less
-		// LDS per block, five blocks per CU instead of four
+		// closest hit with stack_entries = 0 (host: launch_trace): no stack in the dynamic LDS -- the wave's own table of candidates
+		// is free now (its loop is over) and holds the exact walk's stack, [entry][64 lanes], TUTU_FLAT_OWN_STACK entries: 8 KB
+		// less LDS per block
 		const bool own = !ANY && tp.stack_entries == 0;
-		int* xstack = own ? reinterpret_cast<int*>(s_ray + (threadIdx.x >> 6) * (3 * 64)) + lane : lds + threadIdx.x;
+		int* xstack = own ? reinterpret_cast<int*>(s_res + (threadIdx.x >> 6) * TUTU_FLAT_SHARE) + lane : lds + threadIdx.x;
 		for (uint32_t j = (uint32_t)lane; j < n_def; j += 64u) exact_walk_entry<SceneLds, ANY>(ss, tp, tp.defer[begin + j], xstack, cls, own ? 64 : 256);
 	}
 	if (tp.part) {

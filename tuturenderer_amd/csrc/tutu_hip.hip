@@ -508,13 +508,13 @@ void launch_trace(TutuCtx* c, hipStream_t s, int grid, const TraceParams& tp) {
 		dim3 gf = g;
 		unsigned ldsf = lds;
 		if (!ANY) {
-			// closest hit: the kernel's share tables (26 KB of static LDS) decide how many blocks a CU holds; the exact walk's
+			// closest hit: the kernel's share tables (14 KB of static LDS) and 92 registers decide how many blocks a CU holds; the exact walk's
 			// stack moves into them when it fits (device_shade.h: TUTU_FLAT_OWN_STACK), and the grid is what is resident at once
 			if (c->ktrace_entries <= TUTU_FLAT_OWN_STACK) {
 				tf.stack_entries = 0;
 				ldsf = lds - (unsigned)((size_t)c->ktrace_entries * 256 * sizeof(int));
 			}
-			const unsigned per_block = ldsf + 26240u + 64u;
+			const unsigned per_block = ldsf + 13952u + 64u;
 			const int bpc = (int)std::max(1u, std::min(5u, (160u * 1024u) / per_block));  // (92 registers: five waves per SIMD)
 			gf = dim3((unsigned)std::min(grid, c->n_cu * bpc));
 		}
