@@ -1332,7 +1332,8 @@ __global__ void __launch_bounds__(256, ANY ? 8 : 5) k_trace_flat(TraceParams tp,
 		w_node_steps += (uint32_t)fs.n;
 		// ---- phase 2: the leaves behind the boxes that were hit
 		// one leaf -- an object, or the two triangles of a quad -- against the lane's ray
-		auto test_leaf = [&](int k) {
+		auto test_leaf = [&](int k) -> uint32_t {  // (returns the objects tested: the unit of a leaf step in the work counters)
+			uint32_t tested = 0;
 			int item = ~s_ref[k], second = 0;
 			if (!SPH && sc.pair_leaves) {
 				second = item >> TUTU_PAIR_BITS;
@@ -1340,6 +1341,7 @@ __global__ void __launch_bounds__(256, ANY ? 8 : 5) k_trace_flat(TraceParams tp,
 			}
 			for (;;) {
 				n_leaves++;
+				tested++;
 				int ti;
 				float t, u, v;
 				const bool h = leaf_test<SPH>(ss, item, r, ti, t, u, v);
@@ -1361,6 +1363,7 @@ __global__ void __launch_bounds__(256, ANY ? 8 : 5) k_trace_flat(TraceParams tp,
 				item = second - 1;
 				second = 0;
 			}
+			return tested;
 		};
 		if (!ANY && tp.flat_share) {
 			// Closest hit: the wave's (ray, leaf) pairs are dealt to its lanes.  A ray hits 1.7 boxes on average and 4-5 at most:
@@ -1391,7 +1394,7 @@ __global__ void __launch_bounds__(256, ANY ? 8 : 5) k_trace_flat(TraceParams tp,
 				__builtin_amdgcn_wave_barrier();
 				__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 				for (uint32_t j = (uint32_t)lane; j < ((n_items + 63u) & ~63u); j += 64u) {
-					w_leaf_steps++;
+					uint32_t tested = 0;
 					// the pair's ray: from the registers of the lane that owns it (ds_bpermute, every lane of the wave taking part --
 					// no table in LDS: the blocks of the other stages in flight need the room, see k_trace_flat's header)
 					const uint32_t it = j < n_items ? (uint32_t)w_item[j] : 0u;
@@ -1417,6 +1420,7 @@ __global__ void __launch_bounds__(256, ANY ? 8 : 5) k_trace_flat(TraceParams tp,
 						}
 						for (;;) {
 							n_leaves++;
+							tested++;
 							int ti;
 							float t, u, v;
 							if (leaf_test<SPH>(ss, item, q, ti, t, u, v) && (t < bt || (t == bt && ti < btri))) {
@@ -1433,6 +1437,7 @@ __global__ void __launch_bounds__(256, ANY ? 8 : 5) k_trace_flat(TraceParams tp,
 						}
 						w_res[j] = make_float4(bt, bu, bv, __int_as_float(btri));
 					}
+					w_leaf_steps += (__ballot(tested > 1u) != 0ull) ? 2u : 1u;  // (a quad's two triangles are two steps)
 				}
 				__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
 				__builtin_amdgcn_wave_barrier();
@@ -1449,13 +1454,14 @@ __global__ void __launch_bounds__(256, ANY ? 8 : 5) k_trace_flat(TraceParams tp,
 		}
 		// every box that was hit (shadow rays: every box within the limit, until the first blocker)
 		while (__ballot(mask != 0u) != 0ull) {
-			w_leaf_steps++;
+			uint32_t tested = 0;
 			if (mask != 0u) {
 				const int k = __ffs((int)mask) - 1;
 				mask &= mask - 1u;
-				test_leaf(k);
+				tested = test_leaf(k);
 				if (ANY && blocked) mask = 0u;
 			}
+			w_leaf_steps += (__ballot(tested > 1u) != 0ull) ? 2u : 1u;
 		}
 		// ---- finish
 		if (act) {
