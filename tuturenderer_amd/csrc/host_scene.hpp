@@ -131,6 +131,7 @@ struct HostScene {
 	uint32_t n_wide = 0;               // wide nodes (= wnodes.size() for the host build; the device build leaves wnodes empty)
 	bool device_walked = false;        // the walked tree was left to the device (tutu_hip.hip: device_build_walked): no SAH tree, no host wide tree
 	double wide_margin = 0;            // quantisation margin of the wide tree's boxes (host_scene.cpp: wide_frame)
+	bool wide_greedy = false;          // the wide tree was collapsed greedily by surface area (host_scene.cpp: build_wide)
 	float wide_origin_lo[3], wide_origin_hi[3];  // ray origins for which the quantisation margin was sized (others are not "plain")
 	uint32_t depth;  // max over both trees: sizes the traversal stack
 	float eta;

@@ -1410,6 +1410,10 @@ int tutu_hip_get_option(TutuCtx* c, const char* name, int* value) {
 		*value = (int)c->hs.wide_depth;
 		return TUTU_OK;
 	}
+	if (strcmp(name, "wide_greedy") == 0) {  // the host's wide tree was collapsed greedily by surface area (host_scene.cpp: build_wide)
+		*value = c->hs.wide_greedy ? 1 : 0;
+		return TUTU_OK;
+	}
 	if (strcmp(name, "fast_depth") == 0) {  // depth of the walked (SAH) tree; the reference tree's is TutuBvhInfo::depth
 		*value = (int)c->hs.fast_depth;
 		return TUTU_OK;
