@@ -16,6 +16,7 @@ FORMS = {
     "binary": {"TUTU_WIDE": "0"},
     "wide_short_lds_stack": {"TUTU_WIDE": "2", "TUTU_WIDE_LDS_STACK": "6"},   # most pushes land in the HBM tier
     "binary_two_tier_stack": {"TUTU_WIDE": "0", "TUTU_LDS_STACK_MAX": "6"},
+    "wide_greedy_collapse": {"TUTU_WIDE": "2", "TUTU_WIDE_COLLAPSE": "1"},    # the wide tree collapsed by surface area (host_scene.cpp)
 }
 
 
