@@ -1242,8 +1242,14 @@ TUTU_DEV void trace_persistent(const S& ss, const TraceParams& tp, int* stack, c
 // refills around it.  Sixteen box tests in a row cost no more than those fifteen, need none of that, and run on ALL lanes:
 //   phase 1   every lane tests its ray against every leaf box of the walked tree (FlatScene: kernel arguments, read by
 //             scalar loads -- the boxes are wave-uniform) and keeps a bit per box hit
-//   phase 2   while any lane has a bit left: the lane's next leaf -- one object, or the two triangles of a quad -- is tested
-//             with the reference's triangle test; a candidate is validated against the reference's leaf box (device_trace.h)
+//   phase 2   the leaves behind the boxes hit -- one object, or the two triangles of a quad -- with the reference's triangle
+//             test; a candidate is validated against the reference's leaf box (device_trace.h).  Any hit: while any lane has
+//             a bit left, the lane's next leaf (it stops at its first blocker).  Closest hit (knob flat_share): the wave's
+//             (ray, leaf) pairs are DEALT to its lanes -- see there.
+// LDS and registers are the other stages' too: with four passes in flight a CU holds blocks of several kernels, and a block of
+// this one keeps 14 KB of tables + the 4.6 KB scene copy (the pair rays come from their owners' registers by ds_bpermute, the
+// exact walk's stack lives in the wave's own table once its loop is over): five blocks per CU at 94 registers.  Each of those
+// steps was worth more to the frame than to this kernel.
 // No distance pruning at all on the closest-hit side: the minimum over every candidate whose boxes are hit is the reference's
 // recursion (BVH.hpp:145-167) for a plain ray -- boxes that contain a leaf box are hit whenever it is -- so DESIGN.md section 4's
 // hypothesis is not needed here.  (Measured and dropped: skipping a further box where the rounding-error bound of the
@@ -1257,7 +1263,7 @@ TUTU_DEV void trace_persistent(const S& ss, const TraceParams& tp, int* stack, c
 #define TUTU_FLAT_OWN_STACK 12  // entries of the exact walk's stack that fit a wave's table of candidates (192 float4 = [12][64] ints)
 template <bool ANY, bool SPH>
 __global__ void __launch_bounds__(256, ANY ? 8 : 5) k_trace_flat(TraceParams tp, FlatScene fs) {
-	extern __shared__ int lds[];  // [stack entries of the exact walk][256 lanes] | scene copy | class table
+	extern __shared__ int lds[];  // [stack entries of the exact walk][256 lanes] (closest hit: none, see the end) | scene copy | class table
 	const SceneLds ss = stage_scene_lds(tp.sc, lds, tp.stack_entries);
 	uint8_t* cls = reinterpret_cast<uint8_t*>(ss.end());
 	__shared__ int s_ref[TUTU_FLAT_MAX];
