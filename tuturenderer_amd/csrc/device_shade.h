@@ -285,6 +285,11 @@ enum ShadeMode { SHADE_FIRST = 0, SHADE_LAMBERT = 1, SHADE_MIRROR = 2, SHADE_REF
 template <int MODE, int TAB, bool EXT>
 __global__ void __launch_bounds__(256) k_shade(PassParams pp) {
 	constexpr bool FIRST = MODE == SHADE_FIRST;
+	// The shade stage's waves mostly wait for memory; with four passes in flight they share their SIMDs with traversal waves that
+	// issue vector instructions back to back.  At the highest wave priority a shade wave's next loads go out as soon as it can issue
+	// them (Cornell frame +0.7 % over six same-box A/B runs, the other configs unchanged; the reverse -- the traversal kernels at
+	// high priority -- costs 2.5 %: profiles/sessions/r04_s41.sh, r04_s42.sh).
+	__builtin_amdgcn_s_setprio(3);
 	const SceneDev& sc = pp.sc;
 	extern __shared__ float4 shade_lds[];
 	const ShadeTabs tb = stage_shade_tabs<TAB>(sc, shade_lds, pp.n_mats);
