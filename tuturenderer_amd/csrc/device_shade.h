@@ -63,6 +63,17 @@ struct Records {  // one of the two record sets of a work set (structure of arra
 
 // LDS staging area of one wave: [field][lane] float4
 enum StageField { SF_A = 0, SF_B, SF_D, SF_H, SF_L, SF_G, SF_S, SF_P, SF_E, SF_S2, SF_COUNT };
+// Record streams -- written once by one stage, read once by the next, gigabytes per pass -- are stored with the non-temporal
+// hint: +1.6 ... 2.0 % on every config (c2 3011 -> 3073, c3 1418 -> 1446, c4 623 -> 633, c5 1313 -> 1336 Msamples/s, same box).  The
+// hint on the LOADS of the same streams is a loss (the traversal's refill loads: broom stand-in -12 % without the stores' hint,
+// even with it; the shade stage's loads: -1 ... -1.5 % on the bunny stand-in and the veach room; the hint on the list entries and
+// the finished radiances as well: no further gain): profiles/sessions/r04_s43.sh ... r04_s45.sh.
+typedef float tutu_v4f __attribute__((ext_vector_type(4)));
+TUTU_DEV void st_stream(float4* p, const float4& x) {
+	tutu_v4f v;
+	v.x = x.x; v.y = x.y; v.z = x.z; v.w = x.w;
+	__builtin_nontemporal_store(v, reinterpret_cast<tutu_v4f*>(p));
+}
 #define TUTU_STAGE_BYTES_PER_BLOCK (4 * SF_COUNT * 64 * 16)  // 4 waves
 
 struct Totals {  // accumulated over a render call
@@ -730,18 +741,18 @@ __global__ void __launch_bounds__(256) k_shade(PassParams pp) {
 		const uint32_t out0 = chunk * 64u;
 		if ((uint32_t)lane < n_surv) {
 			const uint32_t so = out0 + lane;
-			pp.out.A[so] = stg[SF_A * 64 + src];
-			pp.out.L[so] = stg[SF_L * 64 + src];
+			st_stream(&pp.out.A[so], stg[SF_A * 64 + src]);
+			st_stream(&pp.out.L[so], stg[SF_L * 64 + src]);
 			if (MODE != SHADE_TERMINAL) {
-				pp.out.B[so] = stg[SF_B * 64 + src];
-				pp.out.D[so] = stg[SF_D * 64 + src];
-				pp.out.H[so] = stg[SF_H * 64 + src];
-				pp.out.G[so] = stg[SF_G * 64 + src];
-				if (keep_tp) pp.out.E[so] = stg[SF_E * 64 + src];
+				st_stream(&pp.out.B[so], stg[SF_B * 64 + src]);
+				st_stream(&pp.out.D[so], stg[SF_D * 64 + src]);
+				st_stream(&pp.out.H[so], stg[SF_H * 64 + src]);
+				st_stream(&pp.out.G[so], stg[SF_G * 64 + src]);
+				if (keep_tp) st_stream(&pp.out.E[so], stg[SF_E * 64 + src]);
 			}
-			pp.out.S[so] = stg[SF_S * 64 + src];
-			pp.out.P[so] = stg[SF_P * 64 + src];
-			if (any_alt) pp.out.S2[so] = stg[SF_S2 * 64 + src];
+			st_stream(&pp.out.S[so], stg[SF_S * 64 + src]);
+			st_stream(&pp.out.P[so], stg[SF_P * 64 + src]);
+			if (any_alt) st_stream(&pp.out.S2[so], stg[SF_S2 * 64 + src]);
 		}
 		pp.out.key[out0 + lane] = (uint8_t)key_r;
 		pp.out.V[out0 + lane] = (uint8_t)TUTU_V_BLOCKED;
@@ -1190,7 +1201,7 @@ TUTU_DEV void trace_persistent(const S& ss, const TraceParams& tp, int* stack, c
 		// ---- finish
 		if (cur == TUTU_TRAV_DONE && pend == TUTU_TRAV_IDLE) {
 			if (!ANY) {
-				tp.hitC[slot] = make_float4(best_t, best_u, best_v, __int_as_float(best_tri));
+				st_stream(&tp.hitC[slot], make_float4(best_t, best_u, best_v, __int_as_float(best_tri)));
 				tp.hitK[slot] = best_tri >= 0 ? tri_class[best_tri] : (uint8_t)TUTU_CLASS_MISS;
 			} else if (fl & TUTU_KEY_FINAL) {  // the path ended with this request: its sample is finished
 				float4 F = make_float4(Lpre.x, Lpre.y, Lpre.z, 0.f);
@@ -1477,7 +1488,7 @@ __global__ void __launch_bounds__(256, ANY ? 8 : 5) k_trace_flat(TraceParams tp,
 		// ---- finish
 		if (act) {
 			if (!ANY) {
-				tp.hitC[slot] = make_float4(best_t, best_u, best_v, __int_as_float(best_tri));
+				st_stream(&tp.hitC[slot], make_float4(best_t, best_u, best_v, __int_as_float(best_tri)));
 				tp.hitK[slot] = best_tri >= 0 ? cls[best_tri] : (uint8_t)TUTU_CLASS_MISS;
 			} else if (fl & TUTU_KEY_FINAL) {  // the path ended with this request: its sample is finished
 				float4 F = make_float4(Lpre.x, Lpre.y, Lpre.z, 0.f);
