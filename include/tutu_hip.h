@@ -377,9 +377,10 @@ int tutu_hip_quantise(TutuCtx* ctx, uint32_t n, const float* values, int32_t* le
  *   "trace_lds_bytes", "work_paths_mi", "growing", "grow_ms".
  *   The knobs tutu_hip_create consumes (tree choice, LDS carve-up: "wide", "wide_min_mb", "wide_early", "wide_early_max_mb", "lds_stack_max",
  *   "wide_lds_stack", "trace_bpc") are refused by tutu_hip_set_option afterwards (TUTU_E_INVALID) unless the value is the one in effect.
- *   Environment only (host tree build): TUTU_WIDE_COLLAPSE=1 collapses the host-built wide tree greedily by surface area instead of
- *   taking the grandchildren of every second binary level (read-only fact "wide_greedy"; DESIGN.md section 6: +3 % on the broom stand-in,
- *   +2 % on the veach room, -3 % on the bunny stand-in, same hits).
+ *   Environment only (host tree build): TUTU_WIDE_COLLAPSE = 1 collapses the host-built wide tree greedily by surface area, 0 takes the
+ *   grandchildren of every second binary level; unset: greedy when the walked tree holds more than 1.5 references per object, i.e. was built over
+ *   clipped references (read-only fact "wide_greedy"; DESIGN.md section 6: +3 % on the broom stand-in, +2 % on the veach room, -3 % on the bunny
+ *   stand-in, same hits).
  *   Testing aid, read at every device allocation rather than at create: TUTU_DEBUG_FILL=<0..255> fills every fresh allocation
  *   with that byte (no result may depend on what hipMalloc hands out; tests/test_hip_wide.py).
  * tutu_hip_get_option reports the effective value of any of them, plus the read-only facts "sah_tree", "lds_scene"

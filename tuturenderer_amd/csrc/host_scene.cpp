@@ -523,7 +523,7 @@ namespace {
 
 // t: build tree (pre-order, t[0] = root, must be an inner node); leaf_ref(bn) = the device reference of leaf bn
 template <typename LeafRef>
-static bool build_wide(const std::vector<BuildNode>& t, const LeafRef& leaf_ref, HostScene& hs) {
+static bool build_wide(const std::vector<BuildNode>& t, const LeafRef& leaf_ref, HostScene& hs, bool greedy_default) {
 	hs.wnodes.clear();
 	hs.has_wide = false;
 	hs.n_wide = 0;
@@ -532,14 +532,17 @@ static bool build_wide(const std::vector<BuildNode>& t, const LeafRef& leaf_ref,
 	if (!wide_frame(t[0].pmin, t[0].pmax, &m, hs.wide_origin_lo, hs.wide_origin_hi)) return false;
 	hs.wide_margin = m;
 	auto is_inner = [&](int32_t bn) { return t[bn].left >= 0 || t[bn].right >= 0; };
-	// Collapse, TUTU_WIDE_COLLAPSE: 0 (default) = the grandchildren of a binary node: slots (0, 1) the children of its left child,
-	// (2, 3) of its right child; 1 = greedy: the inner child with the largest surface is replaced by its two children, in place,
-	// until four slots are in use (the slots keep the binary tree's left-to-right order, so neighbours in a pair are neighbours
-	// in space and the kernel's pairwise visiting order stays a good guess -- it is only ever a guess, hits do not depend on it).
-	// Round 4, same box, pairs / greedy: broom stand-in 621 / 640 Msamples/s (40.3 -> 38.3 nodes per closest-hit ray), veach room
-	// 1297 / 1320, bunny stand-in 1410 / 1370 (same visits, the any-hit walk's lanes less busy: 0.59 -> 0.51).  The surface-area
-	// estimate of the visits (printed with TUTU_BUILD_TIMING) does not tell the scenes apart -- it favours the greedy form by 7 %,
-	// 4 % and 3 % in that order -- so the choice stays with the form that was validated over three rounds, and a knob.
+	// Collapse, TUTU_WIDE_COLLAPSE: 0 = the grandchildren of a binary node: slots (0, 1) the children of its left child, (2, 3) of
+	// its right child; 1 = greedy: the inner child with the largest surface is replaced by its two children, in place, until
+	// four slots are in use (the slots keep the binary tree's left-to-right order, so neighbours in a pair are neighbours in
+	// space and the kernel's pairwise visiting order stays a good guess -- it is only ever a guess, hits do not depend on it).
+	// Round 4, same box, pairs / greedy: broom stand-in 621 / 640 Msamples/s (40.3 -> 38.3 nodes per closest-hit ray, 13.9
+	// references per triangle), veach room 1297 / 1320 (any-hit 15.4 -> 14.5 nodes, 2.1 references per triangle), bunny stand-in
+	// 1410 / 1370 (1.0 references per triangle: the visits stay the same -- 13.3 / 13.0, 10.0 / 9.9 -- and the any-hit walk's lanes are
+	// less busy, 0.59 -> 0.51).  The greedy form pays where the tree was built over CLIPPED references -- pieces of uneven size whose
+	// boxes barely overlap -- and that is the default's rule: greedy when there are more than 1.5 references per object.  (The
+	// surface-area estimate of the visits, printed with TUTU_BUILD_TIMING, does not tell the scenes apart: it favours the greedy
+	// form by 7 %, 4 % and 3 % in the order veach room, bunny, broom.)
 	struct Item { int32_t bn; int32_t id; uint32_t level; };
 	auto sa_of = [&](int32_t bn) {
 		const BuildNode& b = t[bn];
@@ -602,7 +605,7 @@ static bool build_wide(const std::vector<BuildNode>& t, const LeafRef& leaf_ref,
 	std::vector<std::array<int32_t, 4>> kids;  // per wide node: build-node index of each child (-1 = unused)
 	uint32_t max_level = 1;
 	{
-		const bool greedy = getenv("TUTU_WIDE_COLLAPSE") && atoi(getenv("TUTU_WIDE_COLLAPSE")) == 1;
+		const bool greedy = getenv("TUTU_WIDE_COLLAPSE") ? atoi(getenv("TUTU_WIDE_COLLAPSE")) == 1 : greedy_default;
 		const double cost = collapse_pass(greedy, queue, kids, max_level);
 		if (getenv("TUTU_BUILD_TIMING")) {
 			std::vector<Item> q2;
@@ -980,7 +983,7 @@ int build_host_scene(const TutuSceneDesc* d, HostScene& hs, HostBuildHooks* hook
 				build_wide(sah, [&](int32_t bn) -> int32_t {
 					const int32_t leaf = hs.leaf_of_orig[sah[bn].tri];
 					return obj_sph[sah[bn].tri] >= 0 ? ~(leaf | kSphereBit) : ~leaf;
-				}, hs);
+				}, hs, hs.n_refs > n + n / 2);  // greedy where the tree was built over clipped references (see build_wide)
 				lap("wide tree (collapse + quantise)");
 			}
 		}
