@@ -74,6 +74,53 @@ def effective_cores():
     return {"os_cpu_count": os.cpu_count(), "affinity": aff, "cgroup_quota": quota, "effective": eff}
 
 
+class BusyProbe:
+    """gpu_busy_percent of the amdgpu cards (sysfs, what rocm-smi --showuse prints), sampled every 50 ms by a thread while the timed
+    region runs: a cross-check for a driver-side sampler that polls too slowly to catch a few seconds of GPU work."""
+
+    def __init__(self):
+        import glob
+        import threading
+
+        self.files = sorted(glob.glob("/sys/class/drm/card*/device/gpu_busy_percent"))
+        self.samples = []
+        self._stop = threading.Event()
+        self._th = threading.Thread(target=self._run, daemon=True)
+
+    def _read(self):
+        best = None
+        for f in self.files:
+            try:
+                v = int(open(f).read().strip())
+            except (OSError, ValueError):
+                continue
+            best = v if best is None else max(best, v)
+        return best
+
+    def _run(self):
+        while not self._stop.is_set():
+            v = self._read()
+            if v is not None:
+                self.samples.append(v)
+            self._stop.wait(0.05)
+
+    def __enter__(self):
+        if self.files:
+            self._th.start()
+        return self
+
+    def __exit__(self, *a):
+        self._stop.set()
+        if self.files:
+            self._th.join(timeout=1.0)
+
+    def summary(self):
+        if not self.samples:
+            return {"samples": 0, "note": "no readable /sys/class/drm/card*/device/gpu_busy_percent on this host"}
+        return {"samples": len(self.samples), "max_percent": max(self.samples), "mean_percent": sum(self.samples) / len(self.samples),
+                "note": "max over the host's amdgpu cards of sysfs gpu_busy_percent, every 50 ms during the timed steps"}
+
+
 def cpu_baseline(scene, cfg, target_seconds=12.0):
     """Time the reference integrator on the host cores: a first 1-spp frame calibrates, then one frame with as many
     spp as fit ~target_seconds.  Only this function touches oracle/."""
@@ -231,18 +278,33 @@ def main():
     for _ in range(args.warmup):
         step()
     fence()
-    t0 = time.perf_counter()
-    agg = None
-    for _ in range(args.steps):
-        st = step()
-        if agg is None:
-            agg = {k: 0 for k in st}
-        for k in st:
-            agg[k] += st[k]
-    fence()
-    dt = time.perf_counter() - t0
+    probe = BusyProbe()
+    with probe:
+        t0 = time.perf_counter()
+        agg = None
+        for _ in range(args.steps):
+            st = step()
+            if agg is None:
+                agg = {k: 0 for k in st}
+            for k in st:
+                agg[k] += st[k]
+        fence()
+        dt = time.perf_counter() - t0
+    # Proof that the collective library saw every rank: a SUM all-reduce of 1 over the process group (backend nccl = RCCL),
+    # and every rank's own time for the timed steps (the line's ms_per_step is their maximum).
+    rank_ms = [dt / args.steps * 1e3]
+    rccl_ranks = None
+    if distributed or self_loop:
+        cdev = dev if args.backend == "nccl" else torch.device("cpu")
+        one = torch.ones(1, dtype=torch.int32, device=cdev)
+        dist.all_reduce(one, op=dist.ReduceOp.SUM)
+        rccl_ranks = int(one.item())
+        mine_ms = torch.tensor([dt / args.steps * 1e3], dtype=torch.float64, device=cdev)
+        every = [torch.zeros_like(mine_ms) for _ in range(dist.get_world_size())]
+        dist.all_gather(every, mine_ms)
+        rank_ms = [float(x.item()) for x in every]
     if distributed:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev if args.backend == "nccl" else torch.device("cpu"))
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
 
@@ -298,7 +360,7 @@ def main():
         # committed PMC collection gives the share of issue cycles, `valu_issue_frac` below), pricing them against 8 TB/s says
         # nothing.  The top-level kernel is then the HBM-bound one, k_shade; otherwise the kernel with the most exclusive time.
         by_time = max(src, key=lambda k: src[k]["ms"])
-        dom = "k_shade" if lds_scene else by_time
+        dom = by_time  # (round 5: always by time; k_shade's own figures are under per_kernel.k_shade whoever dominates)
         top = priced(src, dom)
         # measured HBM traffic of that kernel: a committed PMC collection (profiles/make_traffic.py), stored per unit
         # together with the config and pass size it was collected at; refused when either does not match this run
@@ -329,8 +391,8 @@ def main():
                                                "l2_hit_rate", "wave_cycles_waiting") if m in e}
                 issue_peak = tj2.get("issue_peak_valu_per_simd_cycle")
         roofline = {"bound": "hbm", "kernel": dom, "dominant_by_time": by_time,
-                    "kernel_note": ("scene in LDS: the traversal kernels are VALU-issue bound (per_kernel.*.pmc.valu_issue_frac), "
-                                    "k_shade is the HBM-bound kernel") if lds_scene else "the kernel with the most exclusive time",
+                    "kernel_note": "the kernel with the most exclusive time" + ("; scene in LDS: the traversal kernels touch HBM for 48 B per ray only and are "
+                                    "VALU-issue bound (per_kernel.*.pmc.valu_issue_frac), k_shade is the HBM-bound kernel (per_kernel.k_shade)" if lds_scene else ""),
                     "achieved": top["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": top["frac"],
                     "traffic": traffic, "traffic_note": traffic_note,
                     "avg_launch_ms": top["avg_launch_ms"], "launches": top["launches"], "units_per_launch": top["units_per_launch"],
@@ -374,7 +436,7 @@ def main():
             else:
                 roofline["frac_kind"] = "ALGORITHMIC bytes incl. L2-served node / triangle bytes (no PMC collection for this pass size): an upper bound of the HBM fraction"
         else:
-            roofline["frac_kind"] = "algorithmic HBM bytes of k_shade (the scene is served from LDS)"
+            roofline["frac_kind"] = f"algorithmic HBM bytes of {dom} (the scene is served from LDS)"
         for k, e in roofline["per_kernel"].items():
             if e.get("pmc") and "valu_per_simd_cycle" in e["pmc"]:
                 e["pmc"]["valu_issue_frac_vs_guide_peak_0.50"] = e["pmc"]["valu_per_simd_cycle"] / 0.5
@@ -436,7 +498,9 @@ def main():
                        "timed": "tutu_hip_render_device without per-launch event pairs (knob kernel_events = 0: instrumentation only, 2.7 % of a "
                                 "frame); scene, BVH and work buffers resident in HBM, frame left in HBM (bench contract); "
                                 "see `drop_in` for the SURVEY 8d bracket (create + H2D + render + D2H + destroy)",
-                       "knobs": options, "env": {k: v for k, v in os.environ.items() if k.startswith("TUTU_")}},
+                       "knobs": options, "env": {k: v for k, v in os.environ.items() if k.startswith("TUTU_")},
+                       "gpu_busy_probe": probe.summary()},
+            "rccl_ranks": rccl_ranks, "collective_backend": (args.backend if (distributed or self_loop) else None), "rank_ms_per_step": rank_ms,
             "frame": frame_check,
             "roofline": roofline,
         }

@@ -254,10 +254,14 @@ int tutu_hip_render_multi(TutuCtx* const* ctxs, int32_t n, const TutuCameraFrame
                           float* out_rgb, TutuStats* stats);
 /* Same, with the frame left in DEVICE memory of ctxs[0]'s device (d_out_rgb: n_items*3 floats there).  The gather is on the
  * device side -- what replaces the shared frame buffer the reference's threads write into (PathTracing.hpp:393-429): every
- * context renders its piece into its own device's memory, the pieces travel to ctxs[0]'s device by peer copies (xGMI inside a
- * node) into one buffer in context order, and one kernel un-tiles it into d_out_rgb on `stream` (a hipStream_t of that
- * device, NULL = ctxs[0]'s own); the call returns after that kernel.  tutu_hip_render_multi is this + one frame-sized D2H
- * copy.  (bench.py's process-per-GPU form does the same with one grouped RCCL send / recv: tuturenderer_amd/dist.py.) */
+ * context renders its piece into its own device's memory, the pieces travel to ctxs[0]'s device into one buffer in context
+ * order, and one kernel un-tiles it into d_out_rgb on `stream` (a hipStream_t of that device, NULL = ctxs[0]'s own); the call
+ * returns after that kernel.  How the pieces travel (option "gather_rccl" of ctxs[0]: 0 / 1 / 2; read-only "gather_path",
+ * "rccl_available", "peer_access"): contexts on SEVERAL devices -- ONE grouped RCCL exchange over xGMI (ncclCommInitAll over
+ * the distinct devices, ncclGroupStart ... ncclSend / ncclRecv ... ncclGroupEnd; RCCL is looked up at run time, the
+ * communicators are kept for the next frame); contexts that share a device, RCCL absent or switched off -- peer / local copies,
+ * with peer access enabled explicitly.  tutu_hip_render_multi is this + one frame-sized D2H copy.  (bench.py's
+ * process-per-GPU form does the same exchange through torch.distributed: tuturenderer_amd/dist.py.) */
 int tutu_hip_render_multi_device(TutuCtx* const* ctxs, int32_t n, const TutuCameraFrame* cam, const TutuRenderParams* params,
                                  float* d_out_rgb, void* stream, TutuStats* stats);
 

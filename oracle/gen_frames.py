@@ -10,6 +10,8 @@ Run in the build container (needs /root/reference and oracle/_ref/libtutu_ref.so
     c3  bunny stand-in 1024x1024, 256 spp (configs[2])                                 -> tests/golden/frame_c3.npz
     c4  broom stand-in 1600x900, 16 spp   (configs[3] at a reduced spp: the reference traces 0.05 Msamples/s here)
                                                                                         -> tests/golden/frame_c4.npz
+    c1  Cornell box 800x800, 16 spp       (configs[0], the reference's own CPU-runnable case)   -> tests/golden/frame_c1.npz
+    c4_64  broom stand-in 1600x900, 64 spp (configs[3] at 64 of its 1024 spp, ~1 h of CPU)       -> tests/golden/frame_c4_64.npz
     native  Cornell box 128x128, 4096 spp with the reference's OWN std::mt19937 (no engine swap; SURVEY.md 8c/8d (ii)),
             from oracle/_ref/libtutu_ref_native.so                                      -> tests/golden/frame_native_cornell.npz
 
@@ -41,6 +43,10 @@ FRAMES = {
     "c5": dict(mk=lambda: scenes.veach_room(800, 600, small_light=False), key1=5, spp=512),
     "c3": dict(mk=lambda: scenes.bunny_box(1024, 1024), key1=3, spp=256),
     "c4": dict(mk=lambda: scenes.broom_room(1600, 900), key1=4, spp=16),
+    # round 5: the two thin pins.  c1 = BASELINE configs[0] whole; c4_64 = the broom frame at four times the spp of "c4" (same key,
+    # so its samples 0..15 are c4's): flip noise of single samples falls as 1/spp, a bias would not
+    "c1": dict(mk=lambda: scenes.cornell_box(800, 800), key1=1, spp=16),
+    "c4_64": dict(mk=lambda: scenes.broom_room(1600, 900), key1=4, spp=64),
 }
 NATIVE = dict(mk=lambda: scenes.cornell_box(128, 128), spp=4096)
 
@@ -87,7 +93,7 @@ def main(which):
         sc = cfg["mk"]()
         S = R.scene(sc)
         t0 = time.time()
-        rgb = S.render(cfg["spp"], pc.KEY0, cfg["key1"])
+        rgb = S.render(cfg["spp"], pc.KEY0, cfg["key1"], nthreads=int(os.environ.get("TUTU_GEN_THREADS", "0")) or None)
         dt = time.time() - t0
         S.close()
         n = sc["width"] * sc["height"] * cfg["spp"]

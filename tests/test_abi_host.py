@@ -133,7 +133,8 @@ def test_committed_bench_line_keeps_the_contract():
     # every kernel has its own entry with its bound; the exclusive (one pass in flight) figures are the top-level ones
     assert set(r["per_kernel"]) == {"k_trace_closest", "k_trace_any", "k_shade"} and r["kernel"] in r["per_kernel"]
     assert abs(r["per_kernel"][r["kernel"]]["frac"] - r["frac"]) < 1e-12 and "exclusive_kernel_ms_per_step" in r
-    assert r["lds_scene"] is True and r["kernel"] == "k_shade" and r["per_kernel"]["k_trace_closest"]["bound"] == "valu"
+    # (round 5: the top-level kernel is the one with the most exclusive time, whoever that is; k_shade's figures are always under per_kernel)
+    assert r["lds_scene"] is True and r["kernel"] == r.get("dominant_by_time", "k_shade") and r["per_kernel"]["k_trace_closest"]["bound"] == "valu"
     c = d["cpu_baseline"]
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in c, k

@@ -204,3 +204,36 @@ def test_multi_context_render_is_the_single_context_frame(built):
     finally:
         for c in ctxs:
             c.close()
+
+
+@pytest.mark.gpu
+def test_multi_context_gather_through_rccl_is_the_copy_gather(built):
+    """tutu_hip_render_multi_device's RCCL leg (round 5; csrc/rccl_gather.cpp): ncclCommInitAll over the contexts' distinct
+    devices and ONE ncclGroupStart ... ncclSend / ncclRecv ... ncclGroupEnd per frame into the first context's buffer -- what
+    SURVEY.md 8e names, in the C library itself (PathTracing.hpp:393-429 is what it replaces).  What one GPU allows: a
+    communicator of ONE rank, every piece by a self send / recv (knob gather_rccl = 2) -- the frame is the copy gather's and
+    the single context's, bit for bit, and the library says which path it took.  More than one device has executed nowhere."""
+    import tuturenderer_amd as tr
+    from tuturenderer_amd import scenes
+
+    sc = scenes.cornell_box(200, 136)
+    ctxs = [tr.Context(sc) for _ in range(3)]
+    try:
+        assert ctxs[0].get_option("rccl_available") == 1, "librccl.so.1 was not found by the library"
+        assert ctxs[0].get_option("gather_path") == -1 and ctxs[0].get_option("gather_rccl") == 1
+        one = ctxs[0].render(12, 0x5EED0001, 3, full_frame=False)
+        by_copies = tr.Context.render_multi(ctxs, 12, 0x5EED0001, 3)
+        assert ctxs[0].get_option("gather_path") == 0  # one device: the default keeps the local copies
+        ctxs[0].set_option("gather_rccl", 2)
+        by_rccl = tr.Context.render_multi(ctxs, 12, 0x5EED0001, 3)
+        assert ctxs[0].get_option("gather_path") == 1
+        again = tr.Context.render_multi(ctxs, 7, 3, 4)  # the communicator is kept for the next frame
+        assert ctxs[0].get_option("gather_path") == 1
+        assert by_rccl.tobytes() == one.tobytes() and by_copies.tobytes() == one.tobytes()
+        assert again.tobytes() == ctxs[1].render(7, 3, 4, full_frame=False).tobytes()
+        ctxs[0].set_option("gather_rccl", 0)
+        tr.Context.render_multi(ctxs, 3, 3, 4)
+        assert ctxs[0].get_option("gather_path") == 0
+    finally:
+        for c in ctxs:
+            c.close()

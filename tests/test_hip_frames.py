@@ -61,6 +61,15 @@ def test_c2_cornell_800x800_512spp_whole_frame_vs_reference_build(tr):
     assert share < 2e-2
 
 
+def test_c1_cornell_800x800_16spp_whole_frame_vs_reference_build(tr):
+    """BASELINE configs[0] -- config_cornellBox.txt's own CPU-runnable case at the harness size: 16 spp, key 1 (round 5)"""
+    from tuturenderer_amd import scenes
+
+    frame, want = _frame(tr, "c1", lambda: scenes.cornell_box(800, 800))
+    _, share = _compare("c1 cornell 16 spp", frame, want)
+    assert share < 2e-2
+
+
 def test_c5_veach_800x600_512spp_whole_frame_vs_reference_build(tr):
     """BASELINE configs[4]: Lambertian + PERFECT_REFRACTIVE + MICROFACET_R, wide tree"""
     from tuturenderer_amd import scenes

@@ -703,6 +703,11 @@ def test_two_ranks_on_one_gpu_gather_the_single_process_frame(tr, tmp_path):
            "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--dump", out]
     r = subprocess.run(cmd, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:]
+    import json
+
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    # the line proves that the collective library saw both ranks (an all-reduce of 1) and carries every rank's own time
+    assert line["n_gpus"] == 2 and line["rccl_ranks"] == 2 and line["collective_backend"] == "gloo" and len(line["rank_ms_per_step"]) == 2
     two = np.load(out)
     with tr.Context(scenes.cornell_box(800, 800)) as ctx:
         one = ctx.render(6, pc.KEY0, 1)
@@ -729,6 +734,11 @@ def test_rccl_process_group_self_loop_gathers_the_plain_frame(tr, tmp_path):
            "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-extras", "--dump", out]
     r = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:]
+    import json
+
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["rccl_ranks"] == 1 and line["collective_backend"] == "nccl" and len(line["rank_ms_per_step"]) == 1
+    assert line["config"]["gpu_busy_probe"]["samples"] >= 0
     looped = np.load(out)
     with tr.Context(scenes.cornell_box(800, 800)) as ctx:
         one = ctx.render(6, pc.KEY0, 1)

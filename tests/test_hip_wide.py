@@ -12,12 +12,18 @@ from oracle import parity_cases as pc
 pytestmark = pytest.mark.gpu
 
 FORMS = {
-    "wide": {"TUTU_WIDE": "2"},
+    "wide": {"TUTU_WIDE": "2", "TUTU_WIDE8": "0"},
     "binary": {"TUTU_WIDE": "0"},
-    "wide_short_lds_stack": {"TUTU_WIDE": "2", "TUTU_WIDE_LDS_STACK": "6"},   # most pushes land in the HBM tier
+    "wide_short_lds_stack": {"TUTU_WIDE": "2", "TUTU_WIDE8": "0", "TUTU_WIDE_LDS_STACK": "6"},   # most pushes land in the HBM tier
     "binary_two_tier_stack": {"TUTU_WIDE": "0", "TUTU_LDS_STACK_MAX": "6"},
-    "wide_greedy_collapse": {"TUTU_WIDE": "2", "TUTU_WIDE_COLLAPSE": "1"},    # the wide tree collapsed by surface area (host_scene.cpp)
+    "wide_greedy_collapse": {"TUTU_WIDE": "2", "TUTU_WIDE8": "0", "TUTU_WIDE_COLLAPSE": "1"},    # the wide tree collapsed by surface area (host_scene.cpp)
+    # round 5: the eight-wide tree (node groups, octant order, decoupled leaf stack; device_shade.h: trace_persistent8)
+    "wide8": {"TUTU_WIDE": "2", "TUTU_WIDE8": "1"},
+    "wide8_tight_column": {"TUTU_WIDE": "2", "TUTU_WIDE8": "1", "TUTU_WIDE8_LEAF_ROOM": "1"},    # lanes sit out node steps until leaf steps make room
+    "wide8_slots_in_tree_order": {"TUTU_WIDE": "2", "TUTU_WIDE8": "1", "TUTU_WIDE8_SLOTS": "0"},  # a poor visiting order must not change a hit
+    "wide8_long_rounds": {"TUTU_WIDE": "2", "TUTU_WIDE8": "1", "TUTU_WIDE8_INNER_STEPS": "9", "TUTU_WIDE8_INNER_STEPS_ANY": "7", "TUTU_WIDE8_LEAF_STEPS": "1"},
 }
+KNOB_ENVS = sorted({k for env in FORMS.values() for k in env})
 
 
 @pytest.fixture(scope="module")
@@ -50,7 +56,8 @@ def test_golden_rays_bit_exact_in_every_form(tr, port, monkeypatch, name, form):
         if name == "veach_slight":  # (the sphere scene is small enough to live in LDS: it keeps the binary LDS kernel)
             assert opt["lds_scene"] == 0
             assert opt["wide_tree"] == (1 if form.startswith("wide") else 0)
-            assert opt["stack_entries_hbm"] > 0 or form == "binary"
+            assert opt["wide8_tree"] == (1 if form.startswith("wide8") else 0)
+            assert opt["stack_entries_hbm"] > 0 or form == "binary" or form.startswith("wide8")  # (the eight-wide walk has no HBM tier)
         hits = ctx.trace_closest(O, D)
         h = hits["tri"] >= 0
         assert bit_equal(h.astype(np.uint8), z["scene.hit"])
@@ -108,7 +115,7 @@ def test_frames_are_identical_in_every_form(tr, monkeypatch):
 
     frames = {}
     for form, env in dict(FORMS, default={}).items():
-        for k in ("TUTU_WIDE", "TUTU_WIDE_LDS_STACK", "TUTU_LDS_STACK_MAX"):
+        for k in KNOB_ENVS:
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)

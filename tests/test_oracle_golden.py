@@ -182,6 +182,8 @@ FRAME_RECTS = {  # name -> (scene maker, a 24 x 4 pixel rectangle that sees geom
     "c5": (lambda s: s.veach_room(800, 600, small_light=False), (300, 330)),
     "c3": (lambda s: s.bunny_box(1024, 1024), (560, 700)),
     "c4": (lambda s: s.broom_room(1600, 900), (800, 560)),
+    "c1": (lambda s: s.cornell_box(800, 800), (380, 500)),          # round 5: BASELINE configs[0], 16 spp
+    "c4_64": (lambda s: s.broom_room(1600, 900), (800, 560)),       # round 5: the broom frame at 64 spp
 }
 
 

@@ -823,6 +823,7 @@ struct TraceParams {
 	int leaf_again;      // lanes that must still hold a leaf for a second leaf step in the round (65: never)
 	int xcd_map;         // 1: the blocks of one XCD (blockIdx mod 8) take adjacent ranges of the list
 	uint32_t* defer;     // >= *n_ptr entries: list positions of the rays that are not plain, per wave range (below)
+	int leaf_steps;      // trace_persistent8: leaf steps per round at most
 	int flat_share;      // k_trace_flat, closest hit: deal the wave's (ray, leaf) pairs to its lanes (knob "flat_share")
 };
 
@@ -1253,6 +1254,316 @@ TUTU_DEV void trace_persistent(const S& ss, const TraceParams& tp, int* stack, c
 }
 
 // ------------------------------------------------------------------------------------------------------------
+// Round 5: the persistent walk of the EIGHT-wide tree (GpuWide8Node, host_scene.hpp).  The memory-resident walks are bound by
+// the latency of the dependent node fetch (neither issue nor bandwidth is saturated at 7-8 waves per
+// SIMD), so the lever is fewer fetches per ray: one 80-B fetch decides eight children.  What this walk does differently from
+// trace_persistent<.., WIDE>:
+//   * NODE GROUPS.  The inner children of a node have consecutive ids, so the children still to visit are ONE stack entry,
+//     (child_base >> 3) << 8 | mask: at most one entry per tree level (a stack of depth + 1 entries instead of 3 depth + 3: no
+//     HBM tier).  The mask is kept in VISITING order: bit j = slot j ^ oct, oct = the ray's direction signs -- slots are
+//     assigned by octant on the host, so increasing j is front to back, roughly -- and the next child is __ffs of it.  No
+//     distances are kept, compared or sorted.  A step = take the next child of the top group (the new node's own group if it
+//     has one), fetch it, test its eight boxes, push at most one group.
+//   * LEAVES ARE DECOUPLED.  The hit leaf slots of a node are a group of their own, node << 8 | mask, on a second stack that
+//     grows DOWN from the top of the lane's LDS column; the node steps never look at it.  A lane keeps one leaf "in hand"
+//     (pend = node * 8 + slot) whose reference -- the ~object word in the node's second half -- was requested when it was
+//     taken, so the leaf step starts with the triangle fetch.  The walk of a ray is over when its node stack is down to the
+//     sentinel and no leaf is in hand (leaf stack not empty => a leaf in hand).  A lane whose two stacks are about to meet sits
+//     out the node steps until leaf steps have made room (the host sizes the column so that this cannot dead-lock:
+//     depth + 2 entries are never taken by leaves).
+// Exactness is untouched: the quantised boxes are conservative by the same margin under the same arithmetic as the four-wide
+// node's, every candidate is validated against the reference's leaf box, and the visiting order is only ever an order.
+#define TUTU_W8_WATCHDOG (1u << 26)  // rounds of one wave; a wave that gets here has a bug: it stops and reports it through `part`
+template <bool ANY, bool SPH, bool EARLY>
+TUTU_DEV void trace_persistent8(const SceneGlobal& ss, const TraceParams& tp, int* stack, const uint8_t* tri_class) {
+	const SceneDev& sc = tp.sc;
+	const int lane = __lane_id();
+	const unsigned long long lt_mask = (1ull << lane) - 1ull;
+	const uint32_t n = *tp.n_ptr;
+	const uint32_t n_waves = (gridDim.x * blockDim.x) >> 6;
+	uint32_t vblock = blockIdx.x;
+	if (tp.xcd_map) {  // the blocks of one XCD take adjacent ranges of the list (trace_persistent)
+		const uint32_t q = gridDim.x >> 3, rem = gridDim.x & 7u, x = blockIdx.x & 7u;
+		vblock = x * q + min(x, rem) + (blockIdx.x >> 3);
+	}
+	const uint32_t wave = (vblock * blockDim.x + threadIdx.x) >> 6;
+	const uint32_t per = (n + n_waves - 1) / n_waves;
+	const uint32_t begin = min(n, wave * per), end = min(n, begin + per);
+	uint32_t next = begin;
+	const float inf = __builtin_inff();
+	typedef __attribute__((address_space(3))) int lds_int;
+	lds_int* const lstack = (lds_int*)stack;
+	const int K = tp.stack_entries;
+	const int* const wleaf = reinterpret_cast<const int*>(sc.wnodes8);  // node id * 32 + 20 + slot: the leaf reference of a slot
+
+	lstack[0] = TUTU_TRAV_DONE;  // the sentinel of the node stack: an entry with an EMPTY mask (low byte 0)
+	int cur = TUTU_TRAV_IDLE;    // the node to visit (>= 0), TUTU_TRAV_DONE: node stack exhausted, TUTU_TRAV_IDLE: no ray
+	int sp = 1;                  // node stack: entries [0, sp)
+	int lp = K;                  // leaf stack: entries [lp, K)
+	int pend = -1;               // the leaf in hand: node * 8 + slot, -1 = none
+	int pref = 0;                // ... and its reference (requested when the leaf was taken)
+	uint32_t oct = 0;            // direction signs of the ray: the visiting order of a node's slots is increasing slot ^ oct
+	uint32_t slot = 0;
+	RayPre r = make_ray(mk1(0.f), mk1(1.f));
+	float best_t = FLT_MAX, best_u = 0.f, best_v = 0.f;
+	int best_tri = -1;
+	float lim = FLT_MAX;
+	uint32_t n_nodes = 0, n_leaves = 0;
+	uint32_t w_node_steps = 0, w_leaf_steps = 0, n_def = 0, rounds = 0;
+	float dis = 0.f;
+	float4 Lpre = make_float4(0.f, 0.f, 0.f, 0.f);
+	V3 contrib = mk1(0.f);
+	uint32_t fl = 0;
+	bool blocked = false;
+
+	for (;;) {
+		// ---- refill (as trace_persistent<.., WIDE>)
+		const unsigned long long idle = __ballot(cur == TUTU_TRAV_IDLE);
+		if (idle != 0ull && next < end && (__popcll(idle) >= tp.refill_min || __ballot(cur != TUTU_TRAV_IDLE && (cur != TUTU_TRAV_DONE || pend >= 0)) == 0ull)) {
+			const uint32_t i = next + (uint32_t)__popcll(idle & lt_mask);
+			bool exact = false;
+			if (cur == TUTU_TRAV_IDLE && i < end) {
+				slot = tp.list[i];
+				V3 so, lo = mk1(0.f);
+				if (!ANY) {
+					const float4 A = tp.rec.A[slot], B = tp.rec.B[slot];
+					slot = i;
+					so = mk(A.x, A.y, A.z);
+					r = make_ray(so, mk(B.x, B.y, B.z));
+					best_t = FLT_MAX; best_u = 0.f; best_v = 0.f; best_tri = -1;
+					lim = FLT_MAX;
+				} else {
+					fl = tp.rec.key[slot];
+					const float4 e0 = (fl & TUTU_KEY_ALT) ? tp.rec.S2[slot] : tp.rec.A[slot];
+					const float4 e1 = tp.rec.S[slot];
+					if (fl & TUTU_KEY_FINAL) {
+						Lpre = tp.rec.L[slot];
+						const float4 e2 = tp.rec.P[slot];
+						contrib = mk(e2.x, e2.y, e2.z);
+					}
+					so = mk(e0.x, e0.y, e0.z);
+					lo = mk(e1.x, e1.y, e1.z);
+					const V3 raydir = normalized(lo - so);  // isShadowRayBlocked, IIntegrator.hpp:135-137
+					dis = norm(lo - so);
+					r = make_ray(so, raydir);
+					lim = dis * TUTU_PRUNE_SLACK;
+					blocked = false;
+				}
+				oct = (r.nx ? 1u : 0u) | (r.ny ? 2u : 0u) | (r.nz ? 4u : 0u);
+				sp = 1;
+				lp = K;
+				pend = -1;
+				cur = TUTU_TRAV_DONE;
+				if (sc.root_ref != INT_MIN) {
+					if (!ray_is_plain(r) || !ray_fits_wide(sc, r)) {
+						exact = true;  // the reference's own tree, after the main loop; the lane stays DONE until this round's finish
+						if (ANY) blocked = true;
+					} else {
+						float te;
+						if (slab_plain(r, sc.root_min[0], sc.root_min[1], sc.root_min[2], sc.root_max[0], sc.root_max[1], sc.root_max[2], inf, te)) cur = 0;
+					}
+				}
+			}
+			const unsigned long long em = __ballot(exact);
+			if (em != 0ull) {
+				if (exact) tp.defer[begin + n_def + (uint32_t)__popcll(em & lt_mask)] = i;
+				n_def += (uint32_t)__popcll(em);
+			}
+			next += (uint32_t)__popcll(idle);
+		}
+		if (__ballot(cur != TUTU_TRAV_IDLE) == 0ull) break;
+		if (++rounds > TUTU_W8_WATCHDOG) {  // cannot happen; if it does the launch ends instead of hanging the device
+			n_nodes = 0xFFFFFFFFu;
+			break;
+		}
+
+		// ---- node steps
+#pragma unroll 1
+		for (int k = 0; k < tp.inner_steps; k++) {
+			const bool go = cur >= 0 && sp + 2 <= lp;  // (room for one group on either stack)
+			if (__ballot(go) == 0ull) break;
+			w_node_steps++;
+			if (go) {
+				n_nodes++;
+				const int node = cur;
+				const int top = lstack[(sp - 1) * 256];  // the top group of the node stack, requested with the node
+				const float4* np = sc.wnodes8 + 8 * (size_t)node;
+				const float4 q0 = np[0], q1 = np[1], q2 = np[2], q3 = np[3], q4 = np[4];
+				const float sx = r.inv.x * q0.w, sy = r.inv.y * q1.x, sz = r.inv.z * q1.y;  // 2^e / d (exact: powers of two)
+				const float ox = (q0.x - r.o.x) * r.inv.x, oy = (q0.y - r.o.y) * r.inv.y, oz = (q0.z - r.o.z) * r.inv.z;
+				const uint32_t mx = (uint32_t)(__float_as_int(r.inv.x) >> 31), my = (uint32_t)(__float_as_int(r.inv.y) >> 31), mz = (uint32_t)(__float_as_int(r.inv.z) >> 31);
+				// misses, slot order: bit s = the ray does NOT enter slot s's box within the limit.  Entry / exit planes picked by
+				// the direction sign for four slots at a time; the outcome is the SIGN of exit - entry (a subtraction and a funnel
+				// shift per slot instead of a compare and a select: te <= tx  <=>  tx - te is +0 or positive; no NaN for the rays
+				// this walk admits)
+				uint32_t miss = 0;
+#pragma unroll
+				for (int h = 1; h >= 0; h--) {
+					const uint32_t lxw = __float_as_uint(h ? q2.y : q2.x), lyw = __float_as_uint(h ? q2.w : q2.z), lzw = __float_as_uint(h ? q3.y : q3.x);
+					const uint32_t hxw = __float_as_uint(h ? q3.w : q3.z), hyw = __float_as_uint(h ? q4.y : q4.x), hzw = __float_as_uint(h ? q4.w : q4.z);
+					const uint32_t enx = (hxw & mx) | (lxw & ~mx), exx = (lxw & mx) | (hxw & ~mx);
+					const uint32_t eny = (hyw & my) | (lyw & ~my), exy = (lyw & my) | (hyw & ~my);
+					const uint32_t enz = (hzw & mz) | (lzw & ~mz), exz = (lzw & mz) | (hzw & ~mz);
+#pragma unroll
+					for (int c = 3; c >= 0; c--) {
+						const float ax = fmaf((float)((enx >> (8 * c)) & 0xFFu), sx, ox), bx = fmaf((float)((exx >> (8 * c)) & 0xFFu), sx, ox);
+						const float ay = fmaf((float)((eny >> (8 * c)) & 0xFFu), sy, oy), by = fmaf((float)((exy >> (8 * c)) & 0xFFu), sy, oy);
+						const float az = fmaf((float)((enz >> (8 * c)) & 0xFFu), sz, oz), bz = fmaf((float)((exz >> (8 * c)) & 0xFFu), sz, oz);
+						const float te = raw_max3(ax, ay, raw_max(az, 0.f));
+						const float tx = raw_min3(bx, by, raw_min(bz, lim));
+						miss = __builtin_amdgcn_alignbit(miss, __float_as_uint(tx - te), 31);  // miss = miss << 1 | sign
+					}
+				}
+				const uint32_t meta = __float_as_uint(q1.w);
+				uint32_t hm = ~(miss | (miss << 8)) & meta & 0xFFFFu;  // bits 0-7: inner slots hit, 8-15: leaf slots hit
+				// slot order -> visiting order: bit s moves to bit s ^ oct (three conditional delta swaps on both bytes at once)
+				{
+					const uint32_t c1 = (oct & 1u) ? 0x5555u : 0u, c2 = (oct & 2u) ? 0x3333u : 0u, c4 = (oct & 4u) ? 0x0F0Fu : 0u;
+					uint32_t t1 = ((hm >> 1) ^ hm) & c1;
+					hm ^= t1 | (t1 << 1);
+					t1 = ((hm >> 2) ^ hm) & c2;
+					hm ^= t1 | (t1 << 2);
+					t1 = ((hm >> 4) ^ hm) & c4;
+					hm ^= t1 | (t1 << 4);
+				}
+				const uint32_t PI = hm & 0xFFu;
+				uint32_t PL = hm >> 8;
+				// the next node: the first child of this node's own group, else of the group on top of the stack
+				const bool own = PI != 0u;
+				const uint32_t g = own ? (__float_as_uint(q1.z) | PI) : (uint32_t)top;
+				const int pos = own ? sp : sp - 1;  // where that group's remainder lives
+				const uint32_t m8 = g & 0xFFu;
+				const uint32_t sl = (uint32_t)(__ffs((int)m8) - 1) ^ oct;
+				const uint32_t rest = g & (g - 1u);
+				const bool empty = m8 == 0u;  // only the sentinel has an empty mask
+				lstack[pos * 256] = (int)rest;  // (harmless when the group is used up: the slot is free then)
+				sp = pos + (((rest & 0xFFu) != 0u || empty) ? 1 : 0);
+				cur = empty ? TUTU_TRAV_DONE : (int)(((g >> 5) & 0x03FFFFF8u) | (sl & 7u));
+				// the leaf slots hit: the first goes in hand if nothing is, the others onto the leaf stack as one group
+				if (PL != 0u) {
+					if (pend < 0) {
+						const uint32_t ls = (uint32_t)(__ffs((int)PL) - 1) ^ oct;
+						PL &= PL - 1u;
+						pend = node * 8 + (int)ls;
+						pref = wleaf[(size_t)node * 32 + 20 + ls];
+					}
+					if (PL != 0u) {
+						lp -= 1;
+						lstack[lp * 256] = (int)(((uint32_t)node << 8) | PL);
+					}
+				}
+			}
+		}
+
+		// ---- leaf steps: the leaf in hand; then the next one of the leaf stack's top group goes in hand
+#pragma unroll 1
+		for (int lk = 0; lk < tp.leaf_steps; lk++) {
+			const bool has = pend >= 0;
+			const unsigned long long m_leaf = __ballot(has);
+			if (m_leaf == 0ull || (lk > 0 && __popcll(m_leaf) < tp.leaf_again)) break;
+			w_leaf_steps++;
+			if (has) {
+				n_leaves++;
+				const int le = lstack[min(lp, K - 1) * 256];  // the top group of the leaf stack (if there is one), requested with the triangle
+				int ti;
+				float t, u, v;
+				const int item = ~pref;
+				if (EARLY) {
+					float4 lo, hi;
+					ss.lbox(SPH ? (item & ~TUTU_SPHERE_BIT) : item, lo, hi);
+					const bool h = leaf_test<SPH>(ss, item, r, ti, t, u, v);
+					bool cand;
+					if (ANY) cand = h && t < dis && !float_equal(t, dis);  // BVH.hpp:186
+					else cand = h && (t < best_t || (t == best_t && ti < best_tri));
+					float te;
+					if (cand && slab_plain(r, lo.x, lo.y, lo.z, hi.x, hi.y, hi.z, inf, te)) {  // validated (BVH.hpp:150; device_trace.h)
+						if (ANY) blocked = true;
+						else {
+							best_t = t; best_u = u; best_v = v; best_tri = ti;
+							lim = t * TUTU_PRUNE_SLACK_CLOSEST;
+						}
+					}
+				} else {
+					const bool h = leaf_test<SPH>(ss, item, r, ti, t, u, v);
+					bool cand;
+					if (ANY) cand = h && t < dis && !float_equal(t, dis);  // BVH.hpp:186
+					else cand = h && (t < best_t || (t == best_t && ti < best_tri));
+					if (cand) {
+						float4 lo, hi;
+						ss.lbox(ti, lo, hi);
+						float te;
+						if (slab_plain(r, lo.x, lo.y, lo.z, hi.x, hi.y, hi.z, inf, te)) {
+							if (ANY) blocked = true;
+							else {
+								best_t = t; best_u = u; best_v = v; best_tri = ti;
+								lim = t * TUTU_PRUNE_SLACK_CLOSEST;
+							}
+						}
+					}
+				}
+				if (ANY && blocked) {  // the first blocker ends the ray: both stacks are dropped
+					cur = TUTU_TRAV_DONE;
+					pend = -1;
+					lp = K;
+				} else if (lp < K) {
+					const uint32_t e = (uint32_t)le;
+					const uint32_t ls = (uint32_t)(__ffs((int)(e & 0xFFu)) - 1) ^ oct;
+					const uint32_t rest = e & (e - 1u);
+					const uint32_t node = e >> 8;
+					pend = (int)(node * 8u + (ls & 7u));
+					pref = wleaf[(size_t)node * 32 + 20 + (ls & 7u)];
+					if ((rest & 0xFFu) != 0u) lstack[lp * 256] = (int)rest;
+					else lp += 1;
+				} else {
+					pend = -1;
+				}
+			}
+		}
+
+		// ---- finish
+		if (cur == TUTU_TRAV_DONE && pend < 0) {
+			if (!ANY) {
+				st_stream(&tp.hitC[slot], make_float4(best_t, best_u, best_v, __int_as_float(best_tri)));
+				tp.hitK[slot] = best_tri >= 0 ? tri_class[best_tri] : (uint8_t)TUTU_CLASS_MISS;
+			} else if (fl & TUTU_KEY_FINAL) {
+				float4 F = make_float4(Lpre.x, Lpre.y, Lpre.z, 0.f);
+				if (!blocked) {
+					F.x = F.x + contrib.x; F.y = F.y + contrib.y; F.z = F.z + contrib.z;
+				}
+				tp.F[__float_as_uint(Lpre.w)] = F;
+			} else if (!blocked) {
+				tp.rec.V[slot] = (uint8_t)((fl & TUTU_KEY_KILL) ? TUTU_V_KILLED : TUTU_V_ADD);
+			}
+			cur = TUTU_TRAV_IDLE;
+		}
+	}
+	// ---- the rays that are not plain: the reference's tree, the reference's slab, one ray per lane (device_trace.h)
+	if (n_def != 0u) {
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+		for (uint32_t j = (uint32_t)lane; j < n_def; j += 64u) exact_walk_entry<SceneGlobal, ANY>(ss, tp, tp.defer[begin + j], stack, tri_class);
+	}
+	if (tp.part) {
+		unsigned long long a = n_nodes, b = n_leaves;
+		for (int off = 32; off > 0; off >>= 1) {
+			a += __shfl_xor(a, off);
+			b += __shfl_xor(b, off);
+		}
+		__shared__ unsigned long long acc[4];
+		if (threadIdx.x < 4) acc[threadIdx.x] = 0ull;
+		__syncthreads();
+		if (lane == 0) {
+			atomicAdd(&acc[0], a);
+			atomicAdd(&acc[1], b);
+			atomicAdd(&acc[2], (unsigned long long)w_node_steps);
+			atomicAdd(&acc[3], (unsigned long long)w_leaf_steps);
+		}
+		__syncthreads();
+		if (threadIdx.x < 4) tp.part[4 * blockIdx.x + threadIdx.x] += acc[threadIdx.x];
+	}
+}
+
+// ------------------------------------------------------------------------------------------------------------
 // Tiny scenes: the FLAT scan (round 4).  A ray through the Cornell box visits 7.5 inner nodes of the walked tree -- 15 box
 // tests -- to reach 2-3 of its 16 leaves (the quads), at 61 % of a wave's lanes, with a stack, rounds, parked leaves and
 // refills around it.  Sixteen box tests in a row cost no more than those fifteen, need none of that, and run on ALL lanes:
@@ -1565,6 +1876,17 @@ __global__ void __launch_bounds__(256, 7) k_trace_wide(TraceParams tp) {
 	sg.tris = tp.sc.tri_isect;
 	sg.lboxes = tp.sc.leaf_boxes;
 	trace_persistent<SceneGlobal, ANY, SPH, true, true, EARLY>(sg, tp, lds + threadIdx.x, tp.tri_class);
+}
+
+// the eight-wide tree (round 5): trace_persistent8
+template <bool ANY, bool SPH, bool EARLY>
+__global__ void __launch_bounds__(256, 7) k_trace_wide8(TraceParams tp) {
+	extern __shared__ int lds_dyn[];
+	SceneGlobal sg;
+	sg.nodes = tp.sc.nodes;
+	sg.tris = tp.sc.tri_isect;
+	sg.lboxes = tp.sc.leaf_boxes;
+	trace_persistent8<ANY, SPH, EARLY>(sg, tp, lds_dyn + threadIdx.x, tp.tri_class);
 }
 
 template <bool LDS_SCENE, bool ANY, bool SPH, bool DEEP, bool WIDE>

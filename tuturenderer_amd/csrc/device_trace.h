@@ -74,6 +74,10 @@ struct SceneDev {
 	const float4* wnodes;      // 4 x float4 per node; node 0 = root
 	int has_wide;
 	float wide_lo[3], wide_hi[3];  // ray origins the quantisation margin was sized for
+	// the eight-wide tree (GpuWide8Node, host_scene.hpp; device_shade.h: trace_persistent8); has_wide8 implies has_wide (the ray
+	// admission test and the frame are the four-wide tree's)
+	const float4* wnodes8;     // 8 x float4 per node id; node 0 = root
+	int has_wide8;
 	// knob "exact" (TUTU_EXACT): EVERY ray takes the exact walk -- the reference's own tree, the reference's own slab, no
 	// distance pruning: BVH.hpp:145-194 as written, visit for visit.  The strict form of the library.
 	int exact;

@@ -704,6 +704,191 @@ static bool build_wide(const std::vector<BuildNode>& t, const LeafRef& leaf_ref,
 	return true;
 }
 
+// ---- the eight-wide tree (GpuWide8Node, host_scene.hpp; round 5).  Same frames, same margin and the same per-plane guarantee as
+// build_wide above; what differs is the collapse (eight slots: the inner child with the largest surface is replaced by its two
+// children until eight slots are in use), the naming of children (inner children of a node: consecutive ids, child_base + slot)
+// and the ORDER of the slots: by octant.  Slot s should hold the child that lies towards the corner (s&1 ? +x : -x, s&2 ? +y :
+// -y, s&4 ? +z : -z) of the node: children are dealt to slots greedily by the score sum_a sign_s[a] (centre_child[a] -
+// centre_node[a]) -- the largest score of any (child, free slot) pair first.  The kernel then visits the hit children in the order
+// of increasing slot ^ oct(ray).  A visiting order only: hits do not depend on it.
+template <typename LeafRef>
+static bool build_wide8(const std::vector<BuildNode>& t, const LeafRef& leaf_ref, HostScene& hs) {
+	hs.wnodes8.clear();
+	hs.has_wide8 = false;
+	hs.n_wide8 = 0;
+	hs.wide8_depth = 0;
+	if (t.empty() || !(t[0].left >= 0 || t[0].right >= 0)) return false;
+	double m = 0;
+	float olo[3], ohi[3];
+	if (!wide_frame(t[0].pmin, t[0].pmax, &m, olo, ohi)) return false;
+	auto is_inner = [&](int32_t bn) { return t[bn].left >= 0 || t[bn].right >= 0; };
+	auto sa_of = [&](int32_t bn) {
+		const BuildNode& b = t[bn];
+		const double dx = (double)b.pmax[0] - b.pmin[0], dy = (double)b.pmax[1] - b.pmin[1], dz = (double)b.pmax[2] - b.pmin[2];
+		return dx * dy + dy * dz + dz * dx;
+	};
+	struct Item { int32_t bn; uint32_t id; uint32_t level; };
+	std::vector<Item> queue;
+	std::vector<std::array<int32_t, 8>> kids;  // per queue entry: build node in each slot (-1 = unused)
+	queue.push_back({0, 0u, 1u});
+	uint32_t next_block = 1, max_level = 1;  // ids come in blocks of eight; block 0 = the root (ids 1..7 are holes)
+	const bool by_octant = !(getenv("TUTU_WIDE8_SLOTS") && atoi(getenv("TUTU_WIDE8_SLOTS")) == 0);  // 0: slots in the binary tree's left-to-right order (A/B)
+	for (size_t qi = 0; qi < queue.size(); qi++) {
+		const Item it = queue[qi];
+		max_level = std::max(max_level, it.level);
+		int32_t cur[8] = {t[it.bn].left, t[it.bn].right, -1, -1, -1, -1, -1, -1};
+		int n = 2;
+		while (n < 8) {
+			int best = -1;
+			double bsa = -1.0;
+			for (int i = 0; i < n; i++) {
+				if (!is_inner(cur[i])) continue;
+				const double sa = sa_of(cur[i]);
+				if (sa > bsa) {
+					bsa = sa;
+					best = i;
+				}
+			}
+			if (best < 0) break;
+			const int32_t l = t[cur[best]].left, r = t[cur[best]].right;
+			for (int i = n; i > best + 1; i--) cur[i] = cur[i - 1];
+			cur[best] = l;
+			cur[best + 1] = r;
+			n++;
+		}
+		std::array<int32_t, 8> ch = {-1, -1, -1, -1, -1, -1, -1, -1};
+		if (!by_octant) {
+			for (int i = 0; i < n; i++) ch[i] = cur[i];
+		} else {
+			double c0[3];
+			for (int a = 0; a < 3; a++) c0[a] = 0.5 * ((double)t[it.bn].pmin[a] + (double)t[it.bn].pmax[a]);
+			double score[8][8];
+			for (int i = 0; i < n; i++)
+				for (int sl = 0; sl < 8; sl++) {
+					double sc = 0;
+					for (int a = 0; a < 3; a++) {
+						const double cc = 0.5 * ((double)t[cur[i]].pmin[a] + (double)t[cur[i]].pmax[a]) - c0[a];
+						sc += ((sl >> a) & 1) ? cc : -cc;
+					}
+					score[i][sl] = sc;
+				}
+			bool used_c[8] = {false, false, false, false, false, false, false, false}, used_s[8] = {false, false, false, false, false, false, false, false};
+			for (int round = 0; round < n; round++) {
+				int bi = -1, bs = -1;
+				double bsc = -1e300;
+				for (int i = 0; i < n; i++) {
+					if (used_c[i]) continue;
+					for (int sl = 0; sl < 8; sl++)
+						if (!used_s[sl] && score[i][sl] > bsc) {
+							bsc = score[i][sl];
+							bi = i;
+							bs = sl;
+						}
+				}
+				used_c[bi] = true;
+				used_s[bs] = true;
+				ch[bs] = cur[bi];
+			}
+		}
+		kids.push_back(ch);
+		bool any_inner = false;
+		for (int k = 0; k < 8; k++) any_inner = any_inner || (ch[k] >= 0 && is_inner(ch[k]));
+		if (any_inner) {
+			if (next_block >= (1u << 21) - 1u) return false;  // node ids below 2^24: a leaf group on the stack is node << 8 | mask
+			const uint32_t base = next_block++ * 8u;
+			for (int k = 0; k < 8; k++)
+				if (ch[k] >= 0 && is_inner(ch[k])) queue.push_back({ch[k], base + (uint32_t)k, it.level + 1});
+		}
+	}
+	hs.wnodes8.assign((size_t)next_block * 8u, GpuWide8Node{});
+	// child_base of queue[qi]: its inner children were queued right after it was handled, with ids base + slot
+	std::vector<uint32_t> base_of(queue.size(), 0u);
+	{
+		size_t nq = 1;  // next queue entry whose parent is being looked for
+		for (size_t qi = 0; qi < queue.size(); qi++) {
+			int inner = 0, first_slot = -1;
+			for (int k = 0; k < 8; k++)
+				if (kids[qi][k] >= 0 && is_inner(kids[qi][k])) {
+					if (first_slot < 0) first_slot = k;
+					inner++;
+				}
+			if (inner) {
+				base_of[qi] = queue[nq].id - (uint32_t)first_slot;
+				nq += (size_t)inner;
+			}
+		}
+	}
+	std::atomic<bool> failed{false};
+	auto quantise = [&](size_t q0, size_t q1) {
+		for (size_t qi = q0; qi < q1; qi++) {
+			const std::array<int32_t, 8>& ch = kids[qi];
+			GpuWide8Node& w = hs.wnodes8[queue[qi].id];
+			memset(&w, 0, sizeof(w));
+			for (int a = 0; a < 3; a++) {
+				double lo = 1e300, hi = -1e300;
+				for (int k = 0; k < 8; k++) {
+					if (ch[k] < 0) continue;
+					lo = std::min(lo, (double)t[ch[k]].pmin[a] - m);
+					hi = std::max(hi, (double)t[ch[k]].pmax[a] + m);
+				}
+				float pf = (float)lo;
+				if ((double)pf > lo) pf = std::nextafterf(pf, -INFINITY);  // round the frame's origin DOWN
+				w.p[a] = pf;
+				const double span = hi - (double)pf;
+				int ea = (int)std::ceil(std::log2(std::max(span, 1e-300) / 255.0));
+				while (std::ldexp(255.0, ea) < span) ea++;
+				ea = std::max(-60, std::min(60, ea));
+				if (std::ldexp(255.0, ea) < span) { failed = true; return; }
+				(a == 0 ? w.scale_x : (a == 1 ? w.scale_y : w.scale_z)) = std::ldexp(1.0f, ea);
+				for (int k = 0; k < 8; k++) {
+					uint32_t ql = 255u, qh = 0u;  // unused slot (in neither mask): an inverted box
+					if (ch[k] >= 0) {
+						const double l = ((double)t[ch[k]].pmin[a] - m - (double)pf), h = ((double)t[ch[k]].pmax[a] + m - (double)pf);
+						ql = (uint32_t)std::max(0.0, std::min(255.0, std::floor(std::ldexp(l, -ea))));
+						qh = (uint32_t)std::max(0.0, std::min(255.0, std::ceil(std::ldexp(h, -ea))));
+						// the guarantees the kernel's exactness argument rests on (build_wide)
+						if ((double)pf + std::ldexp((double)ql, ea) > (double)t[ch[k]].pmin[a] - m || (double)pf + std::ldexp((double)qh, ea) < (double)t[ch[k]].pmax[a] + m)
+							{ failed = true; return; }
+					}
+					w.qlo[a][k >> 2] |= ql << (8 * (k & 3));
+					w.qhi[a][k >> 2] |= qh << (8 * (k & 3));
+				}
+			}
+			uint32_t im = 0, lm = 0;
+			for (int k = 0; k < 8; k++) {
+				w.leaf[k] = INT_MIN;
+				if (ch[k] < 0) continue;
+				if (is_inner(ch[k])) im |= 1u << k;
+				else {
+					lm |= 1u << k;
+					w.leaf[k] = leaf_ref(ch[k]);
+				}
+			}
+			w.meta = im | (lm << 8);
+			w.child_entry = (base_of[qi] >> 3) << 8;
+		}
+	};
+	{
+		const size_t nq = queue.size();
+		const uint32_t n_thr = (nq >= 65536 && !getenv("TUTU_BUILD_SERIAL")) ? std::min<uint32_t>(16, std::max<uint32_t>(1, std::thread::hardware_concurrency())) : 1;
+		std::vector<std::thread> pool;
+		for (uint32_t k = 1; k < n_thr; k++) pool.emplace_back(quantise, nq * k / n_thr, nq * (k + 1) / n_thr);
+		quantise(0, nq / n_thr);
+		for (std::thread& th : pool) th.join();
+		if (failed) {
+			hs.wnodes8.clear();
+			return false;
+		}
+	}
+	if (getenv("TUTU_BUILD_TIMING"))
+		fprintf(stderr, "[tutu build] eight-wide tree: %zu nodes in %u blocks of ids (%.1f MB of address range, %.1f MB touched), %u levels\n", queue.size(),
+		        next_block, next_block * 8.0 * 128.0 / 1048576.0, queue.size() * 128.0 / 1048576.0, max_level);
+	hs.wide8_depth = max_level;
+	hs.n_wide8 = (uint32_t)queue.size();
+	hs.has_wide8 = true;
+	return true;
+}
+
 }  // namespace
 
 // independent iterations [0, n) on several host threads (large scenes only; the same results as one thread: every
@@ -985,6 +1170,13 @@ int build_host_scene(const TutuSceneDesc* d, HostScene& hs, HostBuildHooks* hook
 					return obj_sph[sah[bn].tri] >= 0 ? ~(leaf | kSphereBit) : ~leaf;
 				}, hs, hs.n_refs > n + n / 2);  // greedy where the tree was built over clipped references (see build_wide)
 				lap("wide tree (collapse + quantise)");
+				if (hs.has_wide && !getenv("TUTU_NO_WIDE8")) {
+					build_wide8(sah, [&](int32_t bn) -> int32_t {
+						const int32_t leaf = hs.leaf_of_orig[sah[bn].tri];
+						return obj_sph[sah[bn].tri] >= 0 ? ~(leaf | kSphereBit) : ~leaf;
+					}, hs);
+					lap("eight-wide tree (collapse + slots + quantise)");
+				}
 			}
 		}
 	}

@@ -43,6 +43,32 @@ struct GpuWideNode {
 };
 static_assert(sizeof(GpuWideNode) == 64, "GpuWideNode must be 64 B");
 
+// One node of the EIGHT-wide tree (round 5): 128 B = one L2 line, of which the node step fetches the first 80 B (5 x dwordx4).
+// Eight children decided by one fetch: a ray on a memory-resident scene waits for fewer dependent round trips than on the
+// four-wide tree.  The boxes are quantised exactly as GpuWideNode's (same frame, same margin, same arithmetic in the kernel).
+// What differs is how children are NAMED and ORDERED:
+//   * the inner children of a node have CONSECUTIVE ids: the child in slot s is node child_base + s (ids of slots that hold no
+//     inner child are simply unused: holes in the array, never fetched), so that a whole set of pending children is one
+//     32-bit stack entry, (child_base >> 3) << 8 | mask -- at most one entry per tree level instead of up to seven;
+//   * slots are assigned by OCTANT: bit a of the slot number says on which side of the node's centre, along axis a, the child
+//     lies, so a ray with direction signs oct = (dx<0) | (dy<0)<<1 | (dz<0)<<2 meets the children front to back, roughly, in the
+//     order of increasing slot ^ oct -- no distances are kept or sorted, the kernel permutes the 8-bit hit mask by ^ oct and
+//     takes its lowest set bit (__ffs).  Only ever a visiting order: hits do not depend on it (device_trace.h);
+//   * a leaf child's reference (~object, as in GpuWideNode) lives in the node's second half and is fetched only when that
+//     leaf is about to be tested.
+struct GpuWide8Node {
+	float p[3];
+	float scale_x;          // 2^e[0]
+	float scale_y, scale_z;
+	uint32_t child_entry;   // (child_base >> 3) << 8: the stack entry of this node's inner children, without its mask
+	uint32_t meta;          // bits 0-7: slots that hold an inner child; 8-15: slots that hold a leaf; (others: unused slots)
+	uint32_t qlo[3][2];     // axis a: byte (s & 3) of word s >> 2 = slot s
+	uint32_t qhi[3][2];
+	int32_t leaf[8];        // leaf slots: the leaf's reference
+	uint32_t spare[4];
+};
+static_assert(sizeof(GpuWide8Node) == 128, "GpuWide8Node must be 128 B");
+
 // Triangle as the intersector reads it (48 B = 3 x dwordx4): v0, E1 = v1-v0, E2 = v2-v0, n = normalized(E1 x E2).
 // These are exactly the per-test temporaries of Triangle::intersect (Triangle.hpp:25-35), hoisted to the host;
 // the host computes them with the same fp32 operations, so the bits are the same.
@@ -130,6 +156,11 @@ struct HostScene {
 	uint32_t wide_depth = 0;           // levels of wide nodes on the longest root-to-leaf path
 	uint32_t n_wide = 0;               // wide nodes (= wnodes.size() for the host build; the device build leaves wnodes empty)
 	bool device_walked = false;        // the walked tree was left to the device (tutu_hip.hip: device_build_walked): no SAH tree, no host wide tree
+	// the eight-wide tree (round 5; same conditions as the four-wide one)
+	std::vector<GpuWide8Node> wnodes8; // wnodes8[0] is the root; ids of unused slots are holes
+	bool has_wide8 = false;
+	uint32_t wide8_depth = 0;          // levels of eight-wide nodes on the longest root-to-leaf path
+	uint32_t n_wide8 = 0;              // nodes that exist (wnodes8.size() counts the holes as well)
 	double wide_margin = 0;            // quantisation margin of the wide tree's boxes (host_scene.cpp: wide_frame)
 	bool wide_greedy = false;          // the wide tree was collapsed greedily by surface area (host_scene.cpp: build_wide)
 	float wide_origin_lo[3], wide_origin_hi[3];  // ray origins for which the quantisation margin was sized (others are not "plain")

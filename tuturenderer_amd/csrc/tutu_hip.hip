@@ -23,6 +23,7 @@
 #include "device_bidir.h"
 #include "device_build.h"
 #include "host_scene.hpp"
+#include "rccl_gather.hpp"
 
 using namespace tutu;
 
@@ -99,6 +100,8 @@ struct TutuCtx {
 	int ktrace_deep = 0;                    // ... and of the HBM tier (0: the whole stack is in LDS)
 	bool want_stats = true;                 // the current call was given a TutuStats (else no event pairs are recorded)
 	bool wide_early = false;                // wide tree: leaf box fetched with the triangle record (7 waves per SIMD)
+	bool wide8 = false;                     // the eight-wide tree is walked (device_shade.h: trace_persistent8)
+	int wide8_entries = 0;                  // ... entries of its LDS column: node stack from the bottom, leaf stack from the top
 	unsigned ktrace_lds_bytes = TUTU_STACK_DEPTH * 256 * sizeof(int);
 	bool lds_scene = false;
 	FlatScene flat = {};     // flat.n > 0: the traversal stages run k_trace_flat (tiny scenes)
@@ -130,6 +133,12 @@ struct TutuCtx {
 		int wide_early_max_mb = 8;  // TUTU_WIDE_EARLY_MAX_MB  ... "small" = fewer MB of wide nodes than this  [0, 65536]
 		int wide_inner_steps = 4; // TUTU_WIDE_INNER_STEPS node visits per round on the wide tree, closest-hit  [1, 64]
 		int wide_inner_steps_any = 4;  // TUTU_WIDE_INNER_STEPS_ANY  the same, any-hit  [1, 64]
+		int wide8 = 1;            // TUTU_WIDE8          eight-wide tree instead of the four-wide one where the scene has both: 0 never, 1 yes  [0, 1]
+		int wide8_inner_steps = 3;      // TUTU_WIDE8_INNER_STEPS      node visits per round on the eight-wide tree, closest-hit  [1, 64]
+		int wide8_inner_steps_any = 3;  // TUTU_WIDE8_INNER_STEPS_ANY  the same, any-hit  [1, 64]
+		int wide8_leaf_steps = 2;       // TUTU_WIDE8_LEAF_STEPS       leaf steps per round at most  [1, 8]
+		int wide8_leaf_again = 16;      // TUTU_WIDE8_LEAF_AGAIN       lanes with a leaf in hand that trigger a further leaf step, 65 = never  [1, 65]
+		int wide8_leaf_room = 6;        // TUTU_WIDE8_LEAF_ROOM        entries of the LDS column beyond depth + 2: room for leaf groups  [1, 32]
 		int lds_stack_max = 32;   // TUTU_LDS_STACK_MAX  k_trace, binary tree: entries of the LDS tier of a deep tree's stack, 0 = all in LDS  [0, 64]
 		int wide_lds_stack = 19;  // TUTU_WIDE_LDS_STACK k_trace, wide tree: entries of the LDS tier (19 KB: eight blocks per CU)  [4, 64]
 		int trace_xcd = 1;        // TUTU_TRACE_XCD      1: the blocks of one XCD take ADJACENT ranges of the work list  [0, 1]
@@ -141,13 +150,14 @@ struct TutuCtx {
 		int device_build_min_k = 384;  // TUTU_DEVICE_BUILD_MIN_K  ... "large" = at least this many thousand objects  [1, 1048576]
 		int flat_share = 1;       // TUTU_FLAT_SHARE     flat scan, closest hit: the wave's (ray, leaf) pairs dealt to its lanes through LDS  {0, 1}
 		int flat = 1;             // TUTU_FLAT           tiny LDS-resident scenes (<= TUTU_FLAT_MAX leaves): the flat scan instead of the tree walk  {0, 1}
+		int gather_rccl = 1;      // TUTU_GATHER_RCCL    tutu_hip_render_multi(_device): the pieces travel by ONE grouped RCCL send / recv: 0 never (peer copies), 1 when the contexts sit on several devices, 2 always (contexts that share the root's device: a self send / recv)  [0, 2]
 		int exact = 0;            // TUTU_EXACT          every ray takes the exact walk: reference tree, reference slab, no pruning  {0, 1}
 		int cold_paths_mi = 12;   // TUTU_COLD_PATHS_MI  Mi path slots (all work sets together) a context's FIRST default-sized render allocates itself;
 		                          //                     the rest of the default 168 Mi arrives from a background thread (0 = allocate everything at once)  [0, 4096]
 		int bidir_units = 1 << 23;  // TUTU_BIDIR_UNITS  LightTracing / NaivePT / BDPT: (pixel, sample) units per batch  [64, 2^24]  (2 -> 8 Mi: LightTracing +8 %, NaivePT +20 %, BDPT flat; 3.8 GB of BDPT lists)
 	} knobs;
 	int shade_mode_all = SHADE_ANY;  // the kernel of that launch: the scene's only scattering class, or SHADE_ANY
-	DevBuf<float4> d_tri_tex, d_texels, d_tex_desc, d_leaf_boxes, d_wnodes;
+	DevBuf<float4> d_tri_tex, d_texels, d_tex_desc, d_leaf_boxes, d_wnodes, d_wnodes8;
 	DevBuf<uint8_t> d_tri_class;
 	// work buffers: up to four sets, so that consecutive passes run on their own streams and a memory-bound stage of
 	// one pass overlaps a compute-bound stage of another
@@ -200,6 +210,9 @@ struct TutuCtx {
 	DevBuf<float> out_stage;
 	DevBuf<float> gathered, frame_stage;  // tutu_hip_render_multi(_device), on the first context: the pieces in context order; the un-tiled frame
 	DevBuf<int32_t> gather_index;         // ... row of `gathered` -> work item
+	RcclGather* rccl = nullptr;           // ... the RCCL communicators of the last N-device frame's devices (rccl_gather.hpp), kept for the next
+	int gather_path = -1;                 // ... how the last N-device frame was gathered: 0 peer / local copies, 1 one grouped RCCL send / recv
+	int peer_access = -1;                 // ... remote devices the first context's device was given peer access to (-1: never asked)
 	// the other integrators (device_bidir.h): per-unit results, frame-buffer events and their sorted order
 	struct Bidir {
 		DevBuf<float4> own, own_list, ev_val;
@@ -240,6 +253,12 @@ const KnobDesc kKnobs[] = {
     {"wide_inner_steps", "TUTU_WIDE_INNER_STEPS", &TutuCtx::Knobs::wide_inner_steps, 1, 64},
     {"wide_inner_steps_any", "TUTU_WIDE_INNER_STEPS_ANY", &TutuCtx::Knobs::wide_inner_steps_any, 1, 64},
     {"wide_early", "TUTU_WIDE_EARLY", &TutuCtx::Knobs::wide_early, 0, 2, true},
+    {"wide8", "TUTU_WIDE8", &TutuCtx::Knobs::wide8, 0, 1, true},
+    {"wide8_inner_steps", "TUTU_WIDE8_INNER_STEPS", &TutuCtx::Knobs::wide8_inner_steps, 1, 64},
+    {"wide8_inner_steps_any", "TUTU_WIDE8_INNER_STEPS_ANY", &TutuCtx::Knobs::wide8_inner_steps_any, 1, 64},
+    {"wide8_leaf_steps", "TUTU_WIDE8_LEAF_STEPS", &TutuCtx::Knobs::wide8_leaf_steps, 1, 8},
+    {"wide8_leaf_again", "TUTU_WIDE8_LEAF_AGAIN", &TutuCtx::Knobs::wide8_leaf_again, 1, 65},
+    {"wide8_leaf_room", "TUTU_WIDE8_LEAF_ROOM", &TutuCtx::Knobs::wide8_leaf_room, 1, 32, true},
     {"wide_early_max_mb", "TUTU_WIDE_EARLY_MAX_MB", &TutuCtx::Knobs::wide_early_max_mb, 0, 65536, true},
     {"any_near_first", "TUTU_ANY_NEAR_FIRST", &TutuCtx::Knobs::any_near_first, 0, 1},
     {"kernel_events", "TUTU_KERNEL_EVENTS", &TutuCtx::Knobs::kernel_events, 0, 1},
@@ -248,6 +267,7 @@ const KnobDesc kKnobs[] = {
     {"util_stats", "TUTU_UTIL_STATS", &TutuCtx::Knobs::util_stats, 0, 1},
     {"bidir_units", "TUTU_BIDIR_UNITS", &TutuCtx::Knobs::bidir_units, 64, 1 << 24},
     {"exact", "TUTU_EXACT", &TutuCtx::Knobs::exact, 0, 1},
+    {"gather_rccl", "TUTU_GATHER_RCCL", &TutuCtx::Knobs::gather_rccl, 0, 2},
     {"flat", "TUTU_FLAT", &TutuCtx::Knobs::flat, 0, 1, true},
     {"flat_share", "TUTU_FLAT_SHARE", &TutuCtx::Knobs::flat_share, 0, 1},
     {"device_build", "TUTU_DEVICE_BUILD", &TutuCtx::Knobs::device_build, 0, 2, true},
@@ -481,6 +501,22 @@ void launch_trace(TutuCtx* c, hipStream_t s, int grid, const TraceParams& tp) {
 		const dim3 g(grid), b(256);
 		if (c->lds_scene) k_trace_exact<true, ANY><<<g, b, c->ktrace_lds_bytes, s>>>(tp);
 		else k_trace_exact<false, ANY><<<g, b, c->ktrace_lds_bytes, s>>>(tp);
+		return;
+	}
+	if (c->wide8) {  // memory-resident scene: the eight-wide quantised tree, node groups, decoupled leaves
+		dim3 g(grid), b(256);
+		TraceParams t8 = tp;
+		t8.stack_entries = c->wide8_entries;
+		t8.inner_steps = ANY ? c->knobs.wide8_inner_steps_any : c->knobs.wide8_inner_steps;
+		t8.leaf_steps = c->knobs.wide8_leaf_steps;
+		t8.leaf_again = c->knobs.wide8_leaf_again;
+		if (c->wide_early) {
+			if (c->has_spheres) k_trace_wide8<ANY, true, true><<<g, b, c->ktrace_lds_bytes, s>>>(t8);
+			else k_trace_wide8<ANY, false, true><<<g, b, c->ktrace_lds_bytes, s>>>(t8);
+		} else {
+			if (c->has_spheres) k_trace_wide8<ANY, true, false><<<g, b, c->ktrace_lds_bytes, s>>>(t8);
+			else k_trace_wide8<ANY, false, false><<<g, b, c->ktrace_lds_bytes, s>>>(t8);
+		}
 		return;
 	}
 	if (c->sc.has_wide) {  // memory-resident scene: the four-wide quantised tree, two-tier stack
@@ -1160,6 +1196,7 @@ int tutu_hip_create(const TutuSceneDesc* scene, int device, TutuCtx** out) {
 		return fail(TUTU_E_HIP);
 	if ((rc = upload(c->d_leaf_boxes, c->hs.leaf_boxes, s)) != TUTU_OK) return fail(rc);
 	if (!c->hs.device_walked && (rc = upload(c->d_wnodes, c->hs.wnodes, s)) != TUTU_OK) return fail(rc);  // (the device build wrote d_wnodes itself)
+	if (c->hs.has_wide8 && c->knobs.wide8 == 1 && (rc = upload(c->d_wnodes8, c->hs.wnodes8, s)) != TUTU_OK) return fail(rc);
 	c->textured = !c->hs.tri_tex.empty();
 	if (c->textured) {
 		if ((rc = upload(c->d_tri_tex, c->hs.tri_tex, s)) != TUTU_OK) return fail(rc);
@@ -1178,6 +1215,8 @@ int tutu_hip_create(const TutuSceneDesc* scene, int device, TutuCtx** out) {
 	sc.leaf_boxes = c->d_leaf_boxes.p;
 	sc.pair_leaves = c->hs.pair_leaves ? 1 : 0;
 	sc.wnodes = c->d_wnodes.p;
+	sc.wnodes8 = c->d_wnodes8.p;
+	sc.has_wide8 = 0;
 	sc.has_wide = 0;  // decided below, with the traversal kernels' LDS budget
 	sc.exact = c->knobs.exact;
 	memcpy(sc.wide_lo, c->hs.wide_origin_lo, 12);
@@ -1291,6 +1330,16 @@ int tutu_hip_create(const TutuSceneDesc* scene, int device, TutuCtx** out) {
 			c->ktrace_deep = c->stack_entries - lds_tier;
 		}
 	}
+	// The eight-wide tree (round 5) where the scene has one: its LDS column holds the node stack (one group per level: depth + 1
+	// entries with the sentinel, + 1 for the step's own push) from the bottom and the leaf groups from the top; the exact walk
+	// of the deferred rays (reference tree) must fit as well.  No HBM tier.
+	c->wide8 = sc.has_wide && c->hs.has_wide8 && c->knobs.wide8 == 1 && !c->hs.device_walked;
+	sc.has_wide8 = c->wide8 ? 1 : 0;
+	if (c->wide8) {
+		c->wide8_entries = std::max((int)c->hs.ref_depth + 1, (int)c->hs.wide8_depth + 2 + c->knobs.wide8_leaf_room);
+		c->ktrace_entries = c->wide8_entries;
+		c->ktrace_deep = 0;
+	}
 	c->ktrace_lds_bytes = (unsigned)((size_t)c->ktrace_entries * 256 * sizeof(int) + (c->lds_scene ? scene_bytes : 0));
 	// (+ the kernel's 32 B of static LDS: eight blocks of exactly 20 KB do NOT fit a CU, and the blocks that do not fit run
 	// after the others, alone -- a persistent grid must be resident as a whole)
@@ -1300,7 +1349,7 @@ int tutu_hip_create(const TutuSceneDesc* scene, int device, TutuCtx** out) {
 	// registers -- so 7 blocks of 4 waves is what a CU holds.
 	const size_t wide_mb = ((size_t)c->hs.n_wide * sizeof(GpuWideNode)) >> 20;
 	c->wide_early = sc.has_wide && (c->knobs.wide_early == 2 || (c->knobs.wide_early == 1 && wide_mb < (size_t)c->knobs.wide_early_max_mb));
-	if (c->wide_early) c->trace_blocks_per_cu = std::min(c->trace_blocks_per_cu, 7);
+	if (c->wide_early || c->wide8) c->trace_blocks_per_cu = std::min(c->trace_blocks_per_cu, 7);  // (k_trace_wide8: 72 registers as well)
 	// Fewer resident blocks than the LDS use allows (TUTU_TRACE_BPC): the request is padded so that exactly that many FIT --
 	// a grid of fewer blocks than fit is not spread evenly over the CUs by the dispatcher (some CUs get 8, others 2).
 	if (c->knobs.trace_bpc > 0 && c->knobs.trace_bpc < c->trace_blocks_per_cu) {
@@ -1321,7 +1370,9 @@ int tutu_hip_destroy(TutuCtx* c) {
 		(void)hipEventDestroy(e.a);
 		(void)hipEventDestroy(e.b);
 	}
-	c->d_tri_tex.release(); c->d_texels.release(); c->d_tex_desc.release(); c->d_leaf_boxes.release(); c->d_wnodes.release();
+	rccl_gather_destroy(c->rccl);
+	c->rccl = nullptr;
+	c->d_tri_tex.release(); c->d_texels.release(); c->d_tex_desc.release(); c->d_leaf_boxes.release(); c->d_wnodes.release(); c->d_wnodes8.release();
 	c->d_tri_class.release(); c->d_nodes.release(); c->d_tri_isect.release(); c->d_tri_shade.release(); c->d_mats.release(); c->d_lights.release();
 	for (int k = 0; k < TUTU_MAX_SETS - 1; k++)
 		if (c->extra_streams[k]) (void)hipStreamSynchronize(c->extra_streams[k]);
@@ -1404,6 +1455,34 @@ int tutu_hip_get_option(TutuCtx* c, const char* name, int* value) {
 	}
 	if (strcmp(name, "device_built") == 0) {  // the walked tree was built on the device (device_build.h)
 		*value = c->hs.device_walked ? 1 : 0;
+		return TUTU_OK;
+	}
+	if (strcmp(name, "gather_path") == 0) {  // the last tutu_hip_render_multi(_device) through this (first) context: 0 copies, 1 RCCL, -1 none yet
+		*value = c->gather_path;
+		return TUTU_OK;
+	}
+	if (strcmp(name, "peer_access") == 0) {  // remote devices this context's device was given peer access to for the copy gather (-1: never asked)
+		*value = c->peer_access;
+		return TUTU_OK;
+	}
+	if (strcmp(name, "rccl_available") == 0) {
+		*value = rccl_available();
+		return TUTU_OK;
+	}
+	if (strcmp(name, "wide8_tree") == 0) {  // the persistent kernels walk the EIGHT-wide tree (device_shade.h: trace_persistent8)
+		*value = c->wide8 ? 1 : 0;
+		return TUTU_OK;
+	}
+	if (strcmp(name, "wide8_depth") == 0) {
+		*value = (int)c->hs.wide8_depth;
+		return TUTU_OK;
+	}
+	if (strcmp(name, "wide8_nodes") == 0) {
+		*value = (int)c->hs.n_wide8;
+		return TUTU_OK;
+	}
+	if (strcmp(name, "wide8_entries") == 0) {  // entries of a lane's LDS column: node stack from the bottom, leaf groups from the top
+		*value = c->wide8_entries;
 		return TUTU_OK;
 	}
 	if (strcmp(name, "wide_depth") == 0) {
@@ -1603,7 +1682,9 @@ int tutu_hip_render_multi_device(TutuCtx* const* ctxs, int32_t n, const TutuCame
 			g_last_error = errs[(size_t)k];
 			return rcs[(size_t)k];
 		}
-	// ---- the gather, on the first context's device: peer copies into one buffer in context order + one un-tiling kernel
+	// ---- the gather, on the first context's device: the pieces into one buffer in context order + one un-tiling kernel.
+	// Several devices: ONE grouped RCCL send / recv (rccl_gather.hpp; knob gather_rccl) -- the collective SURVEY.md 8e names;
+	// peer copies (with peer access asked for explicitly) where RCCL is absent, switched off, or every context shares a device.
 	TutuCtx* root = ctxs[0];
 	HIP_TRY(hipSetDevice(root->device));
 	hipStream_t s = stream ? (hipStream_t)stream : root->stream;
@@ -1611,16 +1692,63 @@ int tutu_hip_render_multi_device(TutuCtx* const* ctxs, int32_t n, const TutuCame
 	if (rc != TUTU_OK) return rc;
 	if ((rc = root->gather_index.ensure((size_t)n_items)) != TUTU_OK) return rc;
 	HIP_TRY(hipMemcpyAsync(root->gather_index.p, item_of_row.data(), sizeof(int32_t) * (size_t)n_items, hipMemcpyHostToDevice, s));
-	for (int k = 0; k < n; k++) {
-		const size_t rows = pieces[(size_t)k].pixels.size();
-		if (rows == 0) continue;
-		float* dst = root->gathered.p + 3 * offset[(size_t)k];
-		if (ctxs[k]->device == root->device) HIP_TRY(hipMemcpyAsync(dst, ctxs[k]->out_stage.p, sizeof(float) * 3 * rows, hipMemcpyDeviceToDevice, s));
-		else HIP_TRY(hipMemcpyPeerAsync(dst, root->device, ctxs[k]->out_stage.p, ctxs[k]->device, sizeof(float) * 3 * rows, s));
+	std::vector<int> devs;  // distinct devices, the root's first
+	for (int k = 0; k < n; k++)
+		if (std::find(devs.begin(), devs.end(), ctxs[k]->device) == devs.end()) devs.push_back(ctxs[k]->device);
+	bool by_rccl = false;
+	if ((root->knobs.gather_rccl == 2 || (root->knobs.gather_rccl == 1 && devs.size() > 1)) && rccl_available()) {
+		std::string err;
+		if (!rccl_gather_matches(root->rccl, devs.data(), (int)devs.size())) {
+			rccl_gather_destroy(root->rccl);
+			root->rccl = rccl_gather_create(devs.data(), (int)devs.size(), &err);
+			HIP_TRY(hipSetDevice(root->device));
+		}
+		if (root->rccl) {
+			std::vector<RcclPiece> ps;
+			for (int k = 0; k < n; k++) {
+				const size_t rows = pieces[(size_t)k].pixels.size();
+				if (rows) ps.push_back({ctxs[k]->device, ctxs[k]->out_stage.p, root->gathered.p + 3 * offset[(size_t)k], 3 * rows, ctxs[k]->stream});
+			}
+			if (rccl_gather_run(root->rccl, root->device, s, ps.data(), (int)ps.size(), &err) != 0) {
+				g_last_error = err;
+				return TUTU_E_HIP;
+			}
+			by_rccl = true;
+		} else if (root->knobs.gather_rccl == 2) {  // asked for explicitly: fail loudly
+			g_last_error = err;
+			return TUTU_E_HIP;
+		}
+	}
+	root->gather_path = by_rccl ? 1 : 0;
+	if (!by_rccl) {
+		if (devs.size() > 1) {  // peer access, explicitly: without it a peer copy may be staged through the host
+			int enabled = 0;
+			for (size_t k = 1; k < devs.size(); k++) {
+				int can = 0;
+				if (hipDeviceCanAccessPeer(&can, root->device, devs[k]) == hipSuccess && can) {
+					const hipError_t e = hipDeviceEnablePeerAccess(devs[k], 0);
+					if (e == hipSuccess || e == hipErrorPeerAccessAlreadyEnabled) enabled++;
+					(void)hipGetLastError();
+				}
+			}
+			root->peer_access = enabled;
+		}
+		for (int k = 0; k < n; k++) {
+			const size_t rows = pieces[(size_t)k].pixels.size();
+			if (rows == 0) continue;
+			float* dst = root->gathered.p + 3 * offset[(size_t)k];
+			if (ctxs[k]->device == root->device) HIP_TRY(hipMemcpyAsync(dst, ctxs[k]->out_stage.p, sizeof(float) * 3 * rows, hipMemcpyDeviceToDevice, s));
+			else HIP_TRY(hipMemcpyPeerAsync(dst, root->device, ctxs[k]->out_stage.p, ctxs[k]->device, sizeof(float) * 3 * rows, s));
+		}
 	}
 	hipLaunchKernelGGL(k_untile, dim3((unsigned)((n_items + 255) / 256)), dim3(256), 0, s, root->gathered.p, root->gather_index.p, d_out_rgb, (uint32_t)n_items);
 	HIP_TRY(hipGetLastError());
 	HIP_TRY(hipStreamSynchronize(s));
+	if (by_rccl) {  // the senders' streams as well: their pieces are free for the next frame
+		for (int k = 0; k < n; k++)
+			if (ctxs[k]->device != root->device && hipSetDevice(ctxs[k]->device) == hipSuccess) (void)hipStreamSynchronize(ctxs[k]->stream);
+		HIP_TRY(hipSetDevice(root->device));
+	}
 	return TUTU_OK;
 }
 
