@@ -707,10 +707,9 @@ static bool build_wide(const std::vector<BuildNode>& t, const LeafRef& leaf_ref,
 // ---- the eight-wide tree (GpuWide8Node, host_scene.hpp; round 5).  Same frames, same margin and the same per-plane guarantee as
 // build_wide above; what differs is the collapse (eight slots: the inner child with the largest surface is replaced by its two
 // children until eight slots are in use), the naming of children (inner children of a node: consecutive ids, child_base + slot)
-// and the ORDER of the slots: by octant.  Slot s should hold the child that lies towards the corner (s&1 ? +x : -x, s&2 ? +y :
-// -y, s&4 ? +z : -z) of the node: children are dealt to slots greedily by the score sum_a sign_s[a] (centre_child[a] -
-// centre_node[a]) -- the largest score of any (child, free slot) pair first.  The kernel then visits the hit children in the order
-// of increasing slot ^ oct(ray).  A visiting order only: hits do not depend on it.
+// and the ORDER of the slots.  The kernel visits the hit children of a node in the order of increasing slot ^ x, x = the entry of the
+// node's own table for the ray's sign octant -- so the host decides, per node, what the three bits of a slot number MEAN (below: kd
+// slots, the default; octant slots; the binary tree's order).  A visiting order only: hits do not depend on it.
 template <typename LeafRef>
 static bool build_wide8(const std::vector<BuildNode>& t, const LeafRef& leaf_ref, HostScene& hs) {
 	hs.wnodes8.clear();
@@ -732,7 +731,9 @@ static bool build_wide8(const std::vector<BuildNode>& t, const LeafRef& leaf_ref
 	std::vector<std::array<int32_t, 8>> kids;  // per queue entry: build node in each slot (-1 = unused)
 	queue.push_back({0, 0u, 1u});
 	uint32_t next_block = 1, max_level = 1;  // ids come in blocks of eight; block 0 = the root (ids 1..7 are holes)
-	const bool by_octant = !(getenv("TUTU_WIDE8_SLOTS") && atoi(getenv("TUTU_WIDE8_SLOTS")) == 0);  // 0: slots in the binary tree's left-to-right order (A/B)
+	// TUTU_WIDE8_SLOTS (A/B): 0 slots in the binary tree's left-to-right order and one fixed visiting order, 1 octant slots, 2 kd slots
+	const int slot_mode = getenv("TUTU_WIDE8_SLOTS") ? atoi(getenv("TUTU_WIDE8_SLOTS")) : 2;
+	std::vector<uint32_t> tables;  // per queue entry: the visiting-order table (GpuWide8Node::meta bits 8-31)
 	for (size_t qi = 0; qi < queue.size(); qi++) {
 		const Item it = queue[qi];
 		max_level = std::max(max_level, it.level);
@@ -757,9 +758,12 @@ static bool build_wide8(const std::vector<BuildNode>& t, const LeafRef& leaf_ref
 			n++;
 		}
 		std::array<int32_t, 8> ch = {-1, -1, -1, -1, -1, -1, -1, -1};
-		if (!by_octant) {
-			for (int i = 0; i < n; i++) ch[i] = cur[i];
-		} else {
+		uint32_t table = 0;  // visiting-order table: bits 3 oct .. 3 oct + 2 = the XOR constant for rays of sign octant oct
+		if (slot_mode == 0) {
+			for (int i = 0; i < n; i++) ch[i] = cur[i];  // the binary tree's left-to-right order, one fixed visiting order (A/B)
+		} else if (slot_mode == 1) {
+			// octant slots: bit a of the slot = the side of the node's centre along axis a; children dealt greedily by the score
+			// sum_a sign_s[a] (centre_child[a] - centre_node[a]); rays of octant oct visit in the order of increasing slot ^ oct
 			double c0[3];
 			for (int a = 0; a < 3; a++) c0[a] = 0.5 * ((double)t[it.bn].pmin[a] + (double)t[it.bn].pmax[a]);
 			double score[8][8];
@@ -789,12 +793,61 @@ static bool build_wide8(const std::vector<BuildNode>& t, const LeafRef& leaf_ref
 				used_s[bs] = true;
 				ch[bs] = cur[bi];
 			}
+			for (uint32_t oct = 0; oct < 8; oct++) table |= oct << (3 * oct);
+		} else {
+			// kd slots (default): three levels of median splits of the children's centres, ONE axis per level (the axis along which
+			// that level's groups are spread most); bit 2 of the slot = the side of the first split, bit 1 of the second, bit 0 of
+			// the third.  A ray visits the lower side of a level first when it travels up that level's axis: the XOR constant of a
+			// sign octant has bit i set when the ray travels DOWN the axis of level i -- for a long thin node all three levels
+			// pick the same axis and the eight slots are simply sorted along it.
+			auto centre = [&](int32_t bn, int a) { return 0.5 * ((double)t[bn].pmin[a] + (double)t[bn].pmax[a]); };
+			std::vector<std::vector<int32_t>> groups(1);
+			for (int i = 0; i < n; i++) groups[0].push_back(cur[i]);
+			int axis_of_level[3] = {0, 0, 0};
+			for (int level = 0; level < 3; level++) {
+				double best = -1.0;
+				int ba = 0;
+				for (int a = 0; a < 3; a++) {
+					double spread = 0;
+					for (const auto& g : groups) {
+						if (g.size() < 2) continue;
+						double lo = 1e300, hi = -1e300;
+						for (int32_t bn : g) {
+							lo = std::min(lo, centre(bn, a));
+							hi = std::max(hi, centre(bn, a));
+						}
+						spread += hi - lo;
+					}
+					if (spread > best) {
+						best = spread;
+						ba = a;
+					}
+				}
+				axis_of_level[level] = ba;
+				std::vector<std::vector<int32_t>> next;
+				for (auto& g : groups) {
+					std::stable_sort(g.begin(), g.end(), [&](int32_t x, int32_t y) { return centre(x, ba) < centre(y, ba); });
+					const size_t half = (g.size() + 1) / 2;
+					next.emplace_back(g.begin(), g.begin() + (long)half);
+					next.emplace_back(g.begin() + (long)half, g.end());
+				}
+				groups.swap(next);
+			}
+			for (int sl = 0; sl < 8; sl++) {  // groups[k]: k's bits from the first level (most significant) to the third
+				if (groups[(size_t)sl].size() > 1) return false;  // (cannot happen: at most eight children, halved three times)
+				if (!groups[(size_t)sl].empty()) ch[sl] = groups[(size_t)sl][0];
+			}
+			for (uint32_t oct = 0; oct < 8; oct++) {
+				const uint32_t on = (((oct >> axis_of_level[0]) & 1u) << 2) | (((oct >> axis_of_level[1]) & 1u) << 1) | ((oct >> axis_of_level[2]) & 1u);
+				table |= on << (3 * oct);
+			}
 		}
+		tables.push_back(table);
 		kids.push_back(ch);
 		bool any_inner = false;
 		for (int k = 0; k < 8; k++) any_inner = any_inner || (ch[k] >= 0 && is_inner(ch[k]));
 		if (any_inner) {
-			if (next_block >= (1u << 21) - 1u) return false;  // node ids below 2^24: a leaf group on the stack is node << 8 | mask
+			if (next_block >= (1u << 18) - 1u) return false;  // node ids below 2^21: a leaf group on the stack is node << 11 | order << 8 | mask
 			const uint32_t base = next_block++ * 8u;
 			for (int k = 0; k < 8; k++)
 				if (ch[k] >= 0 && is_inner(ch[k])) queue.push_back({ch[k], base + (uint32_t)k, it.level + 1});
@@ -864,8 +917,8 @@ static bool build_wide8(const std::vector<BuildNode>& t, const LeafRef& leaf_ref
 					w.leaf[k] = leaf_ref(ch[k]);
 				}
 			}
-			w.meta = im | (lm << 8);
-			w.child_entry = (base_of[qi] >> 3) << 8;
+			w.meta = lm | (tables[qi] << 8);
+			w.child_entry = ((base_of[qi] >> 3) << 11) | im;
 		}
 	};
 	{
@@ -1170,7 +1223,8 @@ int build_host_scene(const TutuSceneDesc* d, HostScene& hs, HostBuildHooks* hook
 					return obj_sph[sah[bn].tri] >= 0 ? ~(leaf | kSphereBit) : ~leaf;
 				}, hs, hs.n_refs > n + n / 2);  // greedy where the tree was built over clipped references (see build_wide)
 				lap("wide tree (collapse + quantise)");
-				if (hs.has_wide && !getenv("TUTU_NO_WIDE8")) {
+				const int w8_mb = hooks ? hooks->wide8_below_mb : -1;
+				if (hs.has_wide && !getenv("TUTU_NO_WIDE8") && (w8_mb < 0 || (int)(((size_t)hs.n_wide * sizeof(GpuWideNode)) >> 20) < w8_mb)) {
 					build_wide8(sah, [&](int32_t bn) -> int32_t {
 						const int32_t leaf = hs.leaf_of_orig[sah[bn].tri];
 						return obj_sph[sah[bn].tri] >= 0 ? ~(leaf | kSphereBit) : ~leaf;

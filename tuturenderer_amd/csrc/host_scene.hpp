@@ -49,19 +49,20 @@ static_assert(sizeof(GpuWideNode) == 64, "GpuWideNode must be 64 B");
 // What differs is how children are NAMED and ORDERED:
 //   * the inner children of a node have CONSECUTIVE ids: the child in slot s is node child_base + s (ids of slots that hold no
 //     inner child are simply unused: holes in the array, never fetched), so that a whole set of pending children is one
-//     32-bit stack entry, (child_base >> 3) << 8 | mask -- at most one entry per tree level instead of up to seven;
-//   * slots are assigned by OCTANT: bit a of the slot number says on which side of the node's centre, along axis a, the child
-//     lies, so a ray with direction signs oct = (dx<0) | (dy<0)<<1 | (dz<0)<<2 meets the children front to back, roughly, in the
-//     order of increasing slot ^ oct -- no distances are kept or sorted, the kernel permutes the 8-bit hit mask by ^ oct and
-//     takes its lowest set bit (__ffs).  Only ever a visiting order: hits do not depend on it (device_trace.h);
+//     32-bit stack entry, (child_base >> 3) << 11 | order << 8 | mask -- at most one entry per tree level instead of up to seven;
+//   * slots are ORDERED: a ray with direction signs oct = (dx<0) | (dy<0)<<1 | (dz<0)<<2 visits the hit children in the order of
+//     increasing slot ^ x, x = the node's own 3-bit table entry for that octant (meta bits 8 + 3 oct ...): the host assigns the
+//     slots by three levels of median splits, one axis per level, and x flips the levels whose axis the ray travels down (a
+//     long thin node sorts its eight children along one axis) -- no distances are kept or sorted, the kernel permutes the
+//     8-bit hit mask by ^ x and takes its lowest set bit (__ffs).  Only ever a visiting order: hits do not depend on it;
 //   * a leaf child's reference (~object, as in GpuWideNode) lives in the node's second half and is fetched only when that
 //     leaf is about to be tested.
 struct GpuWide8Node {
 	float p[3];
 	float scale_x;          // 2^e[0]
 	float scale_y, scale_z;
-	uint32_t child_entry;   // (child_base >> 3) << 8: the stack entry of this node's inner children, without its mask
-	uint32_t meta;          // bits 0-7: slots that hold an inner child; 8-15: slots that hold a leaf; (others: unused slots)
+	uint32_t child_entry;   // (child_base >> 3) << 11 | slots that hold an inner child: the stack entry of the inner children is (this & ~0xFF) | order << 8 | hit mask
+	uint32_t meta;          // bits 0-7: slots that hold a leaf; bits 8 + 3 oct .. 10 + 3 oct: the XOR constant of the visiting order for sign octant oct
 	uint32_t qlo[3][2];     // axis a: byte (s & 3) of word s >> 2 = slot s
 	uint32_t qhi[3][2];
 	int32_t leaf[8];        // leaf slots: the leaf's reference
@@ -185,6 +186,8 @@ int build_reference_tree(uint32_t n_tris, const float* verts, std::vector<BuildN
 // the scene box -- only when every coordinate is finite and the scene box can carry the wide tree's 8-bit frames; else the
 // host builds everything as usual and HostScene::device_walked stays false.
 struct HostBuildHooks {
+	// the eight-wide tree is built when the four-wide one has fewer than this many MB of nodes (-1: always, 0: never)
+	int wide8_below_mb = -1;
 	bool device_walked = false;
 	std::function<void(const float* boxes6, uint32_t n, const float* lo, const float* hi)> on_boxes;
 };

@@ -100,6 +100,7 @@ struct TutuCtx {
 	int ktrace_deep = 0;                    // ... and of the HBM tier (0: the whole stack is in LDS)
 	bool want_stats = true;                 // the current call was given a TutuStats (else no event pairs are recorded)
 	bool wide_early = false;                // wide tree: leaf box fetched with the triangle record (7 waves per SIMD)
+	bool wide4d = false;                    // the four-wide tree is walked with decoupled leaves (device_shade.h: trace_persistent4d)
 	bool wide8 = false;                     // the eight-wide tree is walked (device_shade.h: trace_persistent8)
 	int wide8_entries = 0;                  // ... entries of its LDS column: node stack from the bottom, leaf stack from the top
 	unsigned ktrace_lds_bytes = TUTU_STACK_DEPTH * 256 * sizeof(int);
@@ -133,12 +134,20 @@ struct TutuCtx {
 		int wide_early_max_mb = 8;  // TUTU_WIDE_EARLY_MAX_MB  ... "small" = fewer MB of wide nodes than this  [0, 65536]
 		int wide_inner_steps = 4; // TUTU_WIDE_INNER_STEPS node visits per round on the wide tree, closest-hit  [1, 64]
 		int wide_inner_steps_any = 4;  // TUTU_WIDE_INNER_STEPS_ANY  the same, any-hit  [1, 64]
-		int wide8 = 1;            // TUTU_WIDE8          eight-wide tree instead of the four-wide one where the scene has both: 0 never, 1 yes  [0, 1]
-		int wide8_inner_steps = 3;      // TUTU_WIDE8_INNER_STEPS      node visits per round on the eight-wide tree, closest-hit  [1, 64]
-		int wide8_inner_steps_any = 3;  // TUTU_WIDE8_INNER_STEPS_ANY  the same, any-hit  [1, 64]
+		int wide8 = 1;            // TUTU_WIDE8          eight-wide tree instead of the four-wide one: 0 never, 1 for small trees (the wide_early rule: fewer than
+		                          //                     wide_early_max_mb MB of four-wide nodes -- veach room +2 %, bunny stand-in +0.5 %; broom stand-in -10 %), 2 wherever the scene has one  [0, 2]
+		int wide8_inner_steps = 2;      // TUTU_WIDE8_INNER_STEPS      node visits per round on the eight-wide tree, closest-hit  [1, 64]
+		int wide8_inner_steps_any = 2;  // TUTU_WIDE8_INNER_STEPS_ANY  the same, any-hit  [1, 64]
 		int wide8_leaf_steps = 2;       // TUTU_WIDE8_LEAF_STEPS       leaf steps per round at most  [1, 8]
 		int wide8_leaf_again = 16;      // TUTU_WIDE8_LEAF_AGAIN       lanes with a leaf in hand that trigger a further leaf step, 65 = never  [1, 65]
 		int wide8_leaf_room = 6;        // TUTU_WIDE8_LEAF_ROOM        entries of the LDS column beyond depth + 2: room for leaf groups  [1, 32]
+		int wide_decoupled = 0;   // TUTU_WIDE_DECOUPLED four-wide tree: the hit leaves on a stack of their own, node steps never wait on a leaf (trace_persistent4d)  {0, 1}
+		int wide4d_inner_steps = 3;      // TUTU_WIDE4D_INNER_STEPS      node visits per round, closest-hit  [1, 64]
+		int wide4d_inner_steps_any = 3;  // TUTU_WIDE4D_INNER_STEPS_ANY  the same, any-hit  [1, 64]
+		int wide4d_leaf_steps = 2;       // TUTU_WIDE4D_LEAF_STEPS       leaf steps per round at most  [1, 8]
+		int wide4d_leaf_again = 16;      // TUTU_WIDE4D_LEAF_AGAIN       lanes with a leaf in hand that trigger a further leaf step, 65 = never  [1, 65]
+		int wide4d_leaf_room = 6;        // TUTU_WIDE4D_LEAF_ROOM        entries at the top of the LDS column that belong to the leaf stack  [5, 16]
+		int wide4d_lds_stack = 22;       // TUTU_WIDE4D_LDS_STACK        entries of the LDS column (node tier + leaf stack; 22 KB: seven blocks per CU)  [10, 64]
 		int lds_stack_max = 32;   // TUTU_LDS_STACK_MAX  k_trace, binary tree: entries of the LDS tier of a deep tree's stack, 0 = all in LDS  [0, 64]
 		int wide_lds_stack = 19;  // TUTU_WIDE_LDS_STACK k_trace, wide tree: entries of the LDS tier (19 KB: eight blocks per CU)  [4, 64]
 		int trace_xcd = 1;        // TUTU_TRACE_XCD      1: the blocks of one XCD take ADJACENT ranges of the work list  [0, 1]
@@ -188,7 +197,8 @@ struct TutuCtx {
 		int n_sets = 0;
 		size_t gstack_entries = 0;
 		WorkSet ws[TUTU_MAX_SETS];
-		double seconds = 0.0;       // how long the allocation took (get_option "grow_ms")
+		std::atomic<double> seconds{0.0};  // how long the allocation took (get_option "grow_ms")
+		bool adopted_once = false;  // full-size sets were adopted: from then on a render that needs more grows its sets in place (no second background growth)
 		// Pacing.  A device allocation that has to wait for memory another context just released (the driver clears it first:
 		// 17-27 GB/s measured, profiles/allocbench) STALLS the kernels that run meanwhile -- 16 x fewer launches per second while a
 		// second thread allocates (allocbench part 3), a 0.12 s frame took 2.6 s next to a 2.5 s allocation.  So the thread times
@@ -253,7 +263,14 @@ const KnobDesc kKnobs[] = {
     {"wide_inner_steps", "TUTU_WIDE_INNER_STEPS", &TutuCtx::Knobs::wide_inner_steps, 1, 64},
     {"wide_inner_steps_any", "TUTU_WIDE_INNER_STEPS_ANY", &TutuCtx::Knobs::wide_inner_steps_any, 1, 64},
     {"wide_early", "TUTU_WIDE_EARLY", &TutuCtx::Knobs::wide_early, 0, 2, true},
-    {"wide8", "TUTU_WIDE8", &TutuCtx::Knobs::wide8, 0, 1, true},
+    {"wide_decoupled", "TUTU_WIDE_DECOUPLED", &TutuCtx::Knobs::wide_decoupled, 0, 1, true},
+    {"wide4d_inner_steps", "TUTU_WIDE4D_INNER_STEPS", &TutuCtx::Knobs::wide4d_inner_steps, 1, 64},
+    {"wide4d_inner_steps_any", "TUTU_WIDE4D_INNER_STEPS_ANY", &TutuCtx::Knobs::wide4d_inner_steps_any, 1, 64},
+    {"wide4d_leaf_steps", "TUTU_WIDE4D_LEAF_STEPS", &TutuCtx::Knobs::wide4d_leaf_steps, 1, 8},
+    {"wide4d_leaf_again", "TUTU_WIDE4D_LEAF_AGAIN", &TutuCtx::Knobs::wide4d_leaf_again, 1, 65},
+    {"wide4d_leaf_room", "TUTU_WIDE4D_LEAF_ROOM", &TutuCtx::Knobs::wide4d_leaf_room, 5, 16, true},
+    {"wide4d_lds_stack", "TUTU_WIDE4D_LDS_STACK", &TutuCtx::Knobs::wide4d_lds_stack, 10, 64, true},
+    {"wide8", "TUTU_WIDE8", &TutuCtx::Knobs::wide8, 0, 2, true},
     {"wide8_inner_steps", "TUTU_WIDE8_INNER_STEPS", &TutuCtx::Knobs::wide8_inner_steps, 1, 64},
     {"wide8_inner_steps_any", "TUTU_WIDE8_INNER_STEPS_ANY", &TutuCtx::Knobs::wide8_inner_steps_any, 1, 64},
     {"wide8_leaf_steps", "TUTU_WIDE8_LEAF_STEPS", &TutuCtx::Knobs::wide8_leaf_steps, 1, 8},
@@ -412,10 +429,22 @@ void grow_join(TutuCtx* c) {
 }
 // the full-size sets are ready: they take the place of the sets in use (nothing of this context is in flight: called at the
 // start of a render, after the previous call returned synchronised)
+// the growth thread allocates memory that has to be cleared only while no GPU work of this context is in flight: every entry
+// point that launches kernels holds one of these
+struct InFlight {
+	TutuCtx* c;
+	explicit InFlight(TutuCtx* c_) : c(c_) { c->rendering.fetch_add(1, std::memory_order_acq_rel); }
+	~InFlight() {
+		c->idle_since_us.store(now_us(), std::memory_order_relaxed);
+		c->rendering.fetch_sub(1, std::memory_order_acq_rel);
+	}
+};
+
 void grow_adopt(TutuCtx* c) {
 	const int st = c->grow.state.load(std::memory_order_acquire);
 	if (st != 2 && st != 3) return;
 	grow_join(c);
+	if (st == 2) c->grow.adopted_once = true;
 	if (st == 2)
 		for (int k = 0; k < c->grow.n_sets; k++) {
 			if (c->grow.ws[k].cap <= c->ws[k].cap) continue;
@@ -443,7 +472,7 @@ void grow_start(TutuCtx* c, size_t cap, int n_sets, size_t gstack_entries) {
 			rc = ensure_set(c->grow.ws[k], c->grow.cap, c);
 			if (rc == TUTU_OK && c->grow.gstack_entries > 0) rc = c->grow.ws[k].gstack.ensure(c->grow.gstack_entries);
 		}
-		c->grow.seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+		c->grow.seconds.store(std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(), std::memory_order_relaxed);
 		c->grow.state.store(rc == TUTU_OK ? 2 : 3, std::memory_order_release);
 	});
 }
@@ -516,6 +545,22 @@ void launch_trace(TutuCtx* c, hipStream_t s, int grid, const TraceParams& tp) {
 		} else {
 			if (c->has_spheres) k_trace_wide8<ANY, true, false><<<g, b, c->ktrace_lds_bytes, s>>>(t8);
 			else k_trace_wide8<ANY, false, false><<<g, b, c->ktrace_lds_bytes, s>>>(t8);
+		}
+		return;
+	}
+	if (c->wide4d) {  // memory-resident scene: the four-wide quantised tree, leaves on a stack of their own
+		dim3 g(grid), b(256);
+		TraceParams t4 = tp;
+		t4.inner_steps = ANY ? c->knobs.wide4d_inner_steps_any : c->knobs.wide4d_inner_steps;
+		t4.leaf_steps = c->knobs.wide4d_leaf_steps;
+		t4.leaf_again = c->knobs.wide4d_leaf_again;
+		t4.leaf_room = c->knobs.wide4d_leaf_room;
+		if (c->wide_early) {
+			if (c->has_spheres) k_trace_wide4d<ANY, true, true><<<g, b, c->ktrace_lds_bytes, s>>>(t4);
+			else k_trace_wide4d<ANY, false, true><<<g, b, c->ktrace_lds_bytes, s>>>(t4);
+		} else {
+			if (c->has_spheres) k_trace_wide4d<ANY, true, false><<<g, b, c->ktrace_lds_bytes, s>>>(t4);
+			else k_trace_wide4d<ANY, false, false><<<g, b, c->ktrace_lds_bytes, s>>>(t4);
 		}
 		return;
 	}
@@ -846,19 +891,17 @@ int render_impl(TutuCtx* c, const TutuCameraFrame* cam, const TutuRenderParams* 
 	// 2794, but 6 x 86 2618 and 5 x 103 2463; bunny stand-in 24 x 11 spp 1316, 8 x 32 1389; veach room 20 x 26 1235, 8 x 64
 	// 1291; broom stand-in 128 x 8 613, 47 x 22 644.  Hence 42 Mi slots per work set: 16.6 GB each, 67 GB of the 288.)
 	grow_adopt(c);  // full-size work sets a background thread finished since the last call
-	struct InFlight {  // the growth thread allocates memory that has to be cleared only while no render is in flight
-		TutuCtx* c;
-		explicit InFlight(TutuCtx* c_) : c(c_) { c->rendering.store(1, std::memory_order_release); }
-		~InFlight() {
-			c->idle_since_us.store(now_us(), std::memory_order_relaxed);
-			c->rendering.store(0, std::memory_order_release);
-		}
-	} in_flight(c);
+	InFlight in_flight(c);
 	int64_t max_paths = rp->max_paths > 0 ? rp->max_paths : ((int64_t)168 << 20);
 	if (rp->max_paths <= 0) {
 		// the default must fit the device: at most half of what is free now plus what this context's work sets already hold
 		size_t free_b = 0, total_b = 0, held = 0;
-		for (int k = 0; k < TUTU_MAX_SETS; k++) held += (c->ws[k].cap + c->grow.ws[k].cap) * (size_t)TUTU_BYTES_PER_SLOT;
+		// (the sets on their way are read only once their thread is done; while it runs, what it is going to hold counts)
+		const int gst = c->grow.state.load(std::memory_order_acquire);
+		for (int k = 0; k < TUTU_MAX_SETS; k++) {
+			const size_t coming = (gst == 2 || gst == 3) ? c->grow.ws[k].cap : (gst == 1 && k < c->grow.n_sets ? c->grow.cap : 0);
+			held += (c->ws[k].cap + c->retired[k].cap + coming) * (size_t)TUTU_BYTES_PER_SLOT;
+		}
 		if (hipMemGetInfo(&free_b, &total_b) == hipSuccess)
 			max_paths = std::max<int64_t>((int64_t)4 << 20, std::min<int64_t>(max_paths, (int64_t)((free_b + held) / 2 / TUTU_BYTES_PER_SLOT)));
 	}
@@ -907,7 +950,7 @@ int render_impl(TutuCtx* c, const TutuCameraFrame* cam, const TutuRenderParams* 
 	// first render 1.84 s).  With the default sizing a context allocates only `cold_paths_mi` Mi slots itself (smaller, more
 	// numerous passes: a few per cent slower), a host thread allocates the full-size sets meanwhile, and the first render that
 	// finds them ready adopts them (grow_adopt above).  A caller that names max_paths or spp_per_pass gets exactly that, at once.
-	if (rp->max_paths <= 0 && rp->spp_per_pass <= 0 && c->knobs.cold_paths_mi > 0) {
+	if (rp->max_paths <= 0 && rp->spp_per_pass <= 0 && c->knobs.cold_paths_mi > 0 && !c->grow.adopted_once) {
 		size_t have = (size_t)-1;
 		for (int k = 0; k < use.n_sets; k++) have = std::min(have, c->ws[k].cap);
 		if (have < use.cap) {
@@ -1142,6 +1185,7 @@ int tutu_hip_create(const TutuSceneDesc* scene, int device, TutuCtx** out) {
 		DeviceBuild db;
 		HostBuildHooks hooks;
 		hooks.device_walked = on_device;
+		hooks.wide8_below_mb = c->knobs.wide8 == 0 ? 0 : (c->knobs.wide8 == 1 ? c->knobs.wide_early_max_mb : -1);
 		hooks.on_boxes = [&](const float* boxes6, uint32_t n, const float* lo, const float* hi) {
 			// the copy of the boxes happens here (the caller's array lives only as long as this call); the rest on the thread
 			std::vector<float> keep(boxes6, boxes6 + 6 * (size_t)n);
@@ -1154,7 +1198,7 @@ int tutu_hip_create(const TutuSceneDesc* scene, int device, TutuCtx** out) {
 				db.seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
 			});
 		};
-		rc = build_host_scene(scene, c->hs, on_device ? &hooks : nullptr);
+		rc = build_host_scene(scene, c->hs, &hooks);  // (device_walked = false: the hooks only carry the eight-wide tree's size rule)
 		if (db.th.joinable()) db.th.join();
 		if (rc == TUTU_OK && c->hs.device_walked) {
 			if (getenv("TUTU_BUILD_TIMING")) fprintf(stderr, "[tutu build] %-28s %8.3f s (its own thread, beside the host build)\n", "device: walked tree", db.seconds);
@@ -1180,7 +1224,9 @@ int tutu_hip_create(const TutuSceneDesc* scene, int device, TutuCtx** out) {
 			} else {
 				// the device build gave up (a box that cannot be quantised, a tree deeper than the stack): the host builds everything
 				c->d_wnodes.release();
-				rc = build_host_scene(scene, c->hs, nullptr);
+				HostBuildHooks host_only;
+				host_only.wide8_below_mb = hooks.wide8_below_mb;
+				rc = build_host_scene(scene, c->hs, &host_only);
 			}
 		}
 		db.release();
@@ -1196,7 +1242,7 @@ int tutu_hip_create(const TutuSceneDesc* scene, int device, TutuCtx** out) {
 		return fail(TUTU_E_HIP);
 	if ((rc = upload(c->d_leaf_boxes, c->hs.leaf_boxes, s)) != TUTU_OK) return fail(rc);
 	if (!c->hs.device_walked && (rc = upload(c->d_wnodes, c->hs.wnodes, s)) != TUTU_OK) return fail(rc);  // (the device build wrote d_wnodes itself)
-	if (c->hs.has_wide8 && c->knobs.wide8 == 1 && (rc = upload(c->d_wnodes8, c->hs.wnodes8, s)) != TUTU_OK) return fail(rc);
+	if (c->hs.has_wide8 && c->knobs.wide8 != 0 && (rc = upload(c->d_wnodes8, c->hs.wnodes8, s)) != TUTU_OK) return fail(rc);
 	c->textured = !c->hs.tri_tex.empty();
 	if (c->textured) {
 		if ((rc = upload(c->d_tri_tex, c->hs.tri_tex, s)) != TUTU_OK) return fail(rc);
@@ -1333,12 +1379,24 @@ int tutu_hip_create(const TutuSceneDesc* scene, int device, TutuCtx** out) {
 	// The eight-wide tree (round 5) where the scene has one: its LDS column holds the node stack (one group per level: depth + 1
 	// entries with the sentinel, + 1 for the step's own push) from the bottom and the leaf groups from the top; the exact walk
 	// of the deferred rays (reference tree) must fit as well.  No HBM tier.
-	c->wide8 = sc.has_wide && c->hs.has_wide8 && c->knobs.wide8 == 1 && !c->hs.device_walked;
+	c->wide8 = sc.has_wide && c->hs.has_wide8 && !c->hs.device_walked &&
+	           (c->knobs.wide8 == 2 || (c->knobs.wide8 == 1 && (((size_t)c->hs.n_wide * sizeof(GpuWideNode)) >> 20) < (size_t)c->knobs.wide_early_max_mb));
 	sc.has_wide8 = c->wide8 ? 1 : 0;
 	if (c->wide8) {
 		c->wide8_entries = std::max((int)c->hs.ref_depth + 1, (int)c->hs.wide8_depth + 2 + c->knobs.wide8_leaf_room);
 		c->ktrace_entries = c->wide8_entries;
 		c->ktrace_deep = 0;
+	}
+	// The four-wide tree with decoupled leaves (knob wide_decoupled): the LDS column = the LDS tier of the node stack (inner nodes
+	// only: up to three outstanding per level, a fourth in passing) + `leaf_room` entries of leaf stack at its top; the rest of the
+	// node stack in HBM as before.
+	c->wide4d = sc.has_wide && !c->wide8 && c->knobs.wide_decoupled == 1;
+	if (c->wide4d) {
+		const int need = 3 * (int)c->hs.wide_depth + 4 + TUTU_STACK_SENTINELS;
+		const int room = c->knobs.wide4d_leaf_room;
+		const int column = std::max((int)c->hs.ref_depth + 1, std::min(need + room, c->knobs.wide4d_lds_stack));
+		c->ktrace_entries = column;
+		c->ktrace_deep = std::max(0, need - (column - room));
 	}
 	c->ktrace_lds_bytes = (unsigned)((size_t)c->ktrace_entries * 256 * sizeof(int) + (c->lds_scene ? scene_bytes : 0));
 	// (+ the kernel's 32 B of static LDS: eight blocks of exactly 20 KB do NOT fit a CU, and the blocks that do not fit run
@@ -1349,7 +1407,7 @@ int tutu_hip_create(const TutuSceneDesc* scene, int device, TutuCtx** out) {
 	// registers -- so 7 blocks of 4 waves is what a CU holds.
 	const size_t wide_mb = ((size_t)c->hs.n_wide * sizeof(GpuWideNode)) >> 20;
 	c->wide_early = sc.has_wide && (c->knobs.wide_early == 2 || (c->knobs.wide_early == 1 && wide_mb < (size_t)c->knobs.wide_early_max_mb));
-	if (c->wide_early || c->wide8) c->trace_blocks_per_cu = std::min(c->trace_blocks_per_cu, 7);  // (k_trace_wide8: 72 registers as well)
+	if (c->wide_early || c->wide8 || c->wide4d) c->trace_blocks_per_cu = std::min(c->trace_blocks_per_cu, 7);  // (k_trace_wide8 / k_trace_wide4d: 72 registers as well)
 	// Fewer resident blocks than the LDS use allows (TUTU_TRACE_BPC): the request is padded so that exactly that many FIT --
 	// a grid of fewer blocks than fit is not spread evenly over the CUs by the dispatcher (some CUs get 8, others 2).
 	if (c->knobs.trace_bpc > 0 && c->knobs.trace_bpc < c->trace_blocks_per_cu) {
@@ -1469,6 +1527,10 @@ int tutu_hip_get_option(TutuCtx* c, const char* name, int* value) {
 		*value = rccl_available();
 		return TUTU_OK;
 	}
+	if (strcmp(name, "wide4d_tree") == 0) {  // the four-wide tree is walked with decoupled leaves (device_shade.h: trace_persistent4d)
+		*value = c->wide4d ? 1 : 0;
+		return TUTU_OK;
+	}
 	if (strcmp(name, "wide8_tree") == 0) {  // the persistent kernels walk the EIGHT-wide tree (device_shade.h: trace_persistent8)
 		*value = c->wide8 ? 1 : 0;
 		return TUTU_OK;
@@ -1529,7 +1591,7 @@ int tutu_hip_get_option(TutuCtx* c, const char* name, int* value) {
 		return TUTU_OK;
 	}
 	if (strcmp(name, "grow_ms") == 0) {  // how long the last background allocation took
-		*value = (int)(c->grow.seconds * 1e3);
+		*value = (int)(c->grow.seconds.load(std::memory_order_relaxed) * 1e3);
 		return TUTU_OK;
 	}
 	for (const KnobDesc& k : kKnobs)
@@ -1778,6 +1840,7 @@ int tutu_hip_trace_samples(TutuCtx* c, const TutuCameraFrame* cam, uint32_t n, c
 	for (uint32_t i = 0; i < n; i++)
 		if (pix[i] >= (uint32_t)(cam->width * cam->height) || smp[i] >= (1u << 24)) return TUTU_E_INVALID;  // sample index: 24 bits of the record (as spp in render_impl)
 	HIP_TRY(hipSetDevice(c->device));
+	InFlight in_flight(c);
 	hipStream_t s = c->stream;
 	int rc = ensure_work(c, ((size_t)n + 255) / 256 * 256, n, 1);
 	if (rc != TUTU_OK) return rc;
@@ -2018,6 +2081,7 @@ int tutu_hip_render_integrator(TutuCtx* c, int32_t type, const TutuCameraDesc* c
 	if (rc != TUTU_OK) return rc;
 	if (!out_rgb) return TUTU_E_INVALID;
 	HIP_TRY(hipSetDevice(c->device));
+	InFlight in_flight(c);
 	hipStream_t s = c->stream;
 	BidirParams p;
 	if ((rc = bidir_params(c, type, cam, spp, key0, key1, &p)) != TUTU_OK) return rc;
@@ -2112,6 +2176,7 @@ int tutu_hip_integrator_samples(TutuCtx* c, int32_t type, const TutuCameraDesc* 
 	for (uint32_t i = 0; i < n; i++)
 		if (pix[i] >= npix || smp[i] >= (uint32_t)spp) return TUTU_E_INVALID;
 	HIP_TRY(hipSetDevice(c->device));
+	InFlight in_flight(c);
 	hipStream_t s = c->stream;
 	BidirParams p;
 	if ((rc = bidir_params(c, type, cam, spp, key0, key1, &p)) != TUTU_OK) return rc;
@@ -2414,6 +2479,7 @@ int tutu_hip_trace_closest(TutuCtx* c, uint32_t n, const float* orig, const floa
 	if (!c || !orig || !dir || !hits) return TUTU_E_INVALID;
 	if (n == 0) return TUTU_OK;
 	HIP_TRY(hipSetDevice(c->device));
+	InFlight in_flight(c);
 	int rc = ensure_work(c, n, 1, 1);
 	if (rc != TUTU_OK) return rc;
 	std::vector<float4> A(n), B(n);
@@ -2442,6 +2508,7 @@ int tutu_hip_trace_any(TutuCtx* c, uint32_t n, const float* orig, const float* t
 	if (!c || !orig || !target || !blocked) return TUTU_E_INVALID;
 	if (n == 0) return TUTU_OK;
 	HIP_TRY(hipSetDevice(c->device));
+	InFlight in_flight(c);
 	int rc = ensure_work(c, n, 1, 1);
 	if (rc != TUTU_OK) return rc;
 	// plain shadow requests (no KILL, not FINAL): an unblocked ray leaves the verdict TUTU_V_ADD
