@@ -19,10 +19,6 @@ FORMS = {
     "wide_short_lds_stack": {"TUTU_WIDE": "2", "TUTU_WIDE8": "0", "TUTU_WIDE_LDS_STACK": "6"},   # most pushes land in the HBM tier
     "binary_two_tier_stack": {"TUTU_WIDE": "0", "TUTU_LDS_STACK_MAX": "6"},
     "wide_greedy_collapse": {"TUTU_WIDE": "2", "TUTU_WIDE8": "0", "TUTU_WIDE_COLLAPSE": "1"},    # the wide tree collapsed by surface area (host_scene.cpp)
-    # round 5: the four-wide tree with the hit leaves on a stack of their own (device_shade.h: trace_persistent4d)
-    "wide4d": {"TUTU_WIDE": "2", "TUTU_WIDE8": "0", "TUTU_WIDE_DECOUPLED": "1"},
-    "wide4d_tight_column": {"TUTU_WIDE": "2", "TUTU_WIDE8": "0", "TUTU_WIDE_DECOUPLED": "1", "TUTU_WIDE4D_LEAF_ROOM": "5", "TUTU_WIDE4D_LDS_STACK": "10"},  # HBM tier + stalls
-    "wide4d_long_rounds": {"TUTU_WIDE": "2", "TUTU_WIDE8": "0", "TUTU_WIDE_DECOUPLED": "1", "TUTU_WIDE4D_INNER_STEPS": "8", "TUTU_WIDE4D_INNER_STEPS_ANY": "6", "TUTU_WIDE4D_LEAF_STEPS": "1"},
     # round 5: the eight-wide tree (node groups, octant order, decoupled leaf stack; device_shade.h: trace_persistent8)
     "wide8": {"TUTU_WIDE": "2", "TUTU_WIDE8": "2"},
     "wide8_tight_column": {"TUTU_WIDE": "2", "TUTU_WIDE8": "2", "TUTU_WIDE8_LEAF_ROOM": "1"},    # lanes sit out node steps until leaf steps make room
@@ -64,8 +60,7 @@ def test_golden_rays_bit_exact_in_every_form(tr, port, monkeypatch, name, form):
             assert opt["lds_scene"] == 0
             assert opt["wide_tree"] == (1 if form.startswith("wide") else 0)
             assert opt["wide8_tree"] == (1 if form.startswith("wide8") else 0)
-            assert opt["wide4d_tree"] == (1 if form.startswith("wide4d") else 0)
-            assert opt["stack_entries_hbm"] > 0 or form == "binary" or form.startswith("wide8") or form.startswith("wide4d")  # (the eight-wide walk has no HBM tier)
+            assert opt["stack_entries_hbm"] > 0 or form == "binary" or form.startswith("wide8")  # (the eight-wide walk has no HBM tier)
         hits = ctx.trace_closest(O, D)
         h = hits["tri"] >= 0
         assert bit_equal(h.astype(np.uint8), z["scene.hit"])

@@ -334,6 +334,12 @@ __global__ void __launch_bounds__(256) k_shade(PassParams pp) {
 	constexpr bool GROUP = MODE == SHADE_ANY;
 	constexpr uint32_t WCH = 16;  // chunks per window
 	__shared__ uint16_t g_src[GROUP ? WCH * 64 : 1];
+	// Round 5: the window's list entries (| class << 29) and the triangles of its hits, read COALESCED while the window is sorted and
+	// kept in sorted order -- a chunk then starts with everything its loads hang on: record fields, hit and the hit triangle's
+	// shading record all go out at once, where the list entry, the records and the triangle record were three DEPENDENT round
+	// trips per chunk (this kernel waits 56-59 % of its wave-cycles at 0.35 of the issue peak and 0.34 of the HBM peak)
+	__shared__ uint32_t g_slot[GROUP ? WCH * 64 : 1];
+	__shared__ int32_t g_tri[GROUP ? WCH * 64 : 1];
 	__shared__ uint32_t g_cnt[GROUP ? 8 : 1];
 	__shared__ uint32_t g_next[1];
 	uint32_t win = blockIdx.x, win_chunks = 0;
@@ -372,11 +378,14 @@ __global__ void __launch_bounds__(256) k_shade(PassParams pp) {
 				if (threadIdx.x < 8) g_cnt[threadIdx.x] = 0u;
 				if (threadIdx.x == 0) g_next[0] = 0u;
 				__syncthreads();
-				uint32_t ecls[WCH / 4], erank[WCH / 4];
+				uint32_t ecls[WCH / 4], erank[WCH / 4], eslot[WCH / 4];
+				int32_t etri[WCH / 4];
 #pragma unroll
 				for (uint32_t q = 0; q < WCH / 4; q++) {
 					const uint32_t e = threadIdx.x + 256u * q;
 					const uint32_t c = e < n_ent ? (uint32_t)(pp.hitK[e0 + e] & 7) : 8u;  // 8: no entry
+					eslot[q] = e < n_ent ? pp.list[e0 + e] : 0u;
+					etri[q] = e < n_ent ? __float_as_int(reinterpret_cast<const float*>(pp.hitC)[4 * (size_t)(e0 + e) + 3]) : -1;
 					ecls[q] = c;
 					erank[q] = 0;
 					unsigned long long todo = __ballot(c < 8u);
@@ -406,6 +415,8 @@ __global__ void __launch_bounds__(256) k_shade(PassParams pp) {
 						for (uint32_t c = 0; c < 8; c++)
 							if (ecls[q] == c) b0 = cbase[c];
 						g_src[b0 + erank[q]] = (uint16_t)(threadIdx.x + 256u * q);
+						g_slot[b0 + erank[q]] = eslot[q] | (ecls[q] << 29);
+						g_tri[b0 + erank[q]] = etri[q];
 					}
 				__syncthreads();
 				win_chunks = (n_ent + 63u) >> 6;
@@ -420,6 +431,7 @@ __global__ void __launch_bounds__(256) k_shade(PassParams pp) {
 		uint32_t idx = 0;     // work item (FIRST only)
 		uint32_t j = 0;       // list position
 		uint32_t slot_in = 0;
+		int tri_pre = -1;     // GROUP: the triangle of this lane's hit, known before the hit record arrives
 		if (FIRST) {
 			idx = blockIdx.x * blockDim.x + threadIdx.x;
 			act = idx < (uint32_t)pp.npix;
@@ -430,8 +442,10 @@ __global__ void __launch_bounds__(256) k_shade(PassParams pp) {
 				act = e < min(WCH * 64u, n_in - e0);
 				j = e0 + (act ? (uint32_t)g_src[e] : 0u);
 				if (act) {
-					slot_in = pp.list[j];
-					chunk_class = pp.hitK[j] & 7;
+					const uint32_t sc29 = g_slot[e];
+					slot_in = sc29 & 0x1FFFFFFFu;
+					chunk_class = (int)(sc29 >> 29);
+					tri_pre = g_tri[e];
 				}
 			} else {
 				// the list entry and the class byte of a chunk are requested one chunk AHEAD (next_slot / next_class): the records
@@ -458,6 +472,13 @@ __global__ void __launch_bounds__(256) k_shade(PassParams pp) {
 			float t, b1, b2, pm = 0.f, cosprev = 0.f;
 			int tri;
 			uint32_t pix, smp, draw = 0, flags = 0, home;
+			float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0, s2 = s0, s3 = s0;  // the hit triangle's shading record
+			if (GROUP && tri_pre >= 0) {  // requested together with the path's record fields (below)
+				s0 = tb.tri(tri_pre, 0);
+				s1 = tb.tri(tri_pre, 1);
+				s2 = tb.tri(tri_pre, 2);
+				s3 = tb.tri(tri_pre, 3);
+			}
 			if (FIRST) {
 				const float4 pd = pp.prim_dir[idx];
 				const float4 ph = pp.prim_hit[idx];
@@ -503,10 +524,12 @@ __global__ void __launch_bounds__(256) k_shade(PassParams pp) {
 			float hit_light_pdf = 0.f;
 			bool is_sphere = false;
 			if (hit) {
-				const float4 s0 = tb.tri(tri, 0);
-				const float4 s1 = tb.tri(tri, 1);
-				const float4 s2 = tb.tri(tri, 2);
-				const float4 s3 = tb.tri(tri, 3);
+				if (!GROUP) {
+					s0 = tb.tri(tri, 0);
+					s1 = tb.tri(tri, 1);
+					s2 = tb.tri(tri, 2);
+					s3 = tb.tri(tri, 3);
+				}
 				const V3 n0 = mk(s0.x, s0.y, s0.z), n1 = mk(s0.w, s1.x, s1.y), n2 = mk(s1.z, s1.w, s2.x);
 				Ng = mk(s2.y, s2.z, s2.w);
 				mat_id = __float_as_int(s3.x);
@@ -823,8 +846,7 @@ struct TraceParams {
 	int leaf_again;      // lanes that must still hold a leaf for a second leaf step in the round (65: never)
 	int xcd_map;         // 1: the blocks of one XCD (blockIdx mod 8) take adjacent ranges of the list
 	uint32_t* defer;     // >= *n_ptr entries: list positions of the rays that are not plain, per wave range (below)
-	int leaf_steps;      // trace_persistent8 / trace_persistent4d: leaf steps per round at most
-	int leaf_room;       // trace_persistent4d: entries at the top of the lane's LDS column that belong to the leaf stack
+	int leaf_steps;      // trace_persistent8: leaf steps per round at most
 	int flat_share;      // k_trace_flat, closest hit: deal the wave's (ray, leaf) pairs to its lanes (knob "flat_share")
 };
 
@@ -1570,313 +1592,6 @@ TUTU_DEV void trace_persistent8(const SceneGlobal& ss, const TraceParams& tp, in
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// Round 5: the four-wide walk with DECOUPLED LEAVES (trace_persistent4d).  The lane census of trace_persistent<.., WIDE>
-//  says where a node step's lanes are: of 64, 32-38 walk a node and 13-15 SIT ON A LEAF -- a lane
-// that reaches a second leaf while one is parked can do nothing until the round's leaf step.  The eight-wide walk above keeps
-// the hit leaves on a stack of their own and its node steps run at 0.71-0.76 of the lanes where this tree's run at 0.58; that
-// idea is taken back to the four-wide tree, whose children are visited in true near-first order:
-//   * the node stack holds INNER nodes only; the nearest inner child hit is entered, the others are pushed far to near
-//     (unconditional stores, the pointer moves past the ones that count); two tiers as before (LDS, then HBM);
-//   * the hit LEAF children go to a leaf stack that grows down from the top of the lane's LDS column (far to near as well, so the
-//     nearest is popped first); one leaf is kept in hand (pend) so that a leaf step starts with the triangle fetch;
-//   * a lane is finished when its node stack is down to the sentinel and no leaf is in hand (leaf stack not empty => one in hand);
-//     a lane without room for four more leaves sits out the node steps until leaf steps have made room.
-// Same boxes, same arithmetic, same validation of every candidate as trace_persistent<.., WIDE>: only the ORDER in which a ray's
-// nodes and leaves are met changes, and hits do not depend on it (device_trace.h).
-template <bool ANY, bool SPH, bool EARLY>
-TUTU_DEV void trace_persistent4d(const SceneGlobal& ss, const TraceParams& tp, int* stack, const uint8_t* tri_class) {
-	const SceneDev& sc = tp.sc;
-	const int lane = __lane_id();
-	const unsigned long long lt_mask = (1ull << lane) - 1ull;
-	const uint32_t n = *tp.n_ptr;
-	const uint32_t n_waves = (gridDim.x * blockDim.x) >> 6;
-	uint32_t vblock = blockIdx.x;
-	if (tp.xcd_map) {  // the blocks of one XCD take adjacent ranges of the list (trace_persistent)
-		const uint32_t q = gridDim.x >> 3, rem = gridDim.x & 7u, x = blockIdx.x & 7u;
-		vblock = x * q + min(x, rem) + (blockIdx.x >> 3);
-	}
-	const uint32_t wave = (vblock * blockDim.x + threadIdx.x) >> 6;
-	const uint32_t per = (n + n_waves - 1) / n_waves;
-	const uint32_t begin = min(n, wave * per), end = min(n, begin + per);
-	uint32_t next = begin;
-	const float inf = __builtin_inff();
-	typedef __attribute__((address_space(3))) int lds_int;
-	typedef __attribute__((address_space(1))) int hbm_int;
-	lds_int* const lstack = (lds_int*)stack;
-	const int K = tp.stack_entries;   // entries of the lane's LDS column
-	const int KN = K - tp.leaf_room;  // ... of which [0, KN) are the LDS tier of the node stack and [KN, K) the leaf stack
-	const uint32_t gstride = gridDim.x * blockDim.x;
-	hbm_int* const gstack = (hbm_int*)(tp.gstack + (blockIdx.x * blockDim.x + threadIdx.x));
-	auto entry_read = [&](int e) -> int {  // entry e of this lane's node stack (trace_persistent: the two tiers carry their address spaces in the pointer types)
-		if (__ballot(e >= KN) != 0ull) {
-			int v = 0;
-			if (e < KN) v = lstack[e * 256];
-			else v = gstack[(size_t)(e - KN) * gstride];
-			return v;
-		}
-		return lstack[e * 256];
-	};
-	auto entry_write = [&](int e, int v) {
-		if (e < KN) lstack[e * 256] = v;
-		else gstack[(size_t)(e - KN) * gstride] = v;
-	};
-
-	lstack[0] = TUTU_TRAV_DONE;  // the sentinel: a pop below the lane's first entry ends the walk
-	int cur = TUTU_TRAV_IDLE;
-	int pend = TUTU_TRAV_IDLE;   // the leaf in hand (TUTU_TRAV_IDLE = none)
-	int sp = TUTU_STACK_SENTINELS;
-	int lp = K;                  // leaf stack: entries [lp, K)
-	uint32_t slot = 0;
-	RayPre r = make_ray(mk1(0.f), mk1(1.f));
-	float best_t = FLT_MAX, best_u = 0.f, best_v = 0.f;
-	int best_tri = -1;
-	float lim = FLT_MAX;
-	uint32_t n_nodes = 0, n_leaves = 0;
-	uint32_t w_node_steps = 0, w_leaf_steps = 0, n_def = 0, rounds = 0;
-	float dis = 0.f;
-	float4 Lpre = make_float4(0.f, 0.f, 0.f, 0.f);
-	V3 contrib = mk1(0.f);
-	uint32_t fl = 0;
-	bool blocked = false;
-
-	for (;;) {
-		// ---- refill (as trace_persistent<.., WIDE>)
-		const unsigned long long idle = __ballot(cur == TUTU_TRAV_IDLE);
-		if (idle != 0ull && next < end && (__popcll(idle) >= tp.refill_min || __ballot(cur != TUTU_TRAV_IDLE && (cur != TUTU_TRAV_DONE || pend != TUTU_TRAV_IDLE)) == 0ull)) {
-			const uint32_t i = next + (uint32_t)__popcll(idle & lt_mask);
-			bool exact = false;
-			if (cur == TUTU_TRAV_IDLE && i < end) {
-				slot = tp.list[i];
-				V3 so, lo = mk1(0.f);
-				if (!ANY) {
-					const float4 A = tp.rec.A[slot], B = tp.rec.B[slot];
-					slot = i;
-					so = mk(A.x, A.y, A.z);
-					r = make_ray(so, mk(B.x, B.y, B.z));
-					best_t = FLT_MAX; best_u = 0.f; best_v = 0.f; best_tri = -1;
-					lim = FLT_MAX;
-				} else {
-					fl = tp.rec.key[slot];
-					const float4 e0 = (fl & TUTU_KEY_ALT) ? tp.rec.S2[slot] : tp.rec.A[slot];
-					const float4 e1 = tp.rec.S[slot];
-					if (fl & TUTU_KEY_FINAL) {
-						Lpre = tp.rec.L[slot];
-						const float4 e2 = tp.rec.P[slot];
-						contrib = mk(e2.x, e2.y, e2.z);
-					}
-					so = mk(e0.x, e0.y, e0.z);
-					lo = mk(e1.x, e1.y, e1.z);
-					const V3 raydir = normalized(lo - so);  // isShadowRayBlocked, IIntegrator.hpp:135-137
-					dis = norm(lo - so);
-					r = make_ray(so, raydir);
-					lim = dis * TUTU_PRUNE_SLACK;
-					blocked = false;
-				}
-				sp = TUTU_STACK_SENTINELS;
-				lp = K;
-				pend = TUTU_TRAV_IDLE;
-				cur = TUTU_TRAV_DONE;
-				if (sc.root_ref != INT_MIN) {
-					if (!ray_is_plain(r) || !ray_fits_wide(sc, r)) {
-						exact = true;  // the reference's own tree, after the main loop; this round's finish writes nothing for it
-						if (ANY) fl |= 0x80000000u;
-						else best_tri = -2;
-					} else {
-						float te;
-						if (slab_plain(r, sc.root_min[0], sc.root_min[1], sc.root_min[2], sc.root_max[0], sc.root_max[1], sc.root_max[2], inf, te)) cur = 0;
-					}
-				}
-			}
-			const unsigned long long em = __ballot(exact);
-			if (em != 0ull) {
-				if (exact) tp.defer[begin + n_def + (uint32_t)__popcll(em & lt_mask)] = i;
-				n_def += (uint32_t)__popcll(em);
-			}
-			next += (uint32_t)__popcll(idle);
-		}
-		if (__ballot(cur != TUTU_TRAV_IDLE) == 0ull) break;
-		if (++rounds > TUTU_W8_WATCHDOG) {  // cannot happen; if it does the launch ends instead of hanging the device
-			n_nodes = 0xFFFFFFFFu;
-			break;
-		}
-
-		// ---- node steps
-#pragma unroll 1
-		for (int k = 0; k < tp.inner_steps; k++) {
-			const bool go = cur >= 0 && lp - 4 >= KN;  // (room for the four leaf stores of a step)
-			if (__ballot(go) == 0ull) break;
-			w_node_steps++;
-			if (go) {
-				n_nodes++;
-				const int p1 = entry_read(sp - 1);
-				const float4 n0 = sc.wnodes[4 * cur + 0], n1 = sc.wnodes[4 * cur + 1], n2 = sc.wnodes[4 * cur + 2], n3 = sc.wnodes[4 * cur + 3];
-				const float sx = r.inv.x * n0.w, sy = r.inv.y * n3.z, sz = r.inv.z * n3.w;  // 2^e / d: the scales are powers of two
-				const float ox = (n0.x - r.o.x) * r.inv.x, oy = (n0.y - r.o.y) * r.inv.y, oz = (n0.z - r.o.z) * r.inv.z;
-				const uint32_t qlx = __float_as_uint(n2.x), qly = __float_as_uint(n2.y), qlz = __float_as_uint(n2.z);
-				const uint32_t qhx = __float_as_uint(n2.w), qhy = __float_as_uint(n3.x), qhz = __float_as_uint(n3.y);
-				const uint32_t mx = (uint32_t)(__float_as_int(r.inv.x) >> 31), my = (uint32_t)(__float_as_int(r.inv.y) >> 31), mz = (uint32_t)(__float_as_int(r.inv.z) >> 31);
-				const uint32_t enx = (qhx & mx) | (qlx & ~mx), exx = (qlx & mx) | (qhx & ~mx);
-				const uint32_t eny = (qhy & my) | (qly & ~my), exy = (qly & my) | (qhy & ~my);
-				const uint32_t enz = (qhz & mz) | (qlz & ~mz), exz = (qlz & mz) | (qhz & ~mz);
-				float te[4];
-				bool h[4];
-#pragma unroll
-				for (int c = 0; c < 4; c++) {
-					const float ax = fmaf((float)((enx >> (8 * c)) & 0xFFu), sx, ox), bx = fmaf((float)((exx >> (8 * c)) & 0xFFu), sx, ox);
-					const float ay = fmaf((float)((eny >> (8 * c)) & 0xFFu), sy, oy), by = fmaf((float)((exy >> (8 * c)) & 0xFFu), sy, oy);
-					const float az = fmaf((float)((enz >> (8 * c)) & 0xFFu), sz, oz), bz = fmaf((float)((exz >> (8 * c)) & 0xFFu), sz, oz);
-					te[c] = raw_max3(ax, ay, raw_max(az, 0.f));
-					const float tx = raw_min3(bx, by, raw_min(bz, lim));
-					h[c] = te[c] <= tx;
-				}
-				const int c0 = __float_as_int(n1.x), c1 = __float_as_int(n1.y), c2 = __float_as_int(n1.z), c3 = __float_as_int(n1.w);
-				// visiting order = the binary walk's: the nearer PAIR first, inside a pair the nearer slot first (trace_persistent)
-				const bool nf = !ANY || tp.any_near_first;
-				const bool a0 = h[1] && (!h[0] || (nf && te[1] < te[0]));
-				const bool a1 = h[3] && (!h[2] || (nf && te[3] < te[2]));
-				const bool hg0 = h[0] || h[1], hg1 = h[2] || h[3];
-				const float tg0 = a0 ? te[1] : te[0], tg1 = a1 ? te[3] : te[2];
-				const bool g = hg1 && (!hg0 || (nf && tg1 < tg0));
-				const int f0 = a0 ? c1 : c0, s0 = a0 ? c0 : c1, f1 = a1 ? c3 : c2, s1 = a1 ? c2 : c3;
-				const bool hs0 = h[0] && h[1], hs1 = h[2] && h[3];
-				const int o0 = g ? f1 : f0, o1 = g ? s1 : s0, o2 = g ? f0 : f1, o3 = g ? s0 : s1;  // near ... far
-				const bool b0 = hg0 || hg1, b1 = g ? hs1 : hs0, b2 = g ? hg0 : hg1, b3 = g ? hs0 : hs1;
-				// inner children hit (i) and leaf children hit (f), in visiting order
-				const bool l0 = ref_is_leaf(o0), l1 = ref_is_leaf(o1), l2 = ref_is_leaf(o2), l3 = ref_is_leaf(o3);
-				const int i3 = (b3 && !l3) ? 1 : 0, i2 = (b2 && !l2) ? 1 : 0, i1 = (b1 && !l1) ? 1 : 0, i0 = (b0 && !l0) ? 1 : 0;
-				const int f3 = (b3 && l3) ? 1 : 0, f2 = (b2 && l2) ? 1 : 0, f1n = (b1 && l1) ? 1 : 0, f0n = (b0 && l0) ? 1 : 0;
-				// node stack: every inner child hit, far to near -- then the top is taken off again: the nearest inner child if there is
-				// one, else the entry that was on top before (p1)
-				if (__ballot(sp + 4 >= KN) != 0ull) {
-					entry_write(sp, o3);
-					entry_write(sp + i3, o2);
-					entry_write(sp + i3 + i2, o1);
-					entry_write(sp + i3 + i2 + i1, o0);
-				} else {
-					lstack[sp * 256] = o3;
-					lstack[(sp + i3) * 256] = o2;
-					lstack[(sp + i3 + i2) * 256] = o1;
-					lstack[(sp + i3 + i2 + i1) * 256] = o0;
-				}
-				cur = i0 ? o0 : (i1 ? o1 : (i2 ? o2 : (i3 ? o3 : p1)));
-				sp += i3 + i2 + i1 + i0 - 1;
-				// leaf stack (grows down): every leaf child hit, far to near; the nearest goes in hand if nothing is
-				lstack[(lp - 1) * 256] = o3;
-				lstack[(lp - 1 - f3) * 256] = o2;
-				lstack[(lp - 1 - f3 - f2) * 256] = o1;
-				lstack[(lp - 1 - f3 - f2 - f1n) * 256] = o0;
-				const int nf_leaves = f3 + f2 + f1n + f0n;
-				const bool take = pend == TUTU_TRAV_IDLE && nf_leaves != 0;
-				pend = take ? (f0n ? o0 : (f1n ? o1 : (f2 ? o2 : o3))) : pend;
-				lp -= nf_leaves - (take ? 1 : 0);
-			}
-		}
-
-		// ---- leaf steps: the leaf in hand; then the top of the leaf stack goes in hand
-#pragma unroll 1
-		for (int lk = 0; lk < tp.leaf_steps; lk++) {
-			const bool has = pend != TUTU_TRAV_IDLE;
-			const unsigned long long m_leaf = __ballot(has);
-			if (m_leaf == 0ull || (lk > 0 && __popcll(m_leaf) < tp.leaf_again)) break;
-			w_leaf_steps++;
-			if (has) {
-				n_leaves++;
-				const int le = lstack[min(lp, K - 1) * 256];  // the top of the leaf stack (if there is one), requested with the triangle
-				int ti;
-				float t, u, v;
-				const int item = ~pend;
-				if (EARLY) {
-					float4 lo, hi;
-					ss.lbox(SPH ? (item & ~TUTU_SPHERE_BIT) : item, lo, hi);
-					const bool h = leaf_test<SPH>(ss, item, r, ti, t, u, v);
-					bool cand;
-					if (ANY) cand = h && t < dis && !float_equal(t, dis);  // BVH.hpp:186
-					else cand = h && (t < best_t || (t == best_t && ti < best_tri));
-					float te;
-					if (cand && slab_plain(r, lo.x, lo.y, lo.z, hi.x, hi.y, hi.z, inf, te)) {  // validated (BVH.hpp:150; device_trace.h)
-						if (ANY) blocked = true;
-						else {
-							best_t = t; best_u = u; best_v = v; best_tri = ti;
-							lim = t * TUTU_PRUNE_SLACK_CLOSEST;
-						}
-					}
-				} else {
-					const bool h = leaf_test<SPH>(ss, item, r, ti, t, u, v);
-					bool cand;
-					if (ANY) cand = h && t < dis && !float_equal(t, dis);  // BVH.hpp:186
-					else cand = h && (t < best_t || (t == best_t && ti < best_tri));
-					if (cand) {
-						float4 lo, hi;
-						ss.lbox(ti, lo, hi);
-						float te;
-						if (slab_plain(r, lo.x, lo.y, lo.z, hi.x, hi.y, hi.z, inf, te)) {
-							if (ANY) blocked = true;
-							else {
-								best_t = t; best_u = u; best_v = v; best_tri = ti;
-								lim = t * TUTU_PRUNE_SLACK_CLOSEST;
-							}
-						}
-					}
-				}
-				if (ANY && blocked) {  // the first blocker ends the ray: both stacks are dropped
-					cur = TUTU_TRAV_DONE;
-					pend = TUTU_TRAV_IDLE;
-					lp = K;
-				} else {
-					const bool more = lp < K;
-					pend = more ? le : TUTU_TRAV_IDLE;
-					lp += more ? 1 : 0;
-				}
-			}
-		}
-
-		// ---- finish
-		if (cur == TUTU_TRAV_DONE && pend == TUTU_TRAV_IDLE) {
-			if (!ANY) {
-				if (best_tri != -2) {
-					st_stream(&tp.hitC[slot], make_float4(best_t, best_u, best_v, __int_as_float(best_tri)));
-					tp.hitK[slot] = best_tri >= 0 ? tri_class[best_tri] : (uint8_t)TUTU_CLASS_MISS;
-				}
-			} else if (fl & 0x80000000u) {
-			} else if (fl & TUTU_KEY_FINAL) {
-				float4 F = make_float4(Lpre.x, Lpre.y, Lpre.z, 0.f);
-				if (!blocked) {
-					F.x = F.x + contrib.x; F.y = F.y + contrib.y; F.z = F.z + contrib.z;
-				}
-				tp.F[__float_as_uint(Lpre.w)] = F;
-			} else if (!blocked) {
-				tp.rec.V[slot] = (uint8_t)((fl & TUTU_KEY_KILL) ? TUTU_V_KILLED : TUTU_V_ADD);
-			}
-			cur = TUTU_TRAV_IDLE;
-		}
-	}
-	// ---- the rays that are not plain: the reference's tree, the reference's slab, one ray per lane (device_trace.h)
-	if (n_def != 0u) {
-		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-		for (uint32_t j = (uint32_t)lane; j < n_def; j += 64u) exact_walk_entry<SceneGlobal, ANY>(ss, tp, tp.defer[begin + j], stack, tri_class);
-	}
-	if (tp.part) {
-		unsigned long long a = n_nodes, b = n_leaves;
-		for (int off = 32; off > 0; off >>= 1) {
-			a += __shfl_xor(a, off);
-			b += __shfl_xor(b, off);
-		}
-		__shared__ unsigned long long acc[4];
-		if (threadIdx.x < 4) acc[threadIdx.x] = 0ull;
-		__syncthreads();
-		if (lane == 0) {
-			atomicAdd(&acc[0], a);
-			atomicAdd(&acc[1], b);
-			atomicAdd(&acc[2], (unsigned long long)w_node_steps);
-			atomicAdd(&acc[3], (unsigned long long)w_leaf_steps);
-		}
-		__syncthreads();
-		if (threadIdx.x < 4) tp.part[4 * blockIdx.x + threadIdx.x] += acc[threadIdx.x];
-	}
-}
-
-// ------------------------------------------------------------------------------------------------------------
 // Tiny scenes: the FLAT scan (round 4).  A ray through the Cornell box visits 7.5 inner nodes of the walked tree -- 15 box
 // tests -- to reach 2-3 of its 16 leaves (the quads), at 61 % of a wave's lanes, with a stack, rounds, parked leaves and
 // refills around it.  Sixteen box tests in a row cost no more than those fifteen, need none of that, and run on ALL lanes:
@@ -2189,17 +1904,6 @@ __global__ void __launch_bounds__(256, 7) k_trace_wide(TraceParams tp) {
 	sg.tris = tp.sc.tri_isect;
 	sg.lboxes = tp.sc.leaf_boxes;
 	trace_persistent<SceneGlobal, ANY, SPH, true, true, EARLY>(sg, tp, lds + threadIdx.x, tp.tri_class);
-}
-
-// the four-wide tree with decoupled leaves (round 5): trace_persistent4d
-template <bool ANY, bool SPH, bool EARLY>
-__global__ void __launch_bounds__(256, 7) k_trace_wide4d(TraceParams tp) {
-	extern __shared__ int lds_dyn[];
-	SceneGlobal sg;
-	sg.nodes = tp.sc.nodes;
-	sg.tris = tp.sc.tri_isect;
-	sg.lboxes = tp.sc.leaf_boxes;
-	trace_persistent4d<ANY, SPH, EARLY>(sg, tp, lds_dyn + threadIdx.x, tp.tri_class);
 }
 
 // the eight-wide tree (round 5): trace_persistent8

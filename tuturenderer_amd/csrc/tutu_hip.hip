@@ -100,7 +100,6 @@ struct TutuCtx {
 	int ktrace_deep = 0;                    // ... and of the HBM tier (0: the whole stack is in LDS)
 	bool want_stats = true;                 // the current call was given a TutuStats (else no event pairs are recorded)
 	bool wide_early = false;                // wide tree: leaf box fetched with the triangle record (7 waves per SIMD)
-	bool wide4d = false;                    // the four-wide tree is walked with decoupled leaves (device_shade.h: trace_persistent4d)
 	bool wide8 = false;                     // the eight-wide tree is walked (device_shade.h: trace_persistent8)
 	int wide8_entries = 0;                  // ... entries of its LDS column: node stack from the bottom, leaf stack from the top
 	unsigned ktrace_lds_bytes = TUTU_STACK_DEPTH * 256 * sizeof(int);
@@ -141,13 +140,6 @@ struct TutuCtx {
 		int wide8_leaf_steps = 2;       // TUTU_WIDE8_LEAF_STEPS       leaf steps per round at most  [1, 8]
 		int wide8_leaf_again = 16;      // TUTU_WIDE8_LEAF_AGAIN       lanes with a leaf in hand that trigger a further leaf step, 65 = never  [1, 65]
 		int wide8_leaf_room = 6;        // TUTU_WIDE8_LEAF_ROOM        entries of the LDS column beyond depth + 2: room for leaf groups  [1, 32]
-		int wide_decoupled = 0;   // TUTU_WIDE_DECOUPLED four-wide tree: the hit leaves on a stack of their own, node steps never wait on a leaf (trace_persistent4d)  {0, 1}
-		int wide4d_inner_steps = 3;      // TUTU_WIDE4D_INNER_STEPS      node visits per round, closest-hit  [1, 64]
-		int wide4d_inner_steps_any = 3;  // TUTU_WIDE4D_INNER_STEPS_ANY  the same, any-hit  [1, 64]
-		int wide4d_leaf_steps = 2;       // TUTU_WIDE4D_LEAF_STEPS       leaf steps per round at most  [1, 8]
-		int wide4d_leaf_again = 16;      // TUTU_WIDE4D_LEAF_AGAIN       lanes with a leaf in hand that trigger a further leaf step, 65 = never  [1, 65]
-		int wide4d_leaf_room = 6;        // TUTU_WIDE4D_LEAF_ROOM        entries at the top of the LDS column that belong to the leaf stack  [5, 16]
-		int wide4d_lds_stack = 22;       // TUTU_WIDE4D_LDS_STACK        entries of the LDS column (node tier + leaf stack; 22 KB: seven blocks per CU)  [10, 64]
 		int lds_stack_max = 32;   // TUTU_LDS_STACK_MAX  k_trace, binary tree: entries of the LDS tier of a deep tree's stack, 0 = all in LDS  [0, 64]
 		int wide_lds_stack = 19;  // TUTU_WIDE_LDS_STACK k_trace, wide tree: entries of the LDS tier (19 KB: eight blocks per CU)  [4, 64]
 		int trace_xcd = 1;        // TUTU_TRACE_XCD      1: the blocks of one XCD take ADJACENT ranges of the work list  [0, 1]
@@ -263,13 +255,6 @@ const KnobDesc kKnobs[] = {
     {"wide_inner_steps", "TUTU_WIDE_INNER_STEPS", &TutuCtx::Knobs::wide_inner_steps, 1, 64},
     {"wide_inner_steps_any", "TUTU_WIDE_INNER_STEPS_ANY", &TutuCtx::Knobs::wide_inner_steps_any, 1, 64},
     {"wide_early", "TUTU_WIDE_EARLY", &TutuCtx::Knobs::wide_early, 0, 2, true},
-    {"wide_decoupled", "TUTU_WIDE_DECOUPLED", &TutuCtx::Knobs::wide_decoupled, 0, 1, true},
-    {"wide4d_inner_steps", "TUTU_WIDE4D_INNER_STEPS", &TutuCtx::Knobs::wide4d_inner_steps, 1, 64},
-    {"wide4d_inner_steps_any", "TUTU_WIDE4D_INNER_STEPS_ANY", &TutuCtx::Knobs::wide4d_inner_steps_any, 1, 64},
-    {"wide4d_leaf_steps", "TUTU_WIDE4D_LEAF_STEPS", &TutuCtx::Knobs::wide4d_leaf_steps, 1, 8},
-    {"wide4d_leaf_again", "TUTU_WIDE4D_LEAF_AGAIN", &TutuCtx::Knobs::wide4d_leaf_again, 1, 65},
-    {"wide4d_leaf_room", "TUTU_WIDE4D_LEAF_ROOM", &TutuCtx::Knobs::wide4d_leaf_room, 5, 16, true},
-    {"wide4d_lds_stack", "TUTU_WIDE4D_LDS_STACK", &TutuCtx::Knobs::wide4d_lds_stack, 10, 64, true},
     {"wide8", "TUTU_WIDE8", &TutuCtx::Knobs::wide8, 0, 2, true},
     {"wide8_inner_steps", "TUTU_WIDE8_INNER_STEPS", &TutuCtx::Knobs::wide8_inner_steps, 1, 64},
     {"wide8_inner_steps_any", "TUTU_WIDE8_INNER_STEPS_ANY", &TutuCtx::Knobs::wide8_inner_steps_any, 1, 64},
@@ -545,22 +530,6 @@ void launch_trace(TutuCtx* c, hipStream_t s, int grid, const TraceParams& tp) {
 		} else {
 			if (c->has_spheres) k_trace_wide8<ANY, true, false><<<g, b, c->ktrace_lds_bytes, s>>>(t8);
 			else k_trace_wide8<ANY, false, false><<<g, b, c->ktrace_lds_bytes, s>>>(t8);
-		}
-		return;
-	}
-	if (c->wide4d) {  // memory-resident scene: the four-wide quantised tree, leaves on a stack of their own
-		dim3 g(grid), b(256);
-		TraceParams t4 = tp;
-		t4.inner_steps = ANY ? c->knobs.wide4d_inner_steps_any : c->knobs.wide4d_inner_steps;
-		t4.leaf_steps = c->knobs.wide4d_leaf_steps;
-		t4.leaf_again = c->knobs.wide4d_leaf_again;
-		t4.leaf_room = c->knobs.wide4d_leaf_room;
-		if (c->wide_early) {
-			if (c->has_spheres) k_trace_wide4d<ANY, true, true><<<g, b, c->ktrace_lds_bytes, s>>>(t4);
-			else k_trace_wide4d<ANY, false, true><<<g, b, c->ktrace_lds_bytes, s>>>(t4);
-		} else {
-			if (c->has_spheres) k_trace_wide4d<ANY, true, false><<<g, b, c->ktrace_lds_bytes, s>>>(t4);
-			else k_trace_wide4d<ANY, false, false><<<g, b, c->ktrace_lds_bytes, s>>>(t4);
 		}
 		return;
 	}
@@ -920,6 +889,7 @@ int render_impl(TutuCtx* c, const TutuCameraFrame* cam, const TutuRenderParams* 
 		if (cap_limit > 0) spp_pass = (int)std::max<size_t>(1, std::min<size_t>((size_t)spp_pass, cap_limit / npix_pad));
 		spp_pass = std::min(spp_pass, rp->spp);
 		spp_pass = std::min(spp_pass, 65535);  // grid.y limit
+		spp_pass = (int)std::max<size_t>(1, std::min<size_t>((size_t)spp_pass, (((size_t)1 << 29) - 8192) / npix_pad));  // slot numbers fit 29 bits (k_shade's window tables)
 		int n_passes = (rp->spp + spp_pass - 1) / spp_pass;
 		if (rp->spp_per_pass <= 0 && n_passes >= TUTU_MAX_SETS) {
 			n_passes = (n_passes + TUTU_MAX_SETS - 1) / TUTU_MAX_SETS * TUTU_MAX_SETS;
@@ -1387,17 +1357,6 @@ int tutu_hip_create(const TutuSceneDesc* scene, int device, TutuCtx** out) {
 		c->ktrace_entries = c->wide8_entries;
 		c->ktrace_deep = 0;
 	}
-	// The four-wide tree with decoupled leaves (knob wide_decoupled): the LDS column = the LDS tier of the node stack (inner nodes
-	// only: up to three outstanding per level, a fourth in passing) + `leaf_room` entries of leaf stack at its top; the rest of the
-	// node stack in HBM as before.
-	c->wide4d = sc.has_wide && !c->wide8 && c->knobs.wide_decoupled == 1;
-	if (c->wide4d) {
-		const int need = 3 * (int)c->hs.wide_depth + 4 + TUTU_STACK_SENTINELS;
-		const int room = c->knobs.wide4d_leaf_room;
-		const int column = std::max((int)c->hs.ref_depth + 1, std::min(need + room, c->knobs.wide4d_lds_stack));
-		c->ktrace_entries = column;
-		c->ktrace_deep = std::max(0, need - (column - room));
-	}
 	c->ktrace_lds_bytes = (unsigned)((size_t)c->ktrace_entries * 256 * sizeof(int) + (c->lds_scene ? scene_bytes : 0));
 	// (+ the kernel's 32 B of static LDS: eight blocks of exactly 20 KB do NOT fit a CU, and the blocks that do not fit run
 	// after the others, alone -- a persistent grid must be resident as a whole)
@@ -1407,7 +1366,7 @@ int tutu_hip_create(const TutuSceneDesc* scene, int device, TutuCtx** out) {
 	// registers -- so 7 blocks of 4 waves is what a CU holds.
 	const size_t wide_mb = ((size_t)c->hs.n_wide * sizeof(GpuWideNode)) >> 20;
 	c->wide_early = sc.has_wide && (c->knobs.wide_early == 2 || (c->knobs.wide_early == 1 && wide_mb < (size_t)c->knobs.wide_early_max_mb));
-	if (c->wide_early || c->wide8 || c->wide4d) c->trace_blocks_per_cu = std::min(c->trace_blocks_per_cu, 7);  // (k_trace_wide8 / k_trace_wide4d: 72 registers as well)
+	if (c->wide_early || c->wide8) c->trace_blocks_per_cu = std::min(c->trace_blocks_per_cu, 7);  // (k_trace_wide8: 72 registers as well)
 	// Fewer resident blocks than the LDS use allows (TUTU_TRACE_BPC): the request is padded so that exactly that many FIT --
 	// a grid of fewer blocks than fit is not spread evenly over the CUs by the dispatcher (some CUs get 8, others 2).
 	if (c->knobs.trace_bpc > 0 && c->knobs.trace_bpc < c->trace_blocks_per_cu) {
@@ -1525,10 +1484,6 @@ int tutu_hip_get_option(TutuCtx* c, const char* name, int* value) {
 	}
 	if (strcmp(name, "rccl_available") == 0) {
 		*value = rccl_available();
-		return TUTU_OK;
-	}
-	if (strcmp(name, "wide4d_tree") == 0) {  // the four-wide tree is walked with decoupled leaves (device_shade.h: trace_persistent4d)
-		*value = c->wide4d ? 1 : 0;
 		return TUTU_OK;
 	}
 	if (strcmp(name, "wide8_tree") == 0) {  // the persistent kernels walk the EIGHT-wide tree (device_shade.h: trace_persistent8)
