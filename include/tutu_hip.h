@@ -205,6 +205,16 @@ int tutu_camera_raster(const TutuCameraDesc* cam, TutuCameraRaster* out);
 int tutu_bvh_build_preorder(uint32_t n_tris, const float* verts, uint32_t cap, uint32_t* n_nodes, float* bounds6,
                             int32_t* leaf_tri, TutuBvhInfo* info);
 
+/* Host-only (no GPU), for tests of the builder: the EIGHT-WIDE tree tutu_hip_create builds for memory-resident scenes (round 5;
+ * csrc/host_scene.hpp: GpuWide8Node, 128 B per node id).  It is one of the trees the traversal kernels may WALK instead of the
+ * reference's BVHAccel tree (BVH.hpp:47-123) -- never what decides a hit: every candidate is validated against the reference's leaf
+ * box (csrc/device_trace.h).  nodes128: cap_ids records of 128 B or NULL; *n_ids = ids in use (the ids of slots that hold no inner
+ * child are zero-filled holes), *n_nodes = nodes that exist, *depth = levels; leaf_boxes8: the reference's leaf box of every object in
+ * leaf order, [cap_objects][8] floats (min xyz, -, max xyz, -) or NULL; *margin = the quantisation margin of the boxes.
+ * TUTU_E_INVALID when the scene gets no such tree (fewer than three objects, coordinates the 8-bit frames cannot serve). */
+int tutu_host_wide8(const TutuSceneDesc* scene, uint32_t cap_ids, void* nodes128, uint32_t* n_ids, uint32_t* n_nodes, uint32_t* depth,
+                    uint32_t cap_objects, float* leaf_boxes8, uint32_t* n_objects, double* margin);
+
 const char* tutu_hip_error_string(int code);
 const char* tutu_hip_last_error(void); /* text of the last HIP failure on this thread */
 const char* tutu_hip_version(void);

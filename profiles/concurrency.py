@@ -10,7 +10,8 @@ import sys
 
 def short(n):
     for k, v in (("k_trace<true, false", "k_trace_closest"), ("k_trace<true, true", "k_trace_any"), ("k_trace<false, false", "k_trace_closest"),
-                 ("k_trace<false, true", "k_trace_any"), ("k_trace_wide<false", "k_trace_closest"), ("k_trace_wide<true", "k_trace_any"), ("k_shade<0", "k_shade_depth0"), ("k_shade<5", "k_shade_connect_only"), ("k_shade<", "k_shade"),
+                 ("k_trace<false, true", "k_trace_any"), ("k_trace_wide<false", "k_trace_closest"), ("k_trace_wide<true", "k_trace_any"), ("k_trace_wide8<false", "k_trace_closest"), ("k_trace_wide8<true", "k_trace_any"),
+                 ("k_trace_flat<false", "k_trace_closest"), ("k_trace_flat<true", "k_trace_any"), ("k_shade<0", "k_shade_depth0"), ("k_shade<5", "k_shade_connect_only"), ("k_shade<", "k_shade"),
                  ("k_list_", "lists"), ("k_resolve", "resolve"), ("k_finalize", "finalize"), ("k_primary", "primary")):
         if k in n:
             return v

@@ -34,6 +34,9 @@ def stage(name):
     if "k_trace_flat<" in name:
         params = name.split("k_trace_flat<")[1].split(">")[0].replace(" ", "").split(",")  # <ANY, SPH>
         return "k_trace_any" if params[0] == "true" else "k_trace_closest"
+    if "k_trace_wide8<" in name:
+        params = name.split("k_trace_wide8<")[1].split(">")[0].replace(" ", "").split(",")  # <ANY, SPH, EARLY>
+        return "k_trace_any" if params[0] == "true" else "k_trace_closest"
     if "k_trace_wide<" in name:
         params = name.split("k_trace_wide<")[1].split(">")[0].replace(" ", "").split(",")  # <ANY, SPH, EARLY>
         return "k_trace_any" if params[0] == "true" else "k_trace_closest"

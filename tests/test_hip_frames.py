@@ -104,22 +104,30 @@ def test_c4_broom_stand_in_1600x900_16spp_whole_frame_vs_reference_build(tr, mon
     assert n_diff == 0
 
 
-def test_c4_broom_stand_in_64spp_whole_frame_flip_noise_falls_with_spp(tr):
+def test_c4_broom_stand_in_64spp_whole_frame_noise_not_bias(tr):
     """Round 5.  The 16-spp pin of BASELINE configs[3] sits 2.4 x under the bar (mean L2 4.2e-4, 1.4 % of the pixels beyond 1e-2)
-    where every other config sits three orders under it.  If that is the noise of single samples that a last-bit difference in
-    sinf / cosf / acosf / tanf sent another way (MICROFACET_R floor, G_smf), it falls as 1 / spp; a bias would not.  The same frame
-    at 64 spp from the reference build (oracle/gen_frames.py c4_64: one hour of CPU; same key, so its samples 0..15 are the
-    16-spp fixture's): printed next to the 16-spp figures, the frame means compared to 1e-5."""
+    where every other config sits three orders under it.  The same frame at 64 spp from the reference build (oracle/gen_frames.py
+    c4_64: one hour of CPU; same key, so its samples 0..15 are the 16-spp fixture's) says what that is.  MEASURED (profiles/
+    r05_a_gpu_tests.log): the frame means agree to 1e-6 at both spp (no bias); the worst pixel falls 0.114 -> 0.034 and the share
+    beyond 1e-2 falls 1.39 % -> 0.50 % (a diverted sample weighs 1 / spp); the MEAN L2 stays, 4.19e-4 -> 3.95e-4 -- it does not fall
+    as 1 / spp, and it should not: about one sample in a thousand takes another path than the reference's (a last-bit difference in
+    sinf / cosf / acosf / tanf of the MICROFACET_R floor moves a hit point across one of the 4000 prisms' silhouettes), and while a
+    pixel sees at most a few such samples the mean over pixels of |difference| is (number of diverted samples) x (their weight) =
+    spp p x Delta / spp = p Delta, independent of spp; it turns into Delta sqrt(p / spp) only when every pixel holds many of them."""
     from tuturenderer_amd import scenes
 
     f16, w16 = _frame(tr, "c4", lambda: scenes.broom_room(1600, 900))
     l16, s16 = _compare("c4 broom stand-in 16 spp", f16, w16)
     f64, w64 = _frame(tr, "c4_64", lambda: scenes.broom_room(1600, 900))
     l64, s64 = _compare("c4 broom stand-in 64 spp", f64, w64)
-    print(f"[c4] mean L2 16 spp {l16:.3e} -> 64 spp {l64:.3e} (x {l64 / l16:.2f}; 1 / spp would be x 0.25); pixels beyond 1e-2: {s16:.3%} -> {s64:.3%}; "
-          f"frame means at 64 spp {f64.mean():.6f} / {w64.mean():.6f}")
-    assert l64 < 0.5 * l16          # noise of single diverted samples, not a bias
-    assert abs(float(f64.mean(dtype=np.float64)) - float(w64.mean(dtype=np.float64))) < 1e-5
+    d16 = np.sqrt(((f16.astype(np.float64) - w16) ** 2).sum(-1))
+    d64 = np.sqrt(((f64.astype(np.float64) - w64) ** 2).sum(-1))
+    print(f"[c4] mean L2 16 spp {l16:.3e} -> 64 spp {l64:.3e} (x {l64 / l16:.2f}); pixels beyond 1e-2: {s16:.3%} -> {s64:.3%}; worst pixel {d16.max():.3e} -> "
+          f"{d64.max():.3e}; pixels beyond 1e-4: {(d16 > 1e-4).mean():.2%} -> {(d64 > 1e-4).mean():.2%}; frame means at 64 spp {f64.mean():.6f} / {w64.mean():.6f}")
+    assert abs(float(f64.mean(dtype=np.float64)) - float(w64.mean(dtype=np.float64))) < 1e-5   # no bias
+    assert abs(float(f16.mean(dtype=np.float64)) - float(w16.mean(dtype=np.float64))) < 1e-5
+    assert s64 < 0.5 * s16 and d64.max() < 0.5 * d16.max()   # single diverted samples weigh 1 / spp
+    assert l64 <= l16 * 1.05                                  # and the mean does not grow
 
 
 NATIVE_FRAMES = {  # fixture -> (scene maker, tile size, bound on max |z|, bounds on mean z^2)

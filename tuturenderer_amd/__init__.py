@@ -16,7 +16,7 @@ LIB_PATH = os.environ.get("TUTU_HIP_LIB", os.path.join(HERE, "libtutu_hip.so")) 
 
 # every symbol include/tutu_hip.h declares
 ABI_SYMBOLS = [
-    "tutu_camera_frame", "tutu_bvh_build_preorder", "tutu_hip_error_string", "tutu_hip_last_error", "tutu_hip_version",
+    "tutu_camera_frame", "tutu_bvh_build_preorder", "tutu_host_wide8", "tutu_hip_error_string", "tutu_hip_last_error", "tutu_hip_version",
     "tutu_hip_device_count", "tutu_hip_create", "tutu_hip_destroy", "tutu_hip_render", "tutu_hip_render_device", "tutu_hip_render_multi",
     "tutu_hip_trace_closest", "tutu_hip_trace_any", "tutu_hip_trace_samples", "tutu_hip_eval_bxdf", "tutu_hip_eval_pdf",
     "tutu_hip_eval_sample", "tutu_hip_eval_sample_light", "tutu_hip_eval_fn", "tutu_hip_scene_info", "tutu_hip_eval_texture", "tutu_hip_set_option", "tutu_hip_get_option", "tutu_hip_postprocess", "tutu_hip_quantise",
@@ -237,6 +237,42 @@ def bvh_build_preorder(verts):
            "tutu_bvh_build_preorder")
     return b[: nn.value].copy(), leaf[: nn.value].copy(), {"n_tris": info.n_tris, "n_inner": info.n_inner, "depth": info.depth,
                                                             "root_bounds": np.array(list(info.root_bounds), np.float32)}
+
+
+def scene_desc(scene):
+    """(SceneDesc, keep-alive list) for a scene dict as produced by tuturenderer_amd.scenes"""
+    verts = _f32(scene["verts"]).reshape(-1, 9)
+    normals = _f32(scene["normals"]).reshape(-1, 9)
+    mat_id = np.ascontiguousarray(scene["mat_id"], dtype=np.int32)
+    mats = np.ascontiguousarray(scene["mats"], dtype=MAT_DTYPE)
+    d = SceneDesc()
+    d.n_tris = len(verts)
+    d.verts, d.normals, d.mat_id = verts.ctypes.data, normals.ctypes.data, mat_id.ctypes.data
+    d.n_mats = len(mats)
+    d.mats = mats.ctypes.data
+    d.eta = float(scene.get("eta", 1.0))
+    d.bkg = (C.c_float * 3)(*[float(x) for x in scene.get("bkg", (0, 0, 0))])
+    tex, tex_keep = pack_texture_set(scene)
+    d.textures = C.addressof(tex) if tex is not None else None
+    sph, sph_keep = pack_sphere_set(scene)
+    d.spheres = C.addressof(sph) if sph is not None else None
+    return d, [verts, normals, mat_id, mats, tex, tex_keep, sph, sph_keep]
+
+
+def host_wide8(scene):
+    """tutu_host_wide8 (no GPU): the eight-wide tree the library builds for `scene` -> (nodes as an (n_ids, 32) uint32 array,
+    info dict with n_nodes / depth / margin, the reference's leaf boxes (n_objects, 8))"""
+    lib = load_library()
+    d, keep = scene_desc(scene)
+    n_ids, n_nodes, depth, n_obj, margin = C.c_uint32(0), C.c_uint32(0), C.c_uint32(0), C.c_uint32(0), C.c_double(0)
+    _check(lib.tutu_host_wide8(C.byref(d), C.c_uint32(0), None, C.byref(n_ids), C.byref(n_nodes), C.byref(depth), C.c_uint32(0), None, C.byref(n_obj),
+                               C.byref(margin)), "tutu_host_wide8")
+    nodes = np.zeros((n_ids.value, 32), np.uint32)
+    boxes = np.zeros((n_obj.value, 8), np.float32)
+    _check(lib.tutu_host_wide8(C.byref(d), n_ids, _p(nodes), C.byref(n_ids), C.byref(n_nodes), C.byref(depth), n_obj, _p(boxes), C.byref(n_obj),
+                               C.byref(margin)), "tutu_host_wide8")
+    del keep
+    return nodes, {"n_nodes": n_nodes.value, "depth": depth.value, "margin": margin.value}, boxes
 
 
 class Context:

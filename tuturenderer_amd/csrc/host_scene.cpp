@@ -1466,6 +1466,25 @@ int tutu_bvh_build_preorder(uint32_t n_tris, const float* verts, uint32_t cap, u
 	return TUTU_OK;
 }
 
+// The eight-wide tree tutu_hip_create would build for this scene (build_wide8), without a GPU: for tests of the builder.
+int tutu_host_wide8(const TutuSceneDesc* scene, uint32_t cap_ids, void* nodes128, uint32_t* n_ids, uint32_t* n_nodes, uint32_t* depth,
+                    uint32_t cap_objects, float* leaf_boxes8, uint32_t* n_objects, double* margin) {
+	if (!scene || !n_ids || !n_nodes || !depth || !n_objects) return TUTU_E_INVALID;
+	tutu::HostScene hs;
+	tutu::HostBuildHooks hooks;  // (no device build; the eight-wide tree whatever the tree's size)
+	const int rc = tutu::build_host_scene(scene, hs, &hooks);
+	if (rc != TUTU_OK) return rc;
+	if (!hs.has_wide8) return TUTU_E_INVALID;
+	*n_ids = (uint32_t)hs.wnodes8.size();
+	*n_nodes = hs.n_wide8;
+	*depth = hs.wide8_depth;
+	*n_objects = (uint32_t)(hs.leaf_boxes.size() / 8);
+	if (margin) *margin = hs.wide_margin;
+	if (nodes128) memcpy(nodes128, hs.wnodes8.data(), sizeof(tutu::GpuWide8Node) * std::min<size_t>(cap_ids, hs.wnodes8.size()));
+	if (leaf_boxes8) memcpy(leaf_boxes8, hs.leaf_boxes.data(), sizeof(float) * 8 * std::min<size_t>(cap_objects, hs.leaf_boxes.size() / 8));
+	return TUTU_OK;
+}
+
 // Camera::initialize (Camera.hpp:12-17, 43-44) followed by the camera-frame lines of PathTracing::integrate
 // (PathTracing.hpp:357-391).  M_PI there is the float literal 3.1415926535897f (global.hpp:15).
 int tutu_camera_frame(const TutuCameraDesc* cam, TutuCameraFrame* out) {
