@@ -148,7 +148,7 @@ def load_library():
                         "There is no CPU fallback for the render path.")
     lib = C.CDLL(LIB_PATH)
     missing = [s for s in ABI_SYMBOLS if not hasattr(lib, s)]
-    if missing and "TUTU_HIP_LIB" in os.environ and all(s in ("tutu_hip_work_ready", "tutu_hip_render_multi_device") for s in missing):
+    if missing and "TUTU_HIP_LIB" in os.environ and all(s in ("tutu_hip_work_ready", "tutu_hip_render_multi_device", "tutu_host_wide8") for s in missing):
         missing = []  # an older build loaded for a same-box A/B run (profiles/ab.sh): the round-4 entry points are not called there
     if missing:
         raise TutuError(f"{LIB_PATH} lacks ABI symbols: {missing}")
