@@ -415,6 +415,31 @@ def main():
                         "note": "G rays/s of the kernel alone (exclusive step); lanes_active = share of a wave's 64 lanes with work in a step"},
                     "per_kernel": {k: dict(priced(src, k), algorithmic_bytes_per_unit=per_unit[k], hbm_bytes_per_unit=hbm_unit[k],
                                            bound=("valu" if (lds_scene and k != "k_shade") else "hbm"), pmc=sq.get(k)) for k in src}}
+        # Memory-resident scenes: the walks against the MEASURED random-gather rate of a CU's L1 / L2 path (profiles/gatherbench:
+        # every lane chases its own chain of 64-B nodes, no arithmetic) -- divergent 16-B lane requests per cycle and CU.  Requests
+        # per ray from the run's own counters and the form of the tree that was walked.
+        if not lds_scene:
+            try:
+                gb = json.load(open(os.path.join(ROOT, "profiles", "gatherbench", "gatherbench_r05.json")))
+                ceil64 = next(r for r in gb["rows"] if r["table_mb"] == 1 and r["node_bytes"] == 64 and r["variant"] == "own" and r["active_lanes"] == 64)
+                ceil37 = next(r for r in gb["rows"] if r["table_mb"] == 1 and r["node_bytes"] == 64 and r["variant"] == "own" and r["active_lanes"] == 37)
+                props = torch.cuda.get_device_properties(local_rank)
+                cus, hz = props.multi_processor_count, gb["clock_mhz"] * 1e6
+                w8, w4, early = bool(options.get("wide8_tree")), bool(options.get("wide_tree")), bool(options.get("wide_early"))
+                per_node = 5 if w8 else 4
+                per_leaf = (1 if w8 else 0) + 3 + (2 if (early or w8) else 0)
+                for k, nn, tt, fixed in (("k_trace_closest", n_c, t_c, 5), ("k_trace_any", n_s, t_s, 4)):
+                    req = (nn - tt) * per_node + tt * per_leaf + fixed
+                    rays_per_s = src[k]["units"] / max(src[k]["ms"] * 1e-3, 1e-12)
+                    rate = rays_per_s * req / cus / hz
+                    roofline["per_kernel"][k]["gather"] = {
+                        "requests_per_ray": req, "lane_requests_per_cycle_per_cu": rate,
+                        "ceiling_64_lanes": ceil64["lane_requests_per_cu_cycle"], "ceiling_37_lanes": ceil37["lane_requests_per_cu_cycle"],
+                        "frac_of_ceiling_64_lanes": rate / ceil64["lane_requests_per_cu_cycle"],
+                        "note": f"requests per ray = inner nodes x {per_node} + leaf tests x {per_leaf} + {fixed} (record, hit); ceiling = profiles/gatherbench, 1 MB table (L2-resident), "
+                                "dependent random 64-B node fetches per lane, 7 blocks per CU, no arithmetic; beyond L2 the same benchmark tops out at 80 G 128-B lines/s"}
+            except (OSError, KeyError, StopIteration, ValueError):
+                pass
         # what actually reaches HBM (memory-resident scenes: most node / triangle bytes are served by L2): the measured
         # bytes per unit of the committed PMC collection x this run's units / this run's exclusive kernel time
         if traffic is not None and sq.get(dom):
