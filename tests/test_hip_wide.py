@@ -468,7 +468,8 @@ def test_needles_pruned_walks_differ_only_where_the_hypothesis_fails(tr, port, m
             assert (h["tri"][~m] == -1).all()  # and never a hit where the reference has none
 
 
-def test_far_origin_ray_batch_on_the_broom_stand_in(tr, port):
+@pytest.mark.parametrize("walk", ["default", "eight_wide"])
+def test_far_origin_ray_batch_on_the_broom_stand_in(tr, port, monkeypatch, walk):
     """Rays whose origins lie outside the region the wide tree was quantised for are set aside for the exact walk; that walk uses
     the REFERENCE's tree (which fits the LDS tier of the stack by construction), never the SAH tree, whose depth on this scene
     (27) exceeds the tier (19) -- round 3's deferred walk picked the tree by `ray_is_plain` alone and could overrun LDS here."""
@@ -488,8 +489,11 @@ def test_far_origin_ray_batch_on_the_broom_stand_in(tr, port):
     O[::2] = (lo + (hi - lo) * rng.uniform(size=(n // 2, 3))).astype(np.float32)  # every other ray starts inside: both kinds in every wave
     S = port.scene(sc)
     hit, t, tri, pos, _, _ = S.closest(O, D.astype(np.float32))
+    if walk == "eight_wide":  # (round 5) the big tree through the eight-wide walk, which is not its default
+        monkeypatch.setenv("TUTU_WIDE8", "2")
     with tr.Context(sc) as ctx:
         opt = ctx.options()
+        assert opt["wide8_tree"] == (1 if walk == "eight_wide" else 0)
         assert opt["wide_tree"] == 1 and opt["fast_depth"] > opt["stack_entries"]
         h = ctx.trace_closest(O, D.astype(np.float32))
         assert bit_equal(h["tri"], np.where(hit == 1, tri, -1).astype(np.int32))

@@ -39,5 +39,5 @@ for name, (mk, key1) in golden_scenes().items():
         opt = ctx.options()
     S.close()
     bad_total += b1 + b2 + b3
-    print(f"{name}: rays {n} + {len(O2)} + {len(A)} segments, mismatches {b1} {b2} {b3}  (lds_scene {opt['lds_scene']} wide {opt['wide_tree']} refs {opt['n_refs']} pairs {opt.get('pair_leaves')}) {time.time() - t0:.1f} s", flush=True)
+    print(f"{name}: rays {n} + {len(O2)} + {len(A)} segments, mismatches {b1} {b2} {b3}  (lds_scene {opt['lds_scene']} wide {opt['wide_tree']} wide8 {opt.get('wide8_tree')} refs {opt['n_refs']} pairs {opt.get('pair_leaves')}) {time.time() - t0:.1f} s", flush=True)
 print("total mismatches", bad_total)
