@@ -387,10 +387,20 @@ int tutu_hip_quantise(TutuCtx* ctx, uint32_t n, const float* values, int32_t* le
  *   nodes take at least "wide_min_mb" TUTU_WIDE_MIN_MB [0,65536] megabytes (default 0: always), 2 always) |
  *   "wide_inner_steps" TUTU_WIDE_INNER_STEPS [1,64] / "wide_inner_steps_any" TUTU_WIDE_INNER_STEPS_ANY [1,64] | "wide_lds_stack" TUTU_WIDE_LDS_STACK [4,64] and "lds_stack_max"
  *   TUTU_LDS_STACK_MAX [0,64]: entries of the traversal stack kept in LDS (wide / binary tree); deeper ones live in HBM.
- *   Read-only facts: "wide_tree", "wide_depth", "fast_depth", "stack_entries", "stack_entries_hbm", "trace_blocks_per_cu",
+ *   "wide8" TUTU_WIDE8 [0,2] (create-only; round 5: the EIGHT-wide quantised tree -- one stack entry per set of pending children, visiting
+ *   order from per-node tables consumed with __ffs, leaves on a stack of their own; csrc/device_shade.h: trace_persistent8 -- 0 never, 1 for
+ *   trees of fewer than "wide_early_max_mb" megabytes of four-wide nodes (default: it gains 0.5-2 % there and loses 10 % on the broom
+ *   stand-in), 2 wherever the scene has one) with "wide8_inner_steps" / "wide8_inner_steps_any" TUTU_WIDE8_INNER_STEPS(_ANY) [1,64],
+ *   "wide8_leaf_steps" TUTU_WIDE8_LEAF_STEPS [1,8], "wide8_leaf_again" TUTU_WIDE8_LEAF_AGAIN [1,65], "wide8_leaf_room" TUTU_WIDE8_LEAF_ROOM
+ *   [1,32] (create-only); environment only (host tree build): TUTU_WIDE8_SLOTS = 2 kd slots + tables (default), 1 octant slots, 0 tree order.
+ *   "gather_rccl" TUTU_GATHER_RCCL [0,2] (tutu_hip_render_multi(_device), option of the FIRST context: the pieces travel by one grouped
+ *   RCCL send / recv: 0 never, 1 when the contexts sit on several devices, 2 always -- a context on the root's device by a self send / recv).
+ *   Read-only facts: "wide8_tree", "wide8_depth", "wide8_nodes", "wide8_entries", "gather_path" (how the last N-context frame was gathered:
+ *   0 copies, 1 RCCL, -1 none yet), "peer_access", "rccl_available",
+ *   "wide_tree", "wide_depth", "fast_depth", "stack_entries", "stack_entries_hbm", "trace_blocks_per_cu",
  *   "trace_lds_bytes", "work_paths_mi", "growing", "grow_ms".
  *   The knobs tutu_hip_create consumes (tree choice, LDS carve-up: "wide", "wide_min_mb", "wide_early", "wide_early_max_mb", "lds_stack_max",
- *   "wide_lds_stack", "trace_bpc") are refused by tutu_hip_set_option afterwards (TUTU_E_INVALID) unless the value is the one in effect.
+ *   "wide_lds_stack", "trace_bpc", "wide8", "wide8_leaf_room") are refused by tutu_hip_set_option afterwards (TUTU_E_INVALID) unless the value is the one in effect.
  *   Environment only (host tree build): TUTU_WIDE_COLLAPSE = 1 collapses the host-built wide tree greedily by surface area, 0 takes the
  *   grandchildren of every second binary level; unset: greedy when the walked tree holds more than 1.5 references per object, i.e. was built over
  *   clipped references (read-only fact "wide_greedy"; DESIGN.md section 6: +3 % on the broom stand-in, +2 % on the veach room, -3 % on the bunny
