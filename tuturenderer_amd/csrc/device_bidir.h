@@ -1029,7 +1029,10 @@ TUTU_DEV int bd_strategy_index(int L, int s) { return (L - 1) * (L + 2) / 2 + s;
 // another branch).  The eye vertex stays in registers over the loop over s; the MIS chains -- (fwdPdf, revPdf, G, isDelta) of the t eye
 // vertices and of the at most 8 - t light vertices a strategy of this block can reach -- sit in LDS, [entry][lane]: MISweight walks
 // them in two dependent loops, and from memory every step of those loops was a round trip (31 ms per Cornell frame).
-__global__ void __launch_bounds__(256) k_bd_connect(BidirParams p) {
+#ifndef TUTU_BD_CONNECT_WAVES
+#define TUTU_BD_CONNECT_WAVES 2  // waves per SIMD the connection kernel is built for (236 registers unconstrained)
+#endif
+__global__ void __launch_bounds__(256, TUTU_BD_CONNECT_WAVES) k_bd_connect(BidirParams p) {
 	__shared__ float4 s_chain[(TUTU_BIDIR_MAXLEN + 1) * 256];
 	// 1-D grid of 8 blocks per group of 256 units.  The eight blocks of a group (t = 1..8) re-read the same light vertices: they
 	// get ids that are equal mod 8 and close together, so that they run on the SAME XCD at about the same time and seven of the
