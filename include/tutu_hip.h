@@ -131,7 +131,7 @@ typedef struct TutuRenderParams {
 	int32_t n_pixels;
 	int32_t x0, y0, x1, y1;
 	int32_t spp_per_pass; /* samples per pixel traced per wavefront pass; 0 = choose from max_paths */
-	int64_t max_paths;    /* cap on paths in flight, summed over the (up to 4) work sets whose passes overlap (device memory ~ 400 B each); 0 = default 168 Mi = 67 GB, less if the device has less free.
+	int64_t max_paths;    /* cap on paths in flight, summed over the (up to 4) work sets whose passes overlap (device memory ~ 400 B each); 0 = default (option "paths_mi" TUTU_PATHS_MI [4,4096], 168 Mi = 67 GB), less if the device has less free.
 	                       * With the default (both 0), a context's FIRST render allocates only knob "cold_paths_mi" (12 Mi slots, 4.8 GB) itself and a host thread
 	                       * allocates the rest meanwhile (tutu_hip_work_ready); a caller that names a size gets exactly that, allocated before the call renders. */
 } TutuRenderParams;

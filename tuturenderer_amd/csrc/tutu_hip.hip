@@ -153,8 +153,9 @@ struct TutuCtx {
 		int flat = 1;             // TUTU_FLAT           tiny LDS-resident scenes (<= TUTU_FLAT_MAX leaves): the flat scan instead of the tree walk  {0, 1}
 		int gather_rccl = 1;      // TUTU_GATHER_RCCL    tutu_hip_render_multi(_device): the pieces travel by ONE grouped RCCL send / recv: 0 never (peer copies), 1 when the contexts sit on several devices, 2 always (contexts that share the root's device: a self send / recv)  [0, 2]
 		int exact = 0;            // TUTU_EXACT          every ray takes the exact walk: reference tree, reference slab, no pruning  {0, 1}
+		int paths_mi = 168;       // TUTU_PATHS_MI       Mi path slots in flight (all work sets together, ~400 B each) when the caller names none  [4, 4096]
 		int cold_paths_mi = 12;   // TUTU_COLD_PATHS_MI  Mi path slots (all work sets together) a context's FIRST default-sized render allocates itself;
-		                          //                     the rest of the default 168 Mi arrives from a background thread (0 = allocate everything at once)  [0, 4096]
+		                          //                     the rest of the default paths_mi arrives from a background thread (0 = allocate everything at once)  [0, 4096]
 		int bidir_units = 1 << 23;  // TUTU_BIDIR_UNITS  LightTracing / NaivePT / BDPT: (pixel, sample) units per batch  [64, 2^24]  (2 -> 8 Mi: LightTracing +8 %, NaivePT +20 %, BDPT flat; 3.8 GB of BDPT lists)
 	} knobs;
 	int shade_mode_all = SHADE_ANY;  // the kernel of that launch: the scene's only scattering class, or SHADE_ANY
@@ -275,6 +276,7 @@ const KnobDesc kKnobs[] = {
     {"device_build", "TUTU_DEVICE_BUILD", &TutuCtx::Knobs::device_build, 0, 2, true},
     {"device_build_min_k", "TUTU_DEVICE_BUILD_MIN_K", &TutuCtx::Knobs::device_build_min_k, 1, 1 << 20, true},
     {"cold_paths_mi", "TUTU_COLD_PATHS_MI", &TutuCtx::Knobs::cold_paths_mi, 0, 4096},
+    {"paths_mi", "TUTU_PATHS_MI", &TutuCtx::Knobs::paths_mi, 4, 4096},
 };
 
 // strict integer parse: the whole string must be a number inside [lo, hi]
@@ -861,7 +863,10 @@ int render_impl(TutuCtx* c, const TutuCameraFrame* cam, const TutuRenderParams* 
 	// 1291; broom stand-in 128 x 8 613, 47 x 22 644.  Hence 42 Mi slots per work set: 16.6 GB each, 67 GB of the 288.)
 	grow_adopt(c);  // full-size work sets a background thread finished since the last call
 	InFlight in_flight(c);
-	int64_t max_paths = rp->max_paths > 0 ? rp->max_paths : ((int64_t)168 << 20);
+	// Default: knob paths_mi = 168 Mi path slots = 67 GB of the 288.  (Round 5 measured 336 Mi = 134 GB -- four passes of 128 spp per
+	// Cornell frame instead of eight of 64: c3 +2...3.7 %, c5 +0...1 %, c2 +0.5 %, c4 unchanged, but create + first render of a second
+	// context 0.13 -> 0.24 s: profiles/sessions/r05_s15.sh, r05_s17.sh -- and left it a knob.)  Clamped to half of the free memory below
+	int64_t max_paths = rp->max_paths > 0 ? rp->max_paths : ((int64_t)c->knobs.paths_mi << 20);
 	if (rp->max_paths <= 0) {
 		// the default must fit the device: at most half of what is free now plus what this context's work sets already hold
 		size_t free_b = 0, total_b = 0, held = 0;
