@@ -139,3 +139,23 @@ def test_committed_bench_line_keeps_the_contract():
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in c, k
     assert c["kind"] in ("reference", "port") and c["unit"] == "Msamples/s" and c["cores"] >= 1
+
+
+def test_bench_busy_probe_and_configs_without_a_gpu():
+    """bench.py's helpers that need no device: the five BASELINE configs are named, and the sysfs busy probe (round 5: a cross-check
+    for a driver-side sampler that polls too slowly) returns a summary whether or not the host has amdgpu cards"""
+    import importlib.util
+    import os
+    import time
+
+    from conftest import ROOT
+
+    spec = importlib.util.spec_from_file_location("bench_module", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    cfg = bench.configs()
+    assert sorted(cfg) == ["c1", "c2", "c3", "c4", "c5"] and cfg["c2"]["spp"] == 512 and "BASELINE configs[1]" in cfg["c2"]["name"]
+    with bench.BusyProbe() as p:
+        time.sleep(0.12)
+    s = p.summary()
+    assert "samples" in s and (s["samples"] == 0 or 0 <= s["max_percent"] <= 100)
