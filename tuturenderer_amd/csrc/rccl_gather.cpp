@@ -107,7 +107,10 @@ int rccl_gather_run(RcclGather* g, int root_device, hipStream_t root_stream, con
 		return -1;
 	}
 	ncclResult_t r = a.GroupStart();
-	if (r != ncclSuccess) return fail(err, "ncclGroupStart", r) ? 0 : -1;
+	if (r != ncclSuccess) {
+		fail(err, "ncclGroupStart", r);
+		return -1;
+	}
 	bool ok = true;
 	for (int k = 0; k < n && ok; k++) {
 		const RcclPiece& p = pieces[k];
