@@ -3,9 +3,11 @@ written by oracle/gen_frames.py from oracle/_ref/libtutu_ref.so = /root/referenc
 the same Philox streams through the engine swap of oracle/ref_shim.h): what PathTracing.hpp:485-516 leaves in
 g->cam.FrameBuffer.rgb, pixel for pixel.
 
-The bar is north_star's: mean over pixels of the per-pixel L2 distance < 1e-3 at matched seed.  Printed next to it: the share
-of pixels beyond 1e-2 (paths that a last-bit difference in sinf / cosf / acosf / tanf / pow sent another way), the worst
-pixel, and how many pixels are equal bit for bit.
+north_star's bar is: mean over pixels of the per-pixel L2 distance < 1e-3 at matched seed.  The bar HERE since round 5 (the C
+library's sinf / cosf / acosf / tanf / powf restated for the device, csrc/device_libm.h) is 1e-6 for that mean, no pixel beyond
+1e-4 and frame means equal to 1e-6 -- measured 3e-9 .. 1e-8, worst pixel 4e-6 of a value of 19.5.  Until then 0.1-1.4 % of the
+pixels held a path that a last-bit difference in one of those functions had sent another way (mean 1e-6 .. 4e-4).  What is
+left -- about half of the pixels differ in a last bit -- is the order of the radiance sum (tests/test_hip_parity.py docstring).
 
 Also here: the statistical pin against the reference's NATIVE random numbers (std::mt19937 per thread, global.hpp:182-199; no
 engine swap): frame_native_cornell.npz, 128 x 128 at 4096 spp."""
@@ -35,10 +37,12 @@ def _compare(tag, frame, want):
     share = float((d > 1e-2).mean())
     worst = np.unravel_index(int(d.argmax()), d.shape)
     equal = float((frame.view(np.uint32) == want.view(np.uint32)).all(-1).mean())
-    print(f"\n[{tag}] {frame.shape[1]}x{frame.shape[0]}: mean per-pixel L2 vs the reference build {mean_l2:.3e} (bar 1e-3); pixels beyond 1e-2: "
+    print(f"\n[{tag}] {frame.shape[1]}x{frame.shape[0]}: mean per-pixel L2 vs the reference build {mean_l2:.3e} (bar here 1e-6; north_star 1e-3); pixels beyond 1e-2: "
           f"{share:.3%}; worst pixel (x={worst[1]}, y={worst[0]}) {d.max():.3e} of value {np.abs(want[worst]).max():.3f}; "
           f"bit-equal pixels {equal:.1%}; frame means {frame.mean():.6f} / {want.mean():.6f}")
-    assert mean_l2 < 1e-3, mean_l2
+    assert mean_l2 < 1e-6, mean_l2
+    assert share == 0.0 and d.max() < 1e-4 * max(1.0, float(np.abs(want[worst]).max())), (share, float(d.max()))
+    assert abs(float(frame.mean(dtype=np.float64)) - float(want.mean(dtype=np.float64))) < 1e-6
     return mean_l2, share
 
 
@@ -57,8 +61,7 @@ def test_c2_cornell_800x800_512spp_whole_frame_vs_reference_build(tr):
     from tuturenderer_amd import scenes
 
     frame, want = _frame(tr, "c2", lambda: scenes.cornell_box(800, 800))
-    _, share = _compare("c2 cornell 512 spp", frame, want)
-    assert share < 2e-2
+    _compare("c2 cornell 512 spp", frame, want)
 
 
 def test_c1_cornell_800x800_16spp_whole_frame_vs_reference_build(tr):
@@ -66,8 +69,7 @@ def test_c1_cornell_800x800_16spp_whole_frame_vs_reference_build(tr):
     from tuturenderer_amd import scenes
 
     frame, want = _frame(tr, "c1", lambda: scenes.cornell_box(800, 800))
-    _, share = _compare("c1 cornell 16 spp", frame, want)
-    assert share < 2e-2
+    _compare("c1 cornell 16 spp", frame, want)
 
 
 def test_c5_veach_800x600_512spp_whole_frame_vs_reference_build(tr):
@@ -104,30 +106,19 @@ def test_c4_broom_stand_in_1600x900_16spp_whole_frame_vs_reference_build(tr, mon
     assert n_diff == 0
 
 
-def test_c4_broom_stand_in_64spp_whole_frame_noise_not_bias(tr):
-    """Round 5.  The 16-spp pin of BASELINE configs[3] sits 2.4 x under the bar (mean L2 4.2e-4, 1.4 % of the pixels beyond 1e-2)
-    where every other config sits three orders under it.  The same frame at 64 spp from the reference build (oracle/gen_frames.py
-    c4_64: one hour of CPU; same key, so its samples 0..15 are the 16-spp fixture's) says what that is.  MEASURED (profiles/
-    r05_a_gpu_tests.log): the frame means agree to 1e-6 at both spp (no bias); the worst pixel falls 0.114 -> 0.034 and the share
-    beyond 1e-2 falls 1.39 % -> 0.50 % (a diverted sample weighs 1 / spp); the MEAN L2 stays, 4.19e-4 -> 3.95e-4 -- it does not fall
-    as 1 / spp, and it should not: about one sample in a thousand takes another path than the reference's (a last-bit difference in
-    sinf / cosf / acosf / tanf of the MICROFACET_R floor moves a hit point across one of the 4000 prisms' silhouettes), and while a
-    pixel sees at most a few such samples the mean over pixels of |difference| is (number of diverted samples) x (their weight) =
-    spp p x Delta / spp = p Delta, independent of spp; it turns into Delta sqrt(p / spp) only when every pixel holds many of them."""
+def test_c4_broom_stand_in_64spp_whole_frame_vs_reference_build(tr):
+    """Round 5.  The 16-spp pin of BASELINE configs[3] used to sit 2.4 x under the bar (mean L2 4.2e-4, 1.4 % of the pixels beyond
+    1e-2) where every other config sat three orders under it, and the same frame at 64 spp from the reference build (oracle/
+    gen_frames.py c4_64: one hour of CPU) showed what that was: unbiased noise of about one sample in a thousand that took another
+    path than the reference's -- 4.19e-4 -> 3.95e-4, worst pixel 0.114 -> 0.034, frame means equal to 1e-6 (profiles/sessions/
+    r05_c4_before_libm.txt).  Its cause was the last bit of sinf / cosf: a sampled direction one ulp off moves a hit point 1e-5
+    across one of the 4000 prisms' silhouettes.  With the C library's own sinf / cosf / acosf / tanf / powf on the device
+    (csrc/device_libm.h) both frames are the reference's to 1e-8 and no pixel differs by 1e-5."""
     from tuturenderer_amd import scenes
 
-    f16, w16 = _frame(tr, "c4", lambda: scenes.broom_room(1600, 900))
-    l16, s16 = _compare("c4 broom stand-in 16 spp", f16, w16)
-    f64, w64 = _frame(tr, "c4_64", lambda: scenes.broom_room(1600, 900))
-    l64, s64 = _compare("c4 broom stand-in 64 spp", f64, w64)
-    d16 = np.sqrt(((f16.astype(np.float64) - w16) ** 2).sum(-1))
-    d64 = np.sqrt(((f64.astype(np.float64) - w64) ** 2).sum(-1))
-    print(f"[c4] mean L2 16 spp {l16:.3e} -> 64 spp {l64:.3e} (x {l64 / l16:.2f}); pixels beyond 1e-2: {s16:.3%} -> {s64:.3%}; worst pixel {d16.max():.3e} -> "
-          f"{d64.max():.3e}; pixels beyond 1e-4: {(d16 > 1e-4).mean():.2%} -> {(d64 > 1e-4).mean():.2%}; frame means at 64 spp {f64.mean():.6f} / {w64.mean():.6f}")
-    assert abs(float(f64.mean(dtype=np.float64)) - float(w64.mean(dtype=np.float64))) < 1e-5   # no bias
-    assert abs(float(f16.mean(dtype=np.float64)) - float(w16.mean(dtype=np.float64))) < 1e-5
-    assert s64 < 0.5 * s16 and d64.max() < 0.5 * d16.max()   # single diverted samples weigh 1 / spp
-    assert l64 <= l16 * 1.05                                  # and the mean does not grow
+    for name, tag in (("c4", "16 spp"), ("c4_64", "64 spp")):
+        f, w = _frame(tr, name, lambda: scenes.broom_room(1600, 900))
+        _compare(f"c4 broom stand-in {tag}", f, w)
 
 
 NATIVE_FRAMES = {  # fixture -> (scene maker, tile size, bound on max |z|, bounds on mean z^2)

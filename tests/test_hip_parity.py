@@ -1,14 +1,15 @@
 """GPU (MI355X): the HIP path, called through the C ABI, against the CPU oracle and the golden vectors that the
 reference build produced.
 
-Bars:
-  * traversal decisions (hit / triangle index / blocked) and every +,-,*,/,sqrt-only quantity (t, barycentrics,
-    light samples, camera rays): BIT-EXACT;
-  * material functions that go through sinf/cosf/acosf/tanf/pow: <= 16 ulp of float32, or 1e-6 absolute + 2e-5
-    relative (the acosf->tanf chain of G_smf is ill-conditioned near grazing angles);
-  * per-sample radiance at matched Philox seed: relative 1e-4 for >= 99.5 % of the samples (the rest are discrete
-    branch flips caused by a last-bit difference in a transcendental);
-  * images at matched seed: mean per-pixel L2 < 1e-3 (the tolerance BASELINE.json's north_star states).
+Bars (round 5: with the C library's sinf / cosf / acosf / tanf / powf restated for the device, csrc/device_libm.h):
+  * traversal decisions (hit / triangle index / blocked), every +,-,*,/,sqrt-only quantity (t, barycentrics, light samples,
+    camera rays) AND every material function (BxDF, pdf, sampleDirection, Fresnel, D, G): BIT-EXACT;
+  * per-sample radiance at matched Philox seed: every sample within 5e-6 relative of the reference build's (measured: 4e-7 =
+    a few ulp; 13-34 % of the samples differ in a last bit).  What is left is the order of one sum: the reference's traceRay
+    is a recursion that adds from the tail, L_d = S_d + coe_d * L_{d+1} (PathTracing.hpp:275-277), the wavefront carries the
+    product of the coe's forward and adds S_d * beta_d as it goes -- the same real number, rounded in another order;
+  * images at matched seed: mean per-pixel L2 < 1e-6 (measured 3e-9 .. 1e-8; the tolerance BASELINE.json's north_star states
+    is 1e-3).
 """
 import numpy as np
 import pytest
@@ -211,13 +212,14 @@ def test_material_functions(tr, name):
     with tr.Context(scenes.cornell_box(8, 8)) as ctx:
         got = pc.run_material(Dev(ctx, Oracle("port")), name, mat, s_wi_at=want["s_wi"])
     got = {k[len(name) + 1:]: v for k, v in got.items()}
+    # Round 5: every output is the reference build's, bit for bit (until then the values that go through sinf / cosf / acosf / tanf /
+    # x^5 were held to 16 ulp, and a discrete outcome was allowed to flip where xi sat within an ulp of F).
     for k in ("s_ok", "s_special", "s_ndraws"):
-        assert count_diff(got[k], want[k]) <= 2, k  # discrete outcomes (a flip needs xi within an ulp of F)
+        assert count_diff(got[k], want[k]) == 0, k
     for k in ("bxdf", "bxdf_tir", "pdf", "s_wi", "s_pdf", "s_bxdf"):
         g, w = np.asarray(got[k], np.float32), np.asarray(want[k], np.float32)
-        close = (ulp_diff(g, w) <= 16) | (np.abs(g - w) <= 1e-6 + 2e-5 * np.abs(w))
-        # FLOAT_EQUAL / `< 0` branch flips on last-bit input differences are allowed to be rare
-        assert (~close).mean() < 2e-3, (k, int((~close).sum()), g[~close][:4], w[~close][:4])
+        bad = (g.view(np.uint32) != w.view(np.uint32)) & ~(np.isnan(g) & np.isnan(w))
+        assert not bad.any(), (k, int(bad.sum()), g[bad][:4], w[bad][:4])
 
 
 def test_texture_lookup_bit_exact(tr):
@@ -295,22 +297,16 @@ def test_per_sample_radiance_matched_seed(tr, port, name):
     fin = ~(nan_g | nan_w)
     err = np.abs(L[fin] - want[fin]).max(1)
     scale = np.maximum(np.abs(want[fin]).max(1), 1e-3)
-    ok = err <= 1e-4 * scale + 1e-6
-    frac_bad = 1.0 - ok.mean()
-    print(f"{name}: NaN samples {int(nan_w.sum())}; diverged {int((~ok).sum())}/{len(ok)} max rel err of the rest {float((err[ok] / scale[ok]).max()):.2e}")
-    # What the diverged samples do to a PICTURE (the round-3 review's question): a sample that took the other side of a
-    # rounding-noise decision is still a valid sample of the same estimator, so the picture moves by (its difference) / spp in
-    # one pixel and not at all in expectation.  Reported: the worst one, what it moves its pixel by at 512 spp, and the mean
-    # absolute difference over ALL samples -- an upper bound of the mean per-pixel shift of any frame drawn from them.
-    worst = float(err.max()) if len(err) else 0.0
-    mean_abs = float(err.mean()) if len(err) else 0.0
-    print(f"{name}: worst diverged sample |dL| {worst:.3e} (moves its pixel by {worst / 512:.2e} at 512 spp; radiance scale {float(np.abs(want[fin]).mean()):.3f}); "
-          f"mean |dL| over all samples {mean_abs:.3e}")
-    assert mean_abs < 1e-3, mean_abs  # (measured: 8e-5 on the sphere scene, <= 2e-7 on the others; the image bar is 1e-3)
-    # A shadow ray towards a point sampled on a sphere light ends 5e-4 in front of that sphere, and the sphere's own
-    # float quadratic (error ~3e-4 at room-scale distances) decides whether the light blocks itself: the reference's
-    # answer there is rounding noise, and a last-bit difference upstream flips it.  1 % instead of 0.5 % for that scene.
-    assert frac_bad < (1e-2 if name == "cornell_spheres" else 5e-3), frac_bad
+    ok = err <= 5e-6 * scale + 1e-7
+    bits = (L[fin].view(np.uint32) != want[fin].view(np.uint32)).any(1)
+    print(f"{name}: NaN samples {int(nan_w.sum())}; beyond 5e-6 relative {int((~ok).sum())}/{len(ok)}; max rel err {float((err / scale).max()):.2e}; "
+          f"samples with a differing last bit {bits.mean():.3f}; mean |dL| {float(err.mean()):.3e}")
+    # Until round 5, 0.1-1 % of the samples took another path than the reference's (a sampled direction one ulp off, from the
+    # device's own sinf / cosf, moved a hit across an edge or flipped a shadow ray at a sphere light's own surface).  None does
+    # now: the differences left are the rounding of the radiance sum (module docstring).
+    assert ok.all(), (int((~ok).sum()), float((err / scale).max()))
+    assert (nan_g == nan_w).all()
+    assert float(err.mean()) < 1e-6
     assert abs(L[fin].mean() - want[fin].mean()) < 2e-2 * max(want[fin].mean(), 1e-3)
     S.close()
 
@@ -326,7 +322,7 @@ def test_image_matched_seed_l2(tr, name):
     l2 = np.sqrt(((img - ref) ** 2).sum(-1))
     print(f"{name}: mean per-pixel L2 {l2.mean():.3e}  pixels with L2>1e-2: {(l2 > 1e-2).mean():.2e}  stats {st}")
     assert np.isfinite(img).all()
-    assert l2.mean() < 1e-3
+    assert l2.mean() < 1e-6  # (north_star: 1e-3)
     assert st["samples"] == img.shape[0] * img.shape[1] * 16
 
 
@@ -567,15 +563,54 @@ def test_device_math_helpers(fn_ctx, port):
     }
     for k, g in exact.items():
         assert count_diff(g, z[f"math.{k}"]) == 0, k
-    loose = {
+    # (until round 5 these three went through the device's own sinf / acosf / tanf / x^5 and were held to 16 ulp; with the C
+    # library's functions restated in csrc/device_libm.h they are the reference build's bits)
+    libm = {
         "fresnel": f("fresnel", a * scale, b, eta_i, eta_t)[:, 0],
         "fresnel_schlick": f("fresnel_schlick", cos, F0),
         "G": f("G", a, c, b, rough, h)[:, 0],
     }
-    for k, g in loose.items():
-        w = z[f"math.{k}"]
-        close = (ulp_diff(g, w) <= 16) | (np.abs(g - w) <= 1e-6 + 2e-5 * np.abs(w)) | (np.isnan(g) & np.isnan(w))
-        assert (~close).mean() < 2e-3, (k, int((~close).sum()))
+    for k, g in libm.items():
+        assert count_diff(g, z[f"math.{k}"]) == 0, k
+
+
+def test_device_libm_is_the_c_librarys(fn_ctx):
+    """csrc/device_libm.h on the DEVICE against the C library of this box (glibc 2.35, the one the reference build links): sinf,
+    cosf, acosf, tanf, powf on random bit patterns of the whole float32 range, on the ranges the path calls them with, and on the
+    special values.  (Exhaustively, compiled for the host: tests/test_libm_restatement.py and tests/tools/libm_check.c.)"""
+    import ctypes
+
+    ver = ctypes.CDLL(None).gnu_get_libc_version
+    ver.restype = ctypes.c_char_p
+    if ver().decode() != "2.35":
+        pytest.skip("device_libm.h restates glibc 2.35")
+    m = ctypes.CDLL("libm.so.6")
+    for nm in ("sinf", "cosf", "acosf", "tanf"):
+        getattr(m, nm).restype = ctypes.c_float
+        getattr(m, nm).argtypes = [ctypes.c_float]
+    m.powf.restype = ctypes.c_float
+    m.powf.argtypes = [ctypes.c_float, ctypes.c_float]
+    rng = np.random.default_rng(20261005)
+    n = 20000
+    special = np.array([0.0, -0.0, 1.0, -1.0, np.inf, -np.inf, np.nan, 1e-45, -1e-45, 1.17549435e-38, 3.4028235e38, 0.5, 2.0, 5.0,
+                        np.pi, np.pi / 2, np.pi / 4, 2 * np.pi, 0.785398185, 1.57079637, 3.14159274, 6.28318548, 1e9, 1e20, 1e30], np.float32)
+    x = np.concatenate([
+        rng.integers(0, 2 ** 32, n, dtype=np.uint64).astype(np.uint32).view(np.float32),  # any bit pattern
+        (rng.random(n) * 2 * np.pi).astype(np.float32),  # phi = 2 pi xi (sampleDirection)
+        (rng.random(n) * 2 - 1).astype(np.float32),  # cosines (acosf in G_smf, the sphere texture)
+        (rng.random(n) * np.pi).astype(np.float32),  # angles (tanf in G_smf)
+        (1 - rng.random(n) ** 4).astype(np.float32),  # near 1: grazing
+        special,
+    ])
+    y = np.concatenate([np.full(n, 5.0), np.full(n, 2.0), rng.normal(0, 3, n), np.full(n, -1.5), np.full(n, 0.5), special[::-1]]).astype(np.float32)
+    got = fn_ctx.eval_fn("libm", x, y)
+    want = np.empty_like(got)
+    for i, (xi, yi) in enumerate(zip(x.tolist(), y.tolist())):
+        want[i] = (m.sinf(xi), m.cosf(xi), m.acosf(xi), m.tanf(xi), m.powf(xi, yi), m.powf(xi, 5.0))
+    for k, nm in enumerate(("sinf", "cosf", "acosf", "tanf", "powf(x, y)", "powf(x, 5)")):
+        g, w = got[:, k], want[:, k]
+        bad = (g.view(np.uint32) != w.view(np.uint32)) & ~(np.isnan(g) & np.isnan(w))
+        assert not bad.any(), (nm, int(bad.sum()), x[bad][:4], y[bad][:4], g[bad][:4], w[bad][:4])
 
 
 def test_device_rng_known_answers(fn_ctx, port):
@@ -643,7 +678,7 @@ def _frame_checks(tr, port, sc, key1, spp, n_probe_pixels=12, n_samples=2000, lo
     fin = ~(np.isnan(Lg).any(1) | np.isnan(Lw).any(1))
     err = np.abs(Lg[fin] - Lw[fin]).max(1)
     scale = np.maximum(np.abs(Lw[fin]).max(1), 1e-3)
-    assert ((err > 1e-4 * scale + 1e-6).mean()) < 5e-3
+    assert (err <= 5e-6 * scale + 1e-7).all(), float((err / scale).max())  # (every sample takes the reference's path: module docstring)
     # Monte-Carlo error of the low-spp CPU mean: per-channel variance of its pixels / number of pixels (plus the frame's own, smaller)
     for ch in range(3):
         sigma = low[..., ch].std() / np.sqrt(low[..., ch].size) * 1.5

@@ -533,7 +533,7 @@ class Context:
         return wi, ok, sp, nd
 
     FN = {"bbox": (0, 1), "tri": (1, 11), "normalized": (2, 3), "fresnel": (3, 1), "fresnel_schlick": (4, 3), "reflect": (5, 3),
-          "refract": (6, 3), "D": (7, 1), "G": (8, 1), "mis": (9, 1), "local2world": (10, 3), "rng": (11, 8), "philox": (12, 4)}
+          "refract": (6, 3), "D": (7, 1), "G": (8, 1), "mis": (9, 1), "local2world": (10, 3), "rng": (11, 8), "philox": (12, 4), "libm": (13, 6)}
 
     def eval_fn(self, name, *arrays):
         """tutu_hip_eval_fn: one of the hot-path device functions on arrays (float32; the rng / philox inputs are uint32

@@ -138,7 +138,8 @@ TUTU_DEV bool bd_sample_light_dir(V3 N, float& dirPdf, V3& res_out, Rng& rng) { 
 	const float cosTheta = sqrtf(r1);
 	const float phi = 2 * TUTU_PI * r2;
 	const float sinTheta = sqrtf(std_max(0.f, 1 - r1));
-	V3 dir = mk(cosf(phi) * sinTheta, sinf(phi) * sinTheta, cosTheta);
+	const tutu_libm::SinCos sc = lm_sincosf(phi);
+	V3 dir = mk(sc.c * sinTheta, sc.s * sinTheta, cosTheta);
 	dir = normalized(dir);
 	const V3 res = SphereLocal2world(N, dir);
 	if (dot(normalized(res), N) < 0) return false;

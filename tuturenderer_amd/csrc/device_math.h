@@ -1,10 +1,13 @@
 // Device-side math of the path tracer: vector ops, Philox, Fresnel / GGX helpers, Material BxDF / pdf / sample.
 // gfx950 only.  Compiled with -ffp-contract=off and the default correctly-rounded fp32 divide/sqrt, expression
-// order kept as in the reference so that +,-,*,/,sqrt agree bit for bit with the CPU; only the transcendental
-// functions (sinf cosf acosf tanf powf) may differ from glibc by an ulp or two.
+// order kept as in the reference so that +,-,*,/,sqrt agree bit for bit with the CPU.  Round 5: the library functions of the path
+// (sinf cosf acosf tanf, powf(x, 5)) are the C library's own algorithms, restated operation for operation (device_libm.h: all 2^32
+// arguments of each bit-equal to glibc 2.35 on the host) -- a device sample is the reference's sample, bit for bit.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+
+#include "device_libm.h"
 
 namespace tutu {
 
@@ -52,14 +55,18 @@ TUTU_DEV float clampf(float lo, float hi, float v) { return std_max(lo, std_min(
 TUTU_DEV V3 ld3(const float* p) { return mk(p[0], p[1], p[2]); }
 TUTU_DEV bool any_nan(V3 v) { return isnan(v.x) || isnan(v.y) || isnan(v.z); }
 
-// x^2 and x^5 as the reference's powf(x, 2.f) / powf(x, 5.f) (global.hpp:257-258, 290, 298, 340).  glibc's powf is
-// correctly rounded for these; x*x is exact-rounded too, and x^5 is formed in double and rounded once.
+// x^2 and x^5 as the reference's powf(x, 2.f) / powf(x, 5.f) (global.hpp:257-258, 290, 298, 340).  The reference build's compiler
+// folds powf(x, 2.f) into x * x (checked: identical for all 2^32 floats); powf(x, 5.f) is a call into the C library, whose result is
+// NOT the correctly rounded x^5 for 1.4e-4 of all arguments: device_libm.h restates the library's algorithm.
 TUTU_DEV float pow2f(float x) { return x * x; }
-TUTU_DEV float pow5f(float x) {
-	double d = (double)x;
-	double d2 = d * d;
-	return (float)(d2 * d2 * d);
-}
+// The library functions of the path, with the library's bits (device_libm.h).  They are CALLED, not inlined: inlined into the shade
+// kernels their double-precision temporaries cost 27 registers (one-class kernel 126 -> 153: three waves per SIMD instead of
+// four; the generic kernel 165 -> 178: two instead of three -- its time +42 %).
+#define TUTU_LIBM_CALL __device__ __attribute__((noinline))
+TUTU_LIBM_CALL float pow5f(float x) { return tutu_libm::powf_glibc(x, 5.f); }
+TUTU_LIBM_CALL tutu_libm::SinCos lm_sincosf(float x) { return tutu_libm::sincos_pair_glibc(x); }  // every caller wants both of 2 pi xi
+TUTU_LIBM_CALL float lm_acosf(float x) { return tutu_libm::acosf_glibc(x); }
+TUTU_LIBM_CALL float lm_tanf(float x) { return tutu_libm::tanf_glibc(x); }
 
 // ------------------------------------------------------------------------------------------------ RNG
 // Philox4x32-10, counter (pix, smp, k>>2, 0), key (key0, key1); draw k = word k&3; xi = (u32>>8) * 2^-24.
@@ -165,10 +172,10 @@ TUTU_DEV float D_ndf(V3 h, V3 n, float roughness) {
 TUTU_DEV float G_smf(V3 wi, V3 wo, V3 n, float roughness, V3 h) {
 	float alpha = roughness * roughness;
 	alpha = std_max(alpha, 1e-3f);
-	float angle_wi_n = acosf(dot(wi, n));
-	float angle_wo_n = acosf(dot(wo, n));
-	float G1_wi = ((dot(wi, h) / dot(wi, n)) < 0 ? 0.f : 2.f) / (1 + sqrtf(1 + alpha * alpha * pow2f(tanf(angle_wi_n))));
-	float G1_wo = ((dot(wo, h) / dot(wo, n)) < 0 ? 0.f : 2.f) / (1 + sqrtf(1 + alpha * alpha * pow2f(tanf(angle_wo_n))));
+	float angle_wi_n = lm_acosf(dot(wi, n));
+	float angle_wo_n = lm_acosf(dot(wo, n));
+	float G1_wi = ((dot(wi, h) / dot(wi, n)) < 0 ? 0.f : 2.f) / (1 + sqrtf(1 + alpha * alpha * pow2f(lm_tanf(angle_wi_n))));
+	float G1_wo = ((dot(wo, h) / dot(wo, n)) < 0 ? 0.f : 2.f) / (1 + sqrtf(1 + alpha * alpha * pow2f(lm_tanf(angle_wo_n))));
 	if (isnan(G1_wi) || isnan(G1_wo)) return 0;
 	return G1_wi * G1_wo;
 }
@@ -296,7 +303,8 @@ TUTU_DEV void sampleDirection(Mat& m, V3 wo, V3 N, V3& sampledRes, float eta_i, 
 		float costheta = sqrtf((1 - r0) / (r0 * (a2 - 1) + 1));
 		float sintheta = sqrtf(1 - costheta * costheta);
 		float r = sintheta;
-		V3 h = normalized(mk(r * cosf(phi), r * sinf(phi), costheta));
+		const tutu_libm::SinCos sc = lm_sincosf(phi);
+		V3 h = normalized(mk(r * sc.c, r * sc.s, costheta));
 		V3 res = getReflectionDir(wo, SphereLocal2world(N, h));
 		res = normalized(res);
 		if (dot(res, N) <= 0) return;
@@ -314,7 +322,8 @@ TUTU_DEV void sampleDirection(Mat& m, V3 wo, V3 N, V3& sampledRes, float eta_i, 
 		float costheta = sqrtf((1 - r0) / (r0 * (a2 - 1) + 1));
 		float sintheta = sqrtf(1 - costheta * costheta);
 		float r = sintheta;
-		V3 h = normalized(mk(r * cosf(phi), r * sinf(phi), costheta));
+		const tutu_libm::SinCos sc = lm_sincosf(phi);
+		V3 h = normalized(mk(r * sc.c, r * sc.s, costheta));
 		float eta_t = m.eta;
 		V3 interN = N;
 		if (dot(wo, N) < 0) {
@@ -342,8 +351,9 @@ TUTU_DEV void sampleDirection(Mat& m, V3 wo, V3 N, V3& sampledRes, float eta_i, 
 		float phi = 2 * TUTU_PI * r2;
 		V3 dir;
 		float sinTheta = sqrtf(std_max(0.f, 1.f - r1));
-		dir.x = cosf(phi) * sinTheta;
-		dir.y = sinf(phi) * sinTheta;
+		const tutu_libm::SinCos sc = lm_sincosf(phi);
+		dir.x = sc.c * sinTheta;
+		dir.y = sc.s * sinTheta;
 		dir.z = cosTheta;
 		dir = normalized(dir);
 		V3 res = SphereLocal2world(N, dir);

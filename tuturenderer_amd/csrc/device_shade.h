@@ -241,7 +241,7 @@ TUTU_DEV void texture_modify(const SceneDev& sc, int tri, float b1, float b2, bo
 	const float4 x1 = sc.tri_tex[4 * tri + 1];
 	float tu, tv;
 	if (is_sphere) {
-		const float phi = acosf(Ng.z);
+		const float phi = lm_acosf(Ng.z);
 		tv = phi / TUTU_PI;
 		float theta = atan2f(Ng.y, Ng.x);
 		if (theta < 0) theta += 2 * TUTU_PI;

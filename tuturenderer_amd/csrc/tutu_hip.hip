@@ -2362,6 +2362,13 @@ __global__ void k_test_fn(FnArgs a) {
 		o[0] = rng.w0; o[1] = rng.w1; o[2] = rng.w2; o[3] = rng.w3;
 		break;
 	}
+	case TUTU_FN_LIBM: {  // the C library's functions as the path calls them (device_math.h's wrappers of device_libm.h): x, y -> sinf cosf acosf tanf powf(x, y) powf(x, 5)
+		const float x = a.in[0][i], y = a.in[1][i];
+		const tutu_libm::SinCos sc = lm_sincosf(x);
+		float* o = a.out + 6 * (size_t)i;
+		o[0] = sc.s; o[1] = sc.c; o[2] = lm_acosf(x); o[3] = lm_tanf(x); o[4] = tutu_libm::powf_glibc(x, y); o[5] = pow5f(x);
+		break;
+	}
 	default: break;
 	}
 }
@@ -2615,6 +2622,7 @@ static const struct { int n_in; int w[6]; int w_out; } kFnShape[TUTU_FN_COUNT] =
     /* LOCAL2WORLD */ {2, {3, 3, 0, 0, 0, 0}, 3},
     /* RNG */ {1, {5, 0, 0, 0, 0, 0}, 8},
     /* PHILOX */ {1, {5, 0, 0, 0, 0, 0}, 4},
+    /* LIBM */ {2, {1, 1, 0, 0, 0, 0}, 6},
 };
 
 int tutu_hip_eval_fn(TutuCtx* c, int32_t fn, uint32_t n, const float* const* in, float* out) {
