@@ -345,7 +345,8 @@ int tutu_hip_eval_sample_light(TutuCtx* ctx, uint32_t n, const float* xi3, int32
  *   RNG             the xi stream that replaces getRandomFloat         (pix, smp, key0, key1, first draw) as uint32 -> 8 xi
  *   PHILOX          Philox4x32-10 block                                (ctr0, ctr1, ctr2, key0, key1) as uint32 -> 4 words as uint32
  *   LIBM            the C library calls of the path (global.hpp:238-341, IIntegrator.hpp:196-206, Material.hpp:217-245: sinf cosf
- *                   acosf tanf powf), restated from glibc 2.35 in csrc/device_libm.h          x y -> sinf(x) cosf(x) acosf(x) tanf(x) powf(x, y) powf(x, 5) */
+ *                   acosf tanf powf; Sphere.hpp:64: atan2f), restated from glibc 2.35 in csrc/device_libm.h
+ *                                                                      x y -> sinf(x) cosf(x) acosf(x) tanf(x) powf(x, y) powf(x, 5) atan2f(x, y) atanf(x) */
 enum TutuFn {
 	TUTU_FN_BBOX = 0, TUTU_FN_TRI, TUTU_FN_NORMALIZED, TUTU_FN_FRESNEL, TUTU_FN_FRESNEL_SCHLICK, TUTU_FN_REFLECT, TUTU_FN_REFRACT,
 	TUTU_FN_D, TUTU_FN_G, TUTU_FN_MIS, TUTU_FN_LOCAL2WORLD, TUTU_FN_RNG, TUTU_FN_PHILOX, TUTU_FN_LIBM, TUTU_FN_COUNT

@@ -121,6 +121,35 @@ def test_c4_broom_stand_in_64spp_whole_frame_vs_reference_build(tr):
         _compare(f"c4 broom stand-in {tag}", f, w)
 
 
+EXACT_SUM_FRAMES = {
+    "c1": lambda sc: sc.cornell_box(800, 800), "c2": lambda sc: sc.cornell_box(800, 800), "c5": lambda sc: sc.veach_room(800, 600, small_light=False),
+    "c3": lambda sc: sc.bunny_box(1024, 1024), "c4": lambda sc: sc.broom_room(1600, 900), "c4_64": lambda sc: sc.broom_room(1600, 900),
+}
+
+
+@pytest.mark.parametrize("name", list(EXACT_SUM_FRAMES))
+def test_exact_sum_frame_is_the_reference_builds_bit_for_bit(tr, name):
+    """Round 5, knob exact_sum (TUTU_EXACT_SUM=1): a path's radiance is folded from its deepest vertex back -- L_v = S_v + L_{v+1} * coe_v,
+    the order in which the reference's recursion returns (PathTracing.hpp:275-277, :133) -- instead of carried forward as a sum of
+    throughput * term.  With the C library's functions restated for the device (csrc/device_libm.h) nothing else differed: every
+    BASELINE frame is then the reference build's frame, all 0.64-1.44 M pixels of it, bit for bit (c2: 0.33 G samples; the knob costs
+    4-17 % of the frame rate, DESIGN.md 2.6, so the default keeps the forward sum and differs by the rounding of that sum alone: 1e-8)."""
+    from tuturenderer_amd import scenes
+
+    z = np.load(golden_path(f"frame_{name}.npz"))
+    sc = EXACT_SUM_FRAMES[name](scenes)
+    with tr.Context(sc) as ctx:
+        ctx.set_option("exact_sum", 1)
+        frame = ctx.render(int(z["spp"]), int(z["key0"]), int(z["key1"]))
+        few = ctx.render(int(z["spp"]), int(z["key0"]), int(z["key1"]), max_paths=3_000_000) if name == "c1" else None
+    want = z["rgb"]
+    n_diff = int((frame.view(np.uint32) != want.view(np.uint32)).any(-1).sum())
+    print(f"\n[{name}, exact_sum] pixels whose bits differ from the reference build's: {n_diff} of {want.shape[0] * want.shape[1]}")
+    assert n_diff == 0
+    if few is not None:  # (many small passes: the same frame)
+        assert (few.view(np.uint32) == want.view(np.uint32)).all()
+
+
 NATIVE_FRAMES = {  # fixture -> (scene maker, tile size, bound on max |z|, bounds on mean z^2)
     "native_cornell": (lambda s: s.cornell_box(128, 128), 16, 5.0, (0.5, 1.8)),
     "native_veach": (lambda s: s.veach_room(160, 120, small_light=False), 8, 5.5, (0.5, 1.8)),

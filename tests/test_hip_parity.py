@@ -311,6 +311,25 @@ def test_per_sample_radiance_matched_seed(tr, port, name):
     S.close()
 
 
+@pytest.mark.parametrize("name", SCENES)
+def test_per_sample_radiance_exact_sum_is_the_reference_builds(tr, port, name):
+    """knob exact_sum (device_shade.h: PassParams::xlog): the radiance of every sample of every golden scene -- Lambertian, mirror, glass,
+    both microfacet models, textures, spheres, the degenerate light whose samples are NaN -- is the reference build's traceRay's, bit
+    for bit (NaN where it is NaN)."""
+    sc, key1 = _scene(name)
+    z = np.load(golden_path(f"scene_{name}.npz"))
+    S = port.scene(sc)
+    pix, smp = pc.sample_ids(S)
+    S.close()
+    with tr.Context(sc) as ctx:
+        ctx.set_option("exact_sum", 1)
+        L = ctx.trace_samples(pix, smp, pc.KEY0, key1)
+        assert ctx.get_option("exact_sum") == 1
+    want = z["samples.L"]
+    bad = ((L.view(np.uint32) != want.view(np.uint32)) & ~(np.isnan(L) & np.isnan(want))).any(1)
+    assert not bad.any(), (int(bad.sum()), L[bad][:3], want[bad][:3])
+
+
 @pytest.mark.parametrize("name", ["cornell", "cornell_ggxR_glass", "veach_slight", "cornell_degenerate", "cornell_textured", "cornell_spheres"])
 def test_image_matched_seed_l2(tr, name):
     sc, key1 = _scene(name)
@@ -576,7 +595,7 @@ def test_device_math_helpers(fn_ctx, port):
 
 def test_device_libm_is_the_c_librarys(fn_ctx):
     """csrc/device_libm.h on the DEVICE against the C library of this box (glibc 2.35, the one the reference build links): sinf,
-    cosf, acosf, tanf, powf on random bit patterns of the whole float32 range, on the ranges the path calls them with, and on the
+    cosf, acosf, tanf, powf, atanf, atan2f on random bit patterns of the whole float32 range, on the ranges the path calls them with, and on the
     special values.  (Exhaustively, compiled for the host: tests/test_libm_restatement.py and tests/tools/libm_check.c.)"""
     import ctypes
 
@@ -585,11 +604,12 @@ def test_device_libm_is_the_c_librarys(fn_ctx):
     if ver().decode() != "2.35":
         pytest.skip("device_libm.h restates glibc 2.35")
     m = ctypes.CDLL("libm.so.6")
-    for nm in ("sinf", "cosf", "acosf", "tanf"):
+    for nm in ("sinf", "cosf", "acosf", "tanf", "atanf"):
         getattr(m, nm).restype = ctypes.c_float
         getattr(m, nm).argtypes = [ctypes.c_float]
-    m.powf.restype = ctypes.c_float
-    m.powf.argtypes = [ctypes.c_float, ctypes.c_float]
+    for nm in ("powf", "atan2f"):
+        getattr(m, nm).restype = ctypes.c_float
+        getattr(m, nm).argtypes = [ctypes.c_float, ctypes.c_float]
     rng = np.random.default_rng(20261005)
     n = 20000
     special = np.array([0.0, -0.0, 1.0, -1.0, np.inf, -np.inf, np.nan, 1e-45, -1e-45, 1.17549435e-38, 3.4028235e38, 0.5, 2.0, 5.0,
@@ -606,8 +626,8 @@ def test_device_libm_is_the_c_librarys(fn_ctx):
     got = fn_ctx.eval_fn("libm", x, y)
     want = np.empty_like(got)
     for i, (xi, yi) in enumerate(zip(x.tolist(), y.tolist())):
-        want[i] = (m.sinf(xi), m.cosf(xi), m.acosf(xi), m.tanf(xi), m.powf(xi, yi), m.powf(xi, 5.0))
-    for k, nm in enumerate(("sinf", "cosf", "acosf", "tanf", "powf(x, y)", "powf(x, 5)")):
+        want[i] = (m.sinf(xi), m.cosf(xi), m.acosf(xi), m.tanf(xi), m.powf(xi, yi), m.powf(xi, 5.0), m.atan2f(xi, yi), m.atanf(xi))
+    for k, nm in enumerate(("sinf", "cosf", "acosf", "tanf", "powf(x, y)", "powf(x, 5)", "atan2f(x, y)", "atanf")):
         g, w = got[:, k], want[:, k]
         bad = (g.view(np.uint32) != w.view(np.uint32)) & ~(np.isnan(g) & np.isnan(w))
         assert not bad.any(), (nm, int(bad.sum()), x[bad][:4], y[bad][:4], g[bad][:4], w[bad][:4])

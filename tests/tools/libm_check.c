@@ -1,4 +1,4 @@
-// Compares the restated sinf / cosf / acosf / tanf of tuturenderer_amd/csrc/device_libm.h, compiled for the host, with the C
+// Compares the restated sinf / cosf / acosf / tanf / powf / atanf / atan2f of tuturenderer_amd/csrc/device_libm.h, compiled for the host, with the C
 // library of THIS machine, bit for bit, over every stride-th float bit pattern (stride 1 = all 2^32).  Test infrastructure.
 //   g++ -O2 -ffp-contract=off -fopenmp -o libm_check libm_check.c -lm && ./libm_check [stride]
 #include <math.h>
@@ -8,6 +8,8 @@
 #include <string.h>
 
 #include "../../tuturenderer_amd/csrc/device_libm.h"
+
+#define NF 13
 
 static inline int same(float a, float b) {
 	uint32_t x, y;
@@ -19,8 +21,8 @@ static inline int same(float a, float b) {
 
 int main(int argc, char** argv) {
 	const uint64_t stride = argc > 1 ? strtoull(argv[1], 0, 10) : 1;
-	unsigned long long bad[7] = {0, 0, 0, 0, 0, 0, 0}, n = 0;
-	uint32_t first[7] = {0, 0, 0, 0, 0, 0, 0};
+	unsigned long long bad[NF] = {0}, n = 0;
+	uint32_t first[NF] = {0};
 #pragma omp parallel for schedule(static) reduction(+ : n)
 	for (long long k = 0; k < (long long)((0x100000000ULL + stride - 1) / stride); k++) {
 		const uint32_t u = (uint32_t)((uint64_t)k * stride);
@@ -34,11 +36,19 @@ int main(int argc, char** argv) {
 				if (bad[0]++ == 0) first[0] = u;
 			}
 		}
-		const float got[7] = {sc.s, sc.c, tutu_libm::acosf_glibc(x), tutu_libm::tanf_glibc(x),
-		                      tutu_libm::powf_glibc(x, 5.f), tutu_libm::powf_glibc(x, 2.f), tutu_libm::powf_glibc(x, -1.5f)};
+		// atan2f: the second argument is a hash of the first (all exponents and signs), and x against itself halved / negated
+		uint32_t hsh = u * 2654435761u;
+		hsh ^= hsh >> 15;
+		float xo;
+		memcpy(&xo, &hsh, 4);
+		const float got[NF] = {sc.s, sc.c, tutu_libm::acosf_glibc(x), tutu_libm::tanf_glibc(x),
+		                       tutu_libm::powf_glibc(x, 5.f), tutu_libm::powf_glibc(x, 2.f), tutu_libm::powf_glibc(x, -1.5f),
+		                       tutu_libm::atanf_glibc(x), tutu_libm::atan2f_glibc(x, xo), tutu_libm::atan2f_glibc(xo, x), tutu_libm::atan2f_glibc(x, -0.75f * x),
+		                       tutu_libm::atan2f_glibc(x, 1.0f), tutu_libm::atan2f_glibc(1e-3f, x)};
 		volatile float e5 = 5.f, e2 = 2.f, em = -1.5f;  // (volatile: the compiler must call the library, not fold powf(x, 2) into x * x)
-		const float want[7] = {sinf(x), cosf(x), acosf(x), tanf(x), powf(x, e5), powf(x, e2), powf(x, em)};
-		for (int f = 0; f < 7; f++)
+		const float want[NF] = {sinf(x), cosf(x), acosf(x), tanf(x), powf(x, e5), powf(x, e2), powf(x, em),
+		                        atanf(x), atan2f(x, xo), atan2f(xo, x), atan2f(x, -0.75f * x), atan2f(x, 1.0f), atan2f(1e-3f, x)};
+		for (int f = 0; f < NF; f++)
 			if (!same(got[f], want[f])) {
 #pragma omp critical
 				{
@@ -46,9 +56,10 @@ int main(int argc, char** argv) {
 				}
 			}
 	}
-	const char* names[7] = {"sinf", "cosf", "acosf", "tanf", "powf(x, 5)", "powf(x, 2)", "powf(x, -1.5)"};
+	const char* names[NF] = {"sinf", "cosf", "acosf", "tanf", "powf(x, 5)", "powf(x, 2)", "powf(x, -1.5)",
+	                         "atanf", "atan2f(x, hash)", "atan2f(hash, x)", "atan2f(x, -0.75 x)", "atan2f(x, 1)", "atan2f(1e-3, x)"};
 	int rc = 0;
-	for (int f = 0; f < 7; f++) {
+	for (int f = 0; f < NF; f++) {
 		printf("%s: %llu arguments, %llu differ from this machine's libm", names[f], n, bad[f]);
 		if (bad[f]) {
 			float x;

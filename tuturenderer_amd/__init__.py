@@ -340,7 +340,7 @@ class Context:
 
     OPTION_NAMES = ("sets", "sets_default", "one_set", "shade_bpc", "trace_bpc", "refill_min", "inner_steps", "inner_steps_any", "leaf_again", "trace_xcd", "kernel_events", "any_near_first",
                     "util_stats", "bidir_units", "sah_tree", "n_refs", "lds_scene", "shade_tab", "fast_depth", "stack_entries", "stack_entries_hbm", "lds_stack_max", "wide", "wide_min_mb", "wide_inner_steps", "wide_inner_steps_any", "wide_tree", "wide_depth", "wide_early", "pair_leaves",
-                    "trace_blocks_per_cu", "trace_lds_bytes", "wide_lds_stack", "wide_early_max_mb", "exact", "cold_paths_mi", "work_paths_mi", "device_build", "device_build_min_k", "device_built", "flat", "flat_leaves", "flat_share", "wide_greedy",
+                    "trace_blocks_per_cu", "trace_lds_bytes", "wide_lds_stack", "wide_early_max_mb", "exact", "exact_sum", "cold_paths_mi", "work_paths_mi", "device_build", "device_build_min_k", "device_built", "flat", "flat_leaves", "flat_share", "wide_greedy",
                     "paths_mi", "gather_rccl", "gather_path", "peer_access", "rccl_available",
                     "wide8", "wide8_tree", "wide8_depth", "wide8_nodes", "wide8_entries", "wide8_inner_steps", "wide8_inner_steps_any", "wide8_leaf_steps", "wide8_leaf_again", "wide8_leaf_room")
 
@@ -533,7 +533,7 @@ class Context:
         return wi, ok, sp, nd
 
     FN = {"bbox": (0, 1), "tri": (1, 11), "normalized": (2, 3), "fresnel": (3, 1), "fresnel_schlick": (4, 3), "reflect": (5, 3),
-          "refract": (6, 3), "D": (7, 1), "G": (8, 1), "mis": (9, 1), "local2world": (10, 3), "rng": (11, 8), "philox": (12, 4), "libm": (13, 6)}
+          "refract": (6, 3), "D": (7, 1), "G": (8, 1), "mis": (9, 1), "local2world": (10, 3), "rng": (11, 8), "philox": (12, 4), "libm": (13, 8)}
 
     def eval_fn(self, name, *arrays):
         """tutu_hip_eval_fn: one of the hot-path device functions on arrays (float32; the rng / philox inputs are uint32

@@ -11,6 +11,7 @@
 //                 s_cosf.c, sincosf.h), in the variant built with -mfma (sysdeps/x86_64/fpu/multiarch/s_sinf-fma.c): which products
 //                 are fused was read off the machine code of __sinf_fma / __cosf_fma, and is spelled fma() below;
 //   acosf         fdlibm's float rational approximation (e_acosf.c), no fused operations;
+//   atanf, atan2f fdlibm's float code (s_atanf.c, e_atan2f.c), no fused operations -- the sphere's texture parametrisation (Sphere.hpp:64);
 //   tanf          fdlibm's float kernel (k_tanf.c) behind the double-precision argument reduction of s_tanf.c / the sincosf
 //                 tables (not fused there).
 // Every fp operation below is one IEEE operation in the order the library performs it; the file is compiled with
@@ -206,6 +207,95 @@ TUTU_LIBM_FN float acosf_glibc(float x) {
 		return dw + dw;
 	}
 #undef TUTU_ACOS_PQ
+}
+
+// ---- s_atanf.c (fdlibm, float; no fused operations)
+TUTU_LIBM_FN float atanf_glibc(float x) {
+	const uint32_t hx = f2u(x);
+	const uint32_t ix = hx & 0x7fffffffu;
+	if (ix >= 0x4c000000u) {  // |x| >= 2^25
+		if (ix > 0x7f800000u) return x + x;
+		if ((int32_t)hx > 0) return u2f(0x33a22168u) + u2f(0x3fc90fdau);  // atanhi[3] + atanlo[3]
+		return u2f(0xbfc90fdau) - u2f(0x33a22168u);
+	}
+	float hi = 0.f, lo = 0.f;
+	bool reduced = true;
+	if (ix < 0x3ee00000u) {  // |x| < 0.4375
+		if (ix < 0x31000000u) return x;  // |x| < 2^-29
+		reduced = false;
+	} else {
+		x = u2f(ix);
+		if (ix < 0x3f980000u) {  // |x| < 1.1875
+			if (ix < 0x3f300000u) {  // 7/16 <= |x| < 11/16
+				hi = u2f(0x3eed6338u); lo = u2f(0x31ac3769u);
+				x = ((x + x) - 1.0f) / (x + 2.0f);
+			} else {  // 11/16 <= |x| < 19/16
+				hi = u2f(0x3f490fdau); lo = u2f(0x33222168u);
+				x = (x - 1.0f) / (x + 1.0f);
+			}
+		} else if (ix < 0x401c0000u) {  // |x| < 2.4375
+			hi = u2f(0x3f7b985eu); lo = u2f(0x33140fb4u);
+			x = (x - 1.5f) / (x * 1.5f + 1.0f);
+		} else {
+			hi = u2f(0x3fc90fdau); lo = u2f(0x33a22168u);
+			x = -1.0f / x;
+		}
+	}
+	const float z = x * x;
+	const float w = z * z;
+	float s1 = u2f(0x3c8569d7u) * w;
+	s1 = s1 + u2f(0x3d4bda59u); s1 = s1 * w; s1 = s1 + u2f(0x3d886b35u); s1 = s1 * w; s1 = s1 + u2f(0x3dba2e6eu); s1 = s1 * w;
+	s1 = s1 + u2f(0x3e124925u); s1 = s1 * w; s1 = s1 + u2f(0x3eaaaaabu); s1 = s1 * z;
+	float s2 = u2f(0xbd15a221u) * w;
+	s2 = s2 - u2f(0x3d6ef16bu); s2 = s2 * w; s2 = s2 - u2f(0x3d9d8795u); s2 = s2 * w; s2 = s2 - u2f(0x3de38e38u); s2 = s2 * w;
+	s2 = s2 - u2f(0x3e4ccccdu); s2 = s2 * w;
+	const float t = (s1 + s2) * x;
+	if (!reduced) return x - t;
+	const float r = hi - ((t - lo) - x);
+	return (int32_t)hx < 0 ? -r : r;
+}
+
+// ---- e_atan2f.c (fdlibm, float)
+TUTU_LIBM_FN float atan2f_glibc(float y, float x) {
+	const float tiny = u2f(0x0da24260u), pi_o_4 = u2f(0x3f490fdbu), pi_o_2 = u2f(0x3fc90fdbu), pi = u2f(0x40490fdbu), neg_pi_lo = u2f(0x33bbbd2eu);
+	const uint32_t hx = f2u(x), hy = f2u(y);
+	const uint32_t ix = hx & 0x7fffffffu, iy = hy & 0x7fffffffu;
+	if (ix > 0x7f800000u || iy > 0x7f800000u) return x + y;
+	if (hx == 0x3f800000u) return atanf_glibc(y);
+	const uint32_t m = (hy >> 31) | ((hx >> 30) & 2u);  // 2 * sign(x) + sign(y)
+	if (iy == 0) {
+		if (m < 2) return y;
+		return m == 2 ? pi + tiny : -pi - tiny;
+	}
+	if (ix == 0) return (int32_t)hy < 0 ? -pi_o_2 - tiny : pi_o_2 + tiny;
+	if (ix == 0x7f800000u) {
+		if (iy == 0x7f800000u) {
+			switch (m) {
+			case 0: return pi_o_4 + tiny;
+			case 1: return -pi_o_4 - tiny;
+			case 2: return 3.0f * pi_o_4 + tiny;
+			default: return -3.0f * pi_o_4 - tiny;
+			}
+		}
+		switch (m) {
+		case 0: return 0.0f;
+		case 1: return -0.0f;
+		case 2: return pi + tiny;
+		default: return -pi - tiny;
+		}
+	}
+	if (iy == 0x7f800000u) return (int32_t)hy < 0 ? -pi_o_2 - tiny : pi_o_2 + tiny;
+	const int32_t k = ((int32_t)iy - (int32_t)ix) >> 23;
+	float z;
+	if (k > 60) z = pi_o_2 - u2f(0x333bbd2eu);  // |y / x| > 2^60: pi_o_2 + 0.5 * pi_lo
+	else if ((int32_t)hx < 0 && k < -60) z = 0.0f;
+	else z = atanf_glibc(u2f(f2u(y / x) & 0x7fffffffu));
+	switch (m) {
+	case 0: return z;
+	case 1: return u2f(f2u(z) ^ 0x80000000u);
+	case 2: return pi - (z + neg_pi_lo);
+	default: return (z + neg_pi_lo) - pi;
+	}
 }
 
 // ---- k_tanf.c (fdlibm, float): tan(x + y) for |x| <~ pi/4, iy = 1: tan, -1: -1 / tan

@@ -67,6 +67,7 @@ TUTU_LIBM_CALL float pow5f(float x) { return tutu_libm::powf_glibc(x, 5.f); }
 TUTU_LIBM_CALL tutu_libm::SinCos lm_sincosf(float x) { return tutu_libm::sincos_pair_glibc(x); }  // every caller wants both of 2 pi xi
 TUTU_LIBM_CALL float lm_acosf(float x) { return tutu_libm::acosf_glibc(x); }
 TUTU_LIBM_CALL float lm_tanf(float x) { return tutu_libm::tanf_glibc(x); }
+TUTU_LIBM_CALL float lm_atan2f(float y, float x) { return tutu_libm::atan2f_glibc(y, x); }
 
 // ------------------------------------------------------------------------------------------------ RNG
 // Philox4x32-10, counter (pix, smp, k>>2, 0), key (key0, key1); draw k = word k&3; xi = (u32>>8) * 2^-24.

@@ -96,8 +96,16 @@ struct PassParams {
 	const uint32_t* n_in;    // its length
 	const float4* hitC;      // per list position: t, b1, b2 | triangle (leaf order, -1 miss)
 	const uint8_t* hitK;     // per list position: material class of the hit
-	float4* F;               // per home slot: the finished sample's radiance
+	float4* F;               // per home slot: the finished sample's radiance | (knob "exact_sum") the levels its path logged
 	int n_mats;
+	// Knob "exact_sum": the radiance is NOT carried forward as sum of beta * term.  The reference's traceRay is a recursion that adds
+	// from the tail -- L_v = S_v + L_{v+1} * coe_v (PathTracing.hpp:275-277), L_v = L_{v+1} * cos * f_r / pdf (:133) -- so every
+	// vertex v a path continues from logs what its level needs (2 x 16 B at xlog[(2 v + k) * xstride + home]: S_v xyz | pdf or 0,
+	// coe_v or f_r xyz | cos), beta stays 1, the value a path ends with is its deepest level's, and k_unwind folds the levels in the
+	// reference's order.  Null: the forward sum (the same real number, rounded in another order: 10-34 % of the samples differ in
+	// a last bit).
+	float4* xlog;
+	uint32_t xstride;
 };
 
 // Small read-only tables of the shade stage.  TAB selects where they live:
@@ -183,12 +191,11 @@ TUTU_DEV LightSample sample_light(const ShadeTabs& tb, int size, Rng& rng) {
 		// the two angles are drawn uniformly, not the area [sic]
 		const float theta = rng.next() * 2 * TUTU_PI;
 		const float phi = rng.next() * TUTU_PI;
-		// The point feeds a shadow ray that grazes the sphere it was sampled on: the sphere's own quadratic decides
-		// "blocked" within a few 1e-4 of the ray length, so a last-bit difference in sinf/cosf flips whole terms.
-		// Double-precision sin/cos rounded once reproduce the host's (correctly rounded in all but ~1e-3 of the
-		// cases) float results; this runs once per sample that picks a sphere light, not in the common path.
-		const float ct = (float)cos((double)theta), st = (float)sin((double)theta);
-		const float cp = (float)cos((double)phi), sp_ = (float)sin((double)phi);
+		// The point feeds a shadow ray that grazes the sphere it was sampled on: the sphere's own quadratic decides "blocked"
+		// within a few 1e-4 of the ray length, so a last-bit difference in sinf / cosf flips whole terms -- the C library's
+		// (device_libm.h; until round 5: double-precision sin / cos rounded once, right in all but 1e-3 of the cases).
+		const tutu_libm::SinCos t2 = lm_sincosf(theta), p2 = lm_sincosf(phi);
+		const float ct = t2.c, st = t2.s, cp = p2.c, sp_ = p2.s;
 		LightSample s;
 		s.pos.x = v0.x + v1.x * ct * sp_;
 		s.pos.y = v0.y + v1.x * st * sp_;
@@ -243,7 +250,7 @@ TUTU_DEV void texture_modify(const SceneDev& sc, int tri, float b1, float b2, bo
 	if (is_sphere) {
 		const float phi = lm_acosf(Ng.z);
 		tv = phi / TUTU_PI;
-		float theta = atan2f(Ng.y, Ng.x);
+		float theta = lm_atan2f(Ng.y, Ng.x);
 		if (theta < 0) theta += 2 * TUTU_PI;
 		tu = (theta / (2.f * TUTU_PI));
 	} else {
@@ -469,6 +476,7 @@ __global__ void __launch_bounds__(256) k_shade(PassParams pp) {
 			V3 Lsum = mk1(0.f);   // radiance gathered so far
 			V3 Ladd = mk1(0.f);   // radiance this stage adds to the path
 			bool added = false;
+			bool logged_prev = FIRST;  // knob "exact_sum": level depth-1 of this path is in the log
 			float t, b1, b2, pm = 0.f, cosprev = 0.f;
 			int tri;
 			uint32_t pix, smp, draw = 0, flags = 0, home;
@@ -511,6 +519,7 @@ __global__ void __launch_bounds__(256) k_shade(PassParams pp) {
 				} else if (verdict == TUTU_V_KILLED) {
 					flags |= TUTU_FLAG_KILL;
 				}
+				logged_prev = (flags & TUTU_FLAG_PREV_REFRACTIVE) != 0;  // (a refractive vertex logs its level when it is shaded)
 			}
 
 			Rng rng;
@@ -592,7 +601,15 @@ __global__ void __launch_bounds__(256) k_shade(PassParams pp) {
 							go = false;
 						} else {
 							tp = tp * coe;
-							beta = beta * coe;
+							if (pp.xlog) {  // level depth-1 is complete: S = what the vertex gathered (its light sample), coe; a new level starts
+								float4* lg = pp.xlog + (size_t)(2 * (depth - 1)) * pp.xstride + home;
+								lg[0] = make_float4(Lsum.x, Lsum.y, Lsum.z, 0.f);
+								lg[pp.xstride] = make_float4(coe.x, coe.y, coe.z, 0.f);
+								Lsum = mk1(0.f);
+								logged_prev = true;
+							} else {
+								beta = beta * coe;
+							}
 						}
 					}
 				}
@@ -652,7 +669,13 @@ __global__ void __launch_bounds__(256) k_shade(PassParams pp) {
 					}
 					// :128-133 -- the reference traces the continuation and then drops it when pdf < MIN_DIVISOR
 					if (!(p < TUTU_MIN_DIVISOR || depth + 1 > TUTU_MAX_DEPTH)) {
-						beta = ((beta * cosv) * f_r) / p;
+						if (pp.xlog) {
+							float4* lg = pp.xlog + (size_t)(2 * depth) * pp.xstride + home;
+							lg[0] = make_float4(0.f, 0.f, 0.f, p);
+							lg[pp.xstride] = make_float4(f_r.x, f_r.y, f_r.z, cosv);
+						} else {
+							beta = ((beta * cosv) * f_r) / p;
+						}
 						stg[SF_A * 64 + lane] = make_float4(rayOrig.x, rayOrig.y, rayOrig.z, __uint_as_float(pix));
 						stg[SF_B * 64 + lane] = make_float4(wi.x, wi.y, wi.z, __uint_as_float((smp << 8) | (TUTU_FLAG_PREV_REFRACTIVE << 6) | (rng.draw & 0x3Fu)));
 						stg[SF_D * 64 + lane] = make_float4(beta.x, beta.y, beta.z, 0.f);
@@ -746,7 +769,9 @@ __global__ void __launch_bounds__(256) k_shade(PassParams pp) {
 			// radiance: a path has at most one term per stage besides its shadow request (background, UNLIT, emission
 			// or MIS-weighted emission).  A path that ends here without a pending shadow request is finished.
 			if (added) Lsum = mk(Lsum.x + Ladd.x, Lsum.y + Ladd.y, Lsum.z + Ladd.z);
-			if (key == 0) pp.F[home] = make_float4(Lsum.x, Lsum.y, Lsum.z, 0.f);
+			// (exact_sum: the path ends with the value of level `depth`, or -- when it ended in the connect step of an ordinary vertex,
+			// whose level is then not logged -- with that of level depth-1; .w = the levels below it)
+			if (key == 0) pp.F[home] = make_float4(Lsum.x, Lsum.y, Lsum.z, __int_as_float(logged_prev ? depth : depth - 1));
 			else stg[SF_L * 64 + lane] = make_float4(Lsum.x, Lsum.y, Lsum.z, __uint_as_float(home));
 		}
 
@@ -848,6 +873,7 @@ struct TraceParams {
 	uint32_t* defer;     // >= *n_ptr entries: list positions of the rays that are not plain, per wave range (below)
 	int leaf_steps;      // trace_persistent8: leaf steps per round at most
 	int flat_share;      // k_trace_flat, closest hit: deal the wave's (ray, leaf) pairs to its lanes (knob "flat_share")
+	float fin_w;         // any-hit: .w of the F entries written for TUTU_KEY_FINAL requests = the stage's depth as int bits (PassParams::xlog)
 };
 
 // The exact walk of ONE list position: the reference's own tree, the reference's own slab, no validation, no pruning
@@ -871,7 +897,7 @@ TUTU_DEV void exact_walk_entry(const S& ss, const TraceParams& tp, uint32_t i, i
 		const bool blk = trace_any(ss, sc, mk(e0.x, e0.y, e0.z), mk(e1.x, e1.y, e1.z), xstack, stride, true);
 		if (f & TUTU_KEY_FINAL) {
 			const float4 Lp = tp.rec.L[s], e2 = tp.rec.P[s];
-			float4 F = make_float4(Lp.x, Lp.y, Lp.z, 0.f);
+			float4 F = make_float4(Lp.x, Lp.y, Lp.z, tp.fin_w);
 			if (!blk) {
 				F.x = F.x + e2.x; F.y = F.y + e2.y; F.z = F.z + e2.z;
 			}
@@ -1228,7 +1254,7 @@ TUTU_DEV void trace_persistent(const S& ss, const TraceParams& tp, int* stack, c
 				st_stream(&tp.hitC[slot], make_float4(best_t, best_u, best_v, __int_as_float(best_tri)));
 				tp.hitK[slot] = best_tri >= 0 ? tri_class[best_tri] : (uint8_t)TUTU_CLASS_MISS;
 			} else if (fl & TUTU_KEY_FINAL) {  // the path ended with this request: its sample is finished
-				float4 F = make_float4(Lpre.x, Lpre.y, Lpre.z, 0.f);
+				float4 F = make_float4(Lpre.x, Lpre.y, Lpre.z, tp.fin_w);
 				if (!blocked) {
 					F.x = F.x + contrib.x; F.y = F.y + contrib.y; F.z = F.z + contrib.z;
 				}
@@ -1554,7 +1580,7 @@ TUTU_DEV void trace_persistent8(const SceneGlobal& ss, const TraceParams& tp, in
 				}
 			} else if (fl & 0x80000000u) {
 			} else if (fl & TUTU_KEY_FINAL) {
-				float4 F = make_float4(Lpre.x, Lpre.y, Lpre.z, 0.f);
+				float4 F = make_float4(Lpre.x, Lpre.y, Lpre.z, tp.fin_w);
 				if (!blocked) {
 					F.x = F.x + contrib.x; F.y = F.y + contrib.y; F.z = F.z + contrib.z;
 				}
@@ -1830,7 +1856,7 @@ __global__ void __launch_bounds__(256, ANY ? 8 : 5) k_trace_flat(TraceParams tp,
 				st_stream(&tp.hitC[slot], make_float4(best_t, best_u, best_v, __int_as_float(best_tri)));
 				tp.hitK[slot] = best_tri >= 0 ? cls[best_tri] : (uint8_t)TUTU_CLASS_MISS;
 			} else if (fl & TUTU_KEY_FINAL) {  // the path ended with this request: its sample is finished
-				float4 F = make_float4(Lpre.x, Lpre.y, Lpre.z, 0.f);
+				float4 F = make_float4(Lpre.x, Lpre.y, Lpre.z, tp.fin_w);
 				if (!blocked) {
 					F.x = F.x + contrib.x; F.y = F.y + contrib.y; F.z = F.z + contrib.z;
 				}
@@ -1997,6 +2023,20 @@ __global__ void __launch_bounds__(256) k_resolve(const float4* Lout, float4* acc
 		}
 	}
 	accum[p] = a;
+}
+
+// Knob "exact_sum" (PassParams::xlog): fold the levels a path logged, deepest first, exactly as the reference's recursion returns.
+__global__ void __launch_bounds__(256) k_unwind(float4* F, const float4* xlog, uint32_t xstride, uint32_t n) {
+	const uint32_t h = blockIdx.x * blockDim.x + threadIdx.x;
+	if (h >= n) return;
+	const float4 f = F[h];
+	V3 L = mk(f.x, f.y, f.z);
+	for (int v = __float_as_int(f.w) - 1; v >= 0; v--) {
+		const float4 a = xlog[(size_t)(2 * v) * xstride + h], b = xlog[(size_t)(2 * v + 1) * xstride + h];
+		if (a.w != 0.f) L = ((L * b.w) * mk(b.x, b.y, b.z)) / a.w;          // calcForRefractive: Li * cos * f_r / pdf (:133)
+		else L = mk(a.x, a.y, a.z) + (L * mk(b.x, b.y, b.z));                // sampleValue + (Li * coe) (:277)
+	}
+	F[h] = make_float4(L.x, L.y, L.z, 0.f);
 }
 
 // color = estimate * SPP_inv (PathTracing.hpp:513)

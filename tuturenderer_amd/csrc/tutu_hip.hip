@@ -153,6 +153,8 @@ struct TutuCtx {
 		int flat = 1;             // TUTU_FLAT           tiny LDS-resident scenes (<= TUTU_FLAT_MAX leaves): the flat scan instead of the tree walk  {0, 1}
 		int gather_rccl = 1;      // TUTU_GATHER_RCCL    tutu_hip_render_multi(_device): the pieces travel by ONE grouped RCCL send / recv: 0 never (peer copies), 1 when the contexts sit on several devices, 2 always (contexts that share the root's device: a self send / recv)  [0, 2]
 		int exact = 0;            // TUTU_EXACT          every ray takes the exact walk: reference tree, reference slab, no pruning  {0, 1}
+		int exact_sum = 0;        // TUTU_EXACT_SUM      PathTracing: a path's radiance is folded from its deepest vertex back, as the reference's recursion returns it
+		                          //                     (device_shade.h: PassParams::xlog; 224 B more per path slot, allocated on first use)  {0, 1}
 		int paths_mi = 168;       // TUTU_PATHS_MI       Mi path slots in flight (all work sets together, ~400 B each) when the caller names none  [4, 4096]
 		int cold_paths_mi = 12;   // TUTU_COLD_PATHS_MI  Mi path slots (all work sets together) a context's FIRST default-sized render allocates itself;
 		                          //                     the rest of the default paths_mi arrives from a background thread (0 = allocate everything at once)  [0, 4096]
@@ -170,6 +172,7 @@ struct TutuCtx {
 		DevBuf<float4> hitC;       // per list position: the hit of the extension ray
 		DevBuf<uint8_t> hitK;      // per list position: its material class
 		DevBuf<float4> F;          // per home slot: finished radiance
+		DevBuf<float4> xlog;       // knob "exact_sum": [2 * (TUTU_MAX_DEPTH + 1)][cap] the levels of every path (PassParams::xlog)
 		DevBuf<uint32_t> lists;    // [2][cap]: continuing records, records with a shadow request
 		DevBuf<uint32_t> tile_counts, tile_offsets;
 		DevBuf<int> gstack;        // traversal kernels, deep trees: the HBM tier of the per-lane stacks [entry][lane of the grid]
@@ -270,6 +273,7 @@ const KnobDesc kKnobs[] = {
     {"util_stats", "TUTU_UTIL_STATS", &TutuCtx::Knobs::util_stats, 0, 1},
     {"bidir_units", "TUTU_BIDIR_UNITS", &TutuCtx::Knobs::bidir_units, 64, 1 << 24},
     {"exact", "TUTU_EXACT", &TutuCtx::Knobs::exact, 0, 1},
+    {"exact_sum", "TUTU_EXACT_SUM", &TutuCtx::Knobs::exact_sum, 0, 1},
     {"gather_rccl", "TUTU_GATHER_RCCL", &TutuCtx::Knobs::gather_rccl, 0, 2},
     {"flat", "TUTU_FLAT", &TutuCtx::Knobs::flat, 0, 1, true},
     {"flat_share", "TUTU_FLAT_SHARE", &TutuCtx::Knobs::flat_share, 0, 1},
@@ -380,7 +384,7 @@ void release_set(WorkSet& w) {
 		w.key[k2].release();
 		w.verdict[k2].release();
 	}
-	w.hitC.release(); w.hitK.release(); w.F.release(); w.lists.release(); w.tile_counts.release(); w.tile_offsets.release();
+	w.hitC.release(); w.hitK.release(); w.F.release(); w.xlog.release(); w.lists.release(); w.tile_counts.release(); w.tile_offsets.release();
 	w.list_meta.release(); w.part.release(); w.defer.release(); w.gstack.release();
 	if (w.ev_resolved) (void)hipEventDestroy(w.ev_resolved);
 	w.ev_resolved = nullptr;
@@ -668,6 +672,12 @@ int run_pass(TutuCtx* c, WorkSet& w, hipStream_t s, const TutuCameraFrame* cam, 
 	pp.F = w.F.p;
 	pp.list = w.lists.p;
 	pp.n_mats = (int)c->hs.mats.size();
+	if (c->knobs.exact_sum) {
+		int rcx = w.xlog.ensure((size_t)(2 * (TUTU_MAX_DEPTH + 1)) * w.cap);
+		if (rcx != TUTU_OK) return rcx;
+		pp.xlog = w.xlog.p;
+		pp.xstride = (uint32_t)w.cap;
+	}
 
 	const size_t npaths = (size_t)npix * (size_t)nsamp;
 	// persistent blocks: the table staging is paid once per block.  How many per CU: the one-class shade kernel is bound by
@@ -701,6 +711,7 @@ int run_pass(TutuCtx* c, WorkSet& w, hipStream_t s, const TutuCameraFrame* cam, 
 		rc = build_lists(c, w, s, pp.out.key, n_pad, prev_count, (uint32_t)region0, meta, &c->totals.p->closest_rays, &c->totals.p->shadow_rays);
 		if (rc != TUTU_OK) return rc;
 		TraceParams tp;
+		tp.fin_w = 0.f;
 		tp.sc = c->sc;
 		tp.rec = pp.out;
 		tp.list = w.lists.p;
@@ -718,6 +729,7 @@ int run_pass(TutuCtx* c, WorkSet& w, hipStream_t s, const TutuCameraFrame* cam, 
 		tp.xcd_map = c->knobs.trace_xcd;
 		tp.part = w.part.p;
 		tp.defer = w.defer.p;
+		tp.fin_w = __builtin_bit_cast(float, (int32_t)d);
 		TIMED(EV_TRACE_CLOSEST, launch_trace<false>(c, s, trace_grid, tp));
 		(*n_trace_launches)++;
 		tp.list = w.lists.p + w.cap;
@@ -725,6 +737,10 @@ int run_pass(TutuCtx* c, WorkSet& w, hipStream_t s, const TutuCameraFrame* cam, 
 		tp.part = w.part.p + 4 * TUTU_PART_BLOCKS;
 		tp.inner_steps = c->sc.has_wide ? c->knobs.wide_inner_steps_any : c->knobs.inner_steps_any;
 		TIMED(EV_TRACE_ANY, launch_trace<true>(c, s, trace_grid, tp));
+	}
+	if (pp.xlog) {
+		const uint32_t nh = (uint32_t)npaths;
+		TIMED(EV_OTHER, k_unwind<<<dim3((nh + 255) / 256), dim3(256), 0, s>>>(w.F.p, pp.xlog, pp.xstride, nh));
 	}
 	return TUTU_OK;
 }
@@ -1900,6 +1916,7 @@ int lt_wavefront_batch(TutuCtx* c, hipStream_t s, BidirParams p) {
 	HIP_TRY(hipGetLastError());
 	if ((rc = build_lists(c, w, s, p.rec.key, n_pad, nullptr, n_pad, meta0, nullptr, nullptr)) != TUTU_OK) return rc;
 	TraceParams tp;
+	tp.fin_w = 0.f;
 	tp.sc = c->sc;
 	tp.rec = p.rec;
 	tp.list = w.lists.p;
@@ -1959,6 +1976,7 @@ int bdpt_staged_batch(TutuCtx* c, hipStream_t s, BidirParams p) {
 	const dim3 blk(256), g_units((p.n_units + 255) / 256);
 	uint32_t* meta = w.list_meta.p;
 	TraceParams tp;
+	tp.fin_w = 0.f;
 	tp.sc = c->sc;
 	tp.rec = p.rec;
 	tp.hitC = w.hitC.p;
@@ -2362,11 +2380,12 @@ __global__ void k_test_fn(FnArgs a) {
 		o[0] = rng.w0; o[1] = rng.w1; o[2] = rng.w2; o[3] = rng.w3;
 		break;
 	}
-	case TUTU_FN_LIBM: {  // the C library's functions as the path calls them (device_math.h's wrappers of device_libm.h): x, y -> sinf cosf acosf tanf powf(x, y) powf(x, 5)
+	case TUTU_FN_LIBM: {  // the C library's functions as the path calls them (device_math.h's wrappers of device_libm.h): x, y -> sinf cosf acosf tanf powf(x, y) powf(x, 5) atan2f(x, y) atanf
 		const float x = a.in[0][i], y = a.in[1][i];
 		const tutu_libm::SinCos sc = lm_sincosf(x);
-		float* o = a.out + 6 * (size_t)i;
+		float* o = a.out + 8 * (size_t)i;
 		o[0] = sc.s; o[1] = sc.c; o[2] = lm_acosf(x); o[3] = lm_tanf(x); o[4] = tutu_libm::powf_glibc(x, y); o[5] = pow5f(x);
+		o[6] = lm_atan2f(x, y); o[7] = tutu_libm::atanf_glibc(x);
 		break;
 	}
 	default: break;
@@ -2417,6 +2436,7 @@ static int run_trace_kernel(TutuCtx* c, uint32_t n, bool any) {
 	HIP_TRY(hipMemcpyAsync(list, iota.data(), sizeof(uint32_t) * n, hipMemcpyHostToDevice, s));
 	HIP_TRY(hipMemcpyAsync(w.list_meta.p + (any ? 1 : 0), &n, sizeof(uint32_t), hipMemcpyHostToDevice, s));
 	TraceParams tp;
+	tp.fin_w = 0.f;
 	tp.sc = c->sc;
 	tp.rec = records_of(w, 0);
 	tp.list = list;
@@ -2622,7 +2642,7 @@ static const struct { int n_in; int w[6]; int w_out; } kFnShape[TUTU_FN_COUNT] =
     /* LOCAL2WORLD */ {2, {3, 3, 0, 0, 0, 0}, 3},
     /* RNG */ {1, {5, 0, 0, 0, 0, 0}, 8},
     /* PHILOX */ {1, {5, 0, 0, 0, 0, 0}, 4},
-    /* LIBM */ {2, {1, 1, 0, 0, 0, 0}, 6},
+    /* LIBM */ {2, {1, 1, 0, 0, 0, 0}, 8},
 };
 
 int tutu_hip_eval_fn(TutuCtx* c, int32_t fn, uint32_t n, const float* const* in, float* out) {
