@@ -25,6 +25,12 @@ FORMS = {
     "wide8_slots_in_tree_order": {"TUTU_WIDE": "2", "TUTU_WIDE8": "2", "TUTU_WIDE8_SLOTS": "0"},  # a poor visiting order must not change a hit
     "wide8_octant_slots": {"TUTU_WIDE": "2", "TUTU_WIDE8": "2", "TUTU_WIDE8_SLOTS": "1"},
     "wide8_long_rounds": {"TUTU_WIDE": "2", "TUTU_WIDE8": "2", "TUTU_WIDE8_INNER_STEPS": "9", "TUTU_WIDE8_INNER_STEPS_ANY": "7", "TUTU_WIDE8_LEAF_STEPS": "1"},
+    # round 5: which list positions a persistent wave takes (knob trace_deal: contiguous range / chunks of 64 / of 256 dealt round-robin;
+    # the rays set aside for the exact walk are filed under the same map)
+    "binary_contiguous_ranges": {"TUTU_WIDE": "0", "TUTU_TRACE_DEAL": "0"},
+    "wide_chunks_of_256": {"TUTU_WIDE": "2", "TUTU_WIDE8": "0", "TUTU_TRACE_DEAL": "8"},
+    "wide8_contiguous_ranges": {"TUTU_WIDE": "2", "TUTU_WIDE8": "2", "TUTU_TRACE_DEAL": "0"},
+    "wide8_chunks_of_64_overlapped_too": {"TUTU_WIDE": "2", "TUTU_WIDE8": "2", "TUTU_TRACE_DEAL": "6"},
 }
 KNOB_ENVS = sorted({k for env in FORMS.values() for k in env})
 

@@ -63,10 +63,27 @@ TUTU_DEV float pow2f(float x) { return x * x; }
 // kernels their double-precision temporaries cost 27 registers (one-class kernel 126 -> 153: three waves per SIMD instead of
 // four; the generic kernel 165 -> 178: two instead of three -- its time +42 %).
 #define TUTU_LIBM_CALL __device__ __attribute__((noinline))
+// (TUTU_LIBM_COST_*: measuring builds only -- one function at a time replaced by the device library's, to see what each costs)
+#ifdef TUTU_LIBM_COST_POW
+TUTU_DEV float pow5f(float x) { return (x * x) * (x * x) * x; }
+#else
 TUTU_LIBM_CALL float pow5f(float x) { return tutu_libm::powf_glibc(x, 5.f); }
+#endif
+#ifdef TUTU_LIBM_COST_SINCOS
+TUTU_DEV tutu_libm::SinCos lm_sincosf(float x) { tutu_libm::SinCos r; r.s = sinf(x); r.c = cosf(x); return r; }
+#else
 TUTU_LIBM_CALL tutu_libm::SinCos lm_sincosf(float x) { return tutu_libm::sincos_pair_glibc(x); }  // every caller wants both of 2 pi xi
+#endif
+#ifdef TUTU_LIBM_COST_ACOS
+TUTU_DEV float lm_acosf(float x) { return acosf(x); }
+#else
 TUTU_LIBM_CALL float lm_acosf(float x) { return tutu_libm::acosf_glibc(x); }
+#endif
+#ifdef TUTU_LIBM_COST_TAN
+TUTU_DEV float lm_tanf(float x) { return tanf(x); }
+#else
 TUTU_LIBM_CALL float lm_tanf(float x) { return tutu_libm::tanf_glibc(x); }
+#endif
 TUTU_LIBM_CALL float lm_atan2f(float y, float x) { return tutu_libm::atan2f_glibc(y, x); }
 
 // ------------------------------------------------------------------------------------------------ RNG

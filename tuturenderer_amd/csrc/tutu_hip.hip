@@ -153,6 +153,10 @@ struct TutuCtx {
 		int flat = 1;             // TUTU_FLAT           tiny LDS-resident scenes (<= TUTU_FLAT_MAX leaves): the flat scan instead of the tree walk  {0, 1}
 		int gather_rccl = 1;      // TUTU_GATHER_RCCL    tutu_hip_render_multi(_device): the pieces travel by ONE grouped RCCL send / recv: 0 never (peer copies), 1 when the contexts sit on several devices, 2 always (contexts that share the root's device: a self send / recv)  [0, 2]
 		int exact = 0;            // TUTU_EXACT          every ray takes the exact walk: reference tree, reference slab, no pruning  {0, 1}
+		int trace_deal = -1;      // TUTU_TRACE_DEAL     persistent walks: log2 of the chunk of list positions dealt round-robin to the waves; 0: one contiguous range per
+		                          //                     wave; -1 = auto: 6 for a pass that runs by itself (its slowest waves are what the kernel waits for: closest-hit
+		                          //                     -5 ... -21 %, any-hit -5 ... -17 %), 0 when passes overlap (another pass's kernels fill the tail, and a wave
+		                          //                     that stays in one part of the picture keeps its nodes in L1: frames +1.7 / -0.5 / -1.7 %)  {-1, 0, 6..16}
 		int exact_sum = 0;        // TUTU_EXACT_SUM      PathTracing: a path's radiance is folded from its deepest vertex back, as the reference's recursion returns it
 		                          //                     (device_shade.h: PassParams::xlog; 224 B more per path slot, allocated on first use)  {0, 1}
 		int paths_mi = 168;       // TUTU_PATHS_MI       Mi path slots in flight (all work sets together, ~400 B each) when the caller names none  [4, 4096]
@@ -209,6 +213,7 @@ struct TutuCtx {
 	WorkSet retired[TUTU_MAX_SETS];       // the small cold-start sets after the switch: kept until destroy (a hipFree waits for the device)
 	hipStream_t extra_streams[TUTU_MAX_SETS - 1] = {};  // work set k > 0 runs on extra_streams[k - 1]
 	hipEvent_t ev_fork = nullptr, ev_user = nullptr;
+	int last_trace_us = 0;  // run_trace_kernel: the kernel's duration (read-only option "last_trace_us"; measuring tools)
 	DevBuf<float4> prim_dir, prim_hit, accum;
 	DevBuf<Totals> totals;
 	DevBuf<int32_t> pixels;
@@ -274,6 +279,7 @@ const KnobDesc kKnobs[] = {
     {"bidir_units", "TUTU_BIDIR_UNITS", &TutuCtx::Knobs::bidir_units, 64, 1 << 24},
     {"exact", "TUTU_EXACT", &TutuCtx::Knobs::exact, 0, 1},
     {"exact_sum", "TUTU_EXACT_SUM", &TutuCtx::Knobs::exact_sum, 0, 1},
+    {"trace_deal", "TUTU_TRACE_DEAL", &TutuCtx::Knobs::trace_deal, -1, 16},
     {"gather_rccl", "TUTU_GATHER_RCCL", &TutuCtx::Knobs::gather_rccl, 0, 2},
     {"flat", "TUTU_FLAT", &TutuCtx::Knobs::flat, 0, 1, true},
     {"flat_share", "TUTU_FLAT_SHARE", &TutuCtx::Knobs::flat_share, 0, 1},
@@ -712,6 +718,7 @@ int run_pass(TutuCtx* c, WorkSet& w, hipStream_t s, const TutuCameraFrame* cam, 
 		if (rc != TUTU_OK) return rc;
 		TraceParams tp;
 		tp.fin_w = 0.f;
+		tp.deal_log2 = c->knobs.trace_deal >= 6 ? c->knobs.trace_deal : (c->knobs.trace_deal < 0 && !overlapped ? 6 : 0);
 		tp.sc = c->sc;
 		tp.rec = pp.out;
 		tp.list = w.lists.p;
@@ -1503,6 +1510,10 @@ int tutu_hip_get_option(TutuCtx* c, const char* name, int* value) {
 		*value = c->peer_access;
 		return TUTU_OK;
 	}
+	if (strcmp(name, "last_trace_us") == 0) {
+		*value = c->last_trace_us;
+		return TUTU_OK;
+	}
 	if (strcmp(name, "rccl_available") == 0) {
 		*value = rccl_available();
 		return TUTU_OK;
@@ -1917,6 +1928,7 @@ int lt_wavefront_batch(TutuCtx* c, hipStream_t s, BidirParams p) {
 	if ((rc = build_lists(c, w, s, p.rec.key, n_pad, nullptr, n_pad, meta0, nullptr, nullptr)) != TUTU_OK) return rc;
 	TraceParams tp;
 	tp.fin_w = 0.f;
+	tp.deal_log2 = c->knobs.trace_deal >= 6 ? c->knobs.trace_deal : (c->knobs.trace_deal < 0 ? 6 : 0);
 	tp.sc = c->sc;
 	tp.rec = p.rec;
 	tp.list = w.lists.p;
@@ -1977,6 +1989,7 @@ int bdpt_staged_batch(TutuCtx* c, hipStream_t s, BidirParams p) {
 	uint32_t* meta = w.list_meta.p;
 	TraceParams tp;
 	tp.fin_w = 0.f;
+	tp.deal_log2 = c->knobs.trace_deal >= 6 ? c->knobs.trace_deal : (c->knobs.trace_deal < 0 ? 6 : 0);
 	tp.sc = c->sc;
 	tp.rec = p.rec;
 	tp.hitC = w.hitC.p;
@@ -2437,6 +2450,7 @@ static int run_trace_kernel(TutuCtx* c, uint32_t n, bool any) {
 	HIP_TRY(hipMemcpyAsync(w.list_meta.p + (any ? 1 : 0), &n, sizeof(uint32_t), hipMemcpyHostToDevice, s));
 	TraceParams tp;
 	tp.fin_w = 0.f;
+	tp.deal_log2 = c->knobs.trace_deal >= 6 ? c->knobs.trace_deal : (c->knobs.trace_deal < 0 ? 6 : 0);
 	tp.sc = c->sc;
 	tp.rec = records_of(w, 0);
 	tp.list = list;
@@ -2455,10 +2469,19 @@ static int run_trace_kernel(TutuCtx* c, uint32_t n, bool any) {
 	tp.leaf_again = c->knobs.leaf_again;
 	tp.xcd_map = 0;
 	const int grid = persistent_grid(n, c->n_cu, c->trace_blocks_per_cu);
+	hipEvent_t e0 = nullptr, e1 = nullptr;
+	HIP_TRY(hipEventCreate(&e0));
+	HIP_TRY(hipEventCreate(&e1));
+	HIP_TRY(hipEventRecord(e0, s));
 	if (any) launch_trace<true>(c, s, grid, tp);
 	else launch_trace<false>(c, s, grid, tp);
 	HIP_TRY(hipGetLastError());
+	HIP_TRY(hipEventRecord(e1, s));
 	HIP_TRY(hipStreamSynchronize(s));
+	float ms = 0.f;
+	if (hipEventElapsedTime(&ms, e0, e1) == hipSuccess) c->last_trace_us = (int)(ms * 1000.f);
+	(void)hipEventDestroy(e0);
+	(void)hipEventDestroy(e1);
 	return TUTU_OK;
 }
 
