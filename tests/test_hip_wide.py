@@ -25,6 +25,8 @@ FORMS = {
     "wide8_slots_in_tree_order": {"TUTU_WIDE": "2", "TUTU_WIDE8": "2", "TUTU_WIDE8_SLOTS": "0"},  # a poor visiting order must not change a hit
     "wide8_octant_slots": {"TUTU_WIDE": "2", "TUTU_WIDE8": "2", "TUTU_WIDE8_SLOTS": "1"},
     "wide8_long_rounds": {"TUTU_WIDE": "2", "TUTU_WIDE8": "2", "TUTU_WIDE8_INNER_STEPS": "9", "TUTU_WIDE8_INNER_STEPS_ANY": "7", "TUTU_WIDE8_LEAF_STEPS": "1"},
+    "wide8_no_nodes_in_lds": {"TUTU_WIDE": "2", "TUTU_WIDE8": "2", "TUTU_WIDE8_TOP": "0"},     # (default: the top 40 node ids staged in LDS)
+    "wide8_three_levels_in_lds": {"TUTU_WIDE": "2", "TUTU_WIDE8": "2", "TUTU_WIDE8_TOP": "80"},
     # round 5: which list positions a persistent wave takes (knob trace_deal: contiguous range / chunks of 64 / of 256 dealt round-robin;
     # the rays set aside for the exact walk are filed under the same map)
     "binary_contiguous_ranges": {"TUTU_WIDE": "0", "TUTU_TRACE_DEAL": "0"},
@@ -66,7 +68,7 @@ def test_golden_rays_bit_exact_in_every_form(tr, port, monkeypatch, name, form):
             assert opt["lds_scene"] == 0
             assert opt["wide_tree"] == (1 if form.startswith("wide") else 0)
             assert opt["wide8_tree"] == (1 if form.startswith("wide8") else 0)
-            assert opt["stack_entries_hbm"] > 0 or form == "binary" or form.startswith("wide8")  # (the eight-wide walk has no HBM tier)
+            assert opt["stack_entries_hbm"] > 0 or form in ("binary", "binary_contiguous_ranges") or form.startswith("wide8")  # (the eight-wide walk has no HBM tier)
         hits = ctx.trace_closest(O, D)
         h = hits["tri"] >= 0
         assert bit_equal(h.astype(np.uint8), z["scene.hit"])

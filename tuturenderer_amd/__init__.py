@@ -340,7 +340,7 @@ class Context:
 
     OPTION_NAMES = ("sets", "sets_default", "one_set", "shade_bpc", "trace_bpc", "refill_min", "inner_steps", "inner_steps_any", "leaf_again", "trace_xcd", "kernel_events", "any_near_first",
                     "util_stats", "bidir_units", "sah_tree", "n_refs", "lds_scene", "shade_tab", "fast_depth", "stack_entries", "stack_entries_hbm", "lds_stack_max", "wide", "wide_min_mb", "wide_inner_steps", "wide_inner_steps_any", "wide_tree", "wide_depth", "wide_early", "pair_leaves",
-                    "trace_blocks_per_cu", "trace_lds_bytes", "wide_lds_stack", "wide_early_max_mb", "exact", "exact_sum", "trace_deal", "cold_paths_mi", "work_paths_mi", "device_build", "device_build_min_k", "device_built", "flat", "flat_leaves", "flat_share", "wide_greedy",
+                    "trace_blocks_per_cu", "trace_lds_bytes", "wide_lds_stack", "wide_early_max_mb", "exact", "exact_sum", "trace_deal", "wide8_top", "wide8_top_nodes", "cold_paths_mi", "work_paths_mi", "device_build", "device_build_min_k", "device_built", "flat", "flat_leaves", "flat_share", "wide_greedy",
                     "paths_mi", "gather_rccl", "gather_path", "peer_access", "rccl_available", "last_trace_us",
                     "wide8", "wide8_tree", "wide8_depth", "wide8_nodes", "wide8_entries", "wide8_inner_steps", "wide8_inner_steps_any", "wide8_leaf_steps", "wide8_leaf_again", "wide8_leaf_room")
 

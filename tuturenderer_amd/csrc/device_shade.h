@@ -873,6 +873,7 @@ struct TraceParams {
 	uint32_t* defer;     // >= *n_ptr entries: list positions of the rays that are not plain, per wave range (below)
 	int leaf_steps;      // trace_persistent8: leaf steps per round at most
 	int flat_share;      // k_trace_flat, closest hit: deal the wave's (ray, leaf) pairs to its lanes (knob "flat_share")
+	int top_nodes;       // trace_persistent8: node ids below this were staged in LDS behind the stacks (first 80 B of each: what a node step reads)
 	int deal_log2;       // persistent walks: 0 = every wave takes one contiguous range of the list, else chunks of 2^deal_log2 positions dealt round-robin
 	float fin_w;         // any-hit: .w of the F entries written for TUTU_KEY_FINAL requests = the stage's depth as int bits (PassParams::xlog)
 };
@@ -1370,6 +1371,9 @@ TUTU_DEV void trace_persistent8(const SceneGlobal& ss, const TraceParams& tp, in
 	const float inf = __builtin_inff();
 	typedef __attribute__((address_space(3))) int lds_int;
 	lds_int* const lstack = (lds_int*)stack;
+	typedef __attribute__((address_space(3))) tutu_v4f lds_v4;
+	typedef __attribute__((address_space(1))) tutu_v4f hbm_v4;
+	const lds_v4* const ltop = (const lds_v4*)(stack - threadIdx.x + tp.stack_entries * 256);  // k_trace_wide8 staged tp.top_nodes nodes there
 	const int K = tp.stack_entries;
 	const int* const wleaf = reinterpret_cast<const int*>(sc.wnodes8);  // node id * 32 + 20 + slot: the leaf reference of a slot
 
@@ -1466,8 +1470,21 @@ TUTU_DEV void trace_persistent8(const SceneGlobal& ss, const TraceParams& tp, in
 				n_nodes++;
 				const int node = cur;
 				const int top = lstack[(sp - 1) * 256];  // the top group of the node stack, requested with the node
-				const float4* np = sc.wnodes8 + 8 * (size_t)node;
-				const float4 q0 = np[0], q1 = np[1], q2 = np[2], q3 = np[3], q4 = np[4];
+				float4 q0, q1, q2, q3, q4;
+				{
+					// (two address spaces, two branches: a per-lane select of the pointer is compiled into flat loads that wait for both counters)
+					const bool staged = node < tp.top_nodes;
+					tutu_v4f w0, w1, w2, w3, w4;
+					if (staged) {
+						const lds_v4* tq = ltop + 5 * node;
+						w0 = tq[0]; w1 = tq[1]; w2 = tq[2]; w3 = tq[3]; w4 = tq[4];
+					} else {
+						const hbm_v4* np = (const hbm_v4*)(sc.wnodes8 + 8 * (size_t)node);
+						w0 = np[0]; w1 = np[1]; w2 = np[2]; w3 = np[3]; w4 = np[4];
+					}
+					q0 = make_float4(w0.x, w0.y, w0.z, w0.w); q1 = make_float4(w1.x, w1.y, w1.z, w1.w); q2 = make_float4(w2.x, w2.y, w2.z, w2.w);
+					q3 = make_float4(w3.x, w3.y, w3.z, w3.w); q4 = make_float4(w4.x, w4.y, w4.z, w4.w);
+				}
 				const float sx = r.inv.x * q0.w, sy = r.inv.y * q1.x, sz = r.inv.z * q1.y;  // 2^e / d (exact: powers of two)
 				const float ox = (q0.x - r.o.x) * r.inv.x, oy = (q0.y - r.o.y) * r.inv.y, oz = (q0.z - r.o.z) * r.inv.z;
 				const uint32_t mx = (uint32_t)(__float_as_int(r.inv.x) >> 31), my = (uint32_t)(__float_as_int(r.inv.y) >> 31), mz = (uint32_t)(__float_as_int(r.inv.z) >> 31);
@@ -1969,6 +1986,15 @@ __global__ void __launch_bounds__(256, 7) k_trace_wide8(TraceParams tp) {
 	sg.nodes = tp.sc.nodes;
 	sg.tris = tp.sc.tri_isect;
 	sg.lboxes = tp.sc.leaf_boxes;
+	// The top of the tree in LDS.  Node ids are handed out breadth-first in blocks of eight (host_scene.cpp: build_wide8): ids < 16 are
+	// the root and its children, ids < 80 the three top levels -- the nodes EVERY ray fetches, about half of a ray's node steps.  A
+	// memory-resident walk is bound by the 16-B requests its lanes send through the texture-address path (profiles/gatherbench), and a
+	// node step on a staged node sends none: five ds_read_b128 instead of five global loads.
+	if (tp.top_nodes > 0) {
+		float4* top = reinterpret_cast<float4*>(lds_dyn + tp.stack_entries * 256);
+		for (int i = threadIdx.x; i < 5 * tp.top_nodes; i += 256) top[i] = tp.sc.wnodes8[8 * (size_t)(i / 5) + (i % 5)];
+		__syncthreads();
+	}
 	trace_persistent8<ANY, SPH, EARLY>(sg, tp, lds_dyn + threadIdx.x, tp.tri_class);
 }
 

@@ -103,6 +103,7 @@ struct TutuCtx {
 	bool wide8 = false;                     // the eight-wide tree is walked (device_shade.h: trace_persistent8)
 	int wide8_entries = 0;                  // ... entries of its LDS column: node stack from the bottom, leaf stack from the top
 	unsigned ktrace_lds_bytes = TUTU_STACK_DEPTH * 256 * sizeof(int);
+	int wide8_top = 0;  // eight-wide walk: node ids staged in LDS behind the stacks (80 B each)
 	bool lds_scene = false;
 	FlatScene flat = {};     // flat.n > 0: the traversal stages run k_trace_flat (tiny scenes)
 	uint32_t type_mask = 0;  // MaterialType values present among the non-emissive materials
@@ -157,6 +158,9 @@ struct TutuCtx {
 		                          //                     wave; -1 = auto: 6 for a pass that runs by itself (its slowest waves are what the kernel waits for: closest-hit
 		                          //                     -5 ... -21 %, any-hit -5 ... -17 %), 0 when passes overlap (another pass's kernels fill the tail, and a wave
 		                          //                     that stays in one part of the picture keeps its nodes in L1: frames +1.7 / -0.5 / -1.7 %)  {-1, 0, 6..16}
+		int wide8_top = 40;       // TUTU_WIDE8_TOP      eight-wide walk: node ids staged in LDS at most (16 = the root and its children, 80 = three levels; fewer when the
+		                          //                     stacks leave less room at seven blocks per CU; 0 = none).  Worth 2 % of a frame (bunny stand-in 1368 -> 1398, veach
+		                          //                     room 1303 -> 1325 at 16, 40 or 80): lanes that read the SAME node were one request already  [0, 592]
 		int exact_sum = 0;        // TUTU_EXACT_SUM      PathTracing: a path's radiance is folded from its deepest vertex back, as the reference's recursion returns it
 		                          //                     (device_shade.h: PassParams::xlog; 224 B more per path slot, allocated on first use)  {0, 1}
 		int paths_mi = 168;       // TUTU_PATHS_MI       Mi path slots in flight (all work sets together, ~400 B each) when the caller names none  [4, 4096]
@@ -279,6 +283,7 @@ const KnobDesc kKnobs[] = {
     {"bidir_units", "TUTU_BIDIR_UNITS", &TutuCtx::Knobs::bidir_units, 64, 1 << 24},
     {"exact", "TUTU_EXACT", &TutuCtx::Knobs::exact, 0, 1},
     {"exact_sum", "TUTU_EXACT_SUM", &TutuCtx::Knobs::exact_sum, 0, 1},
+    {"wide8_top", "TUTU_WIDE8_TOP", &TutuCtx::Knobs::wide8_top, 0, 592, true},
     {"trace_deal", "TUTU_TRACE_DEAL", &TutuCtx::Knobs::trace_deal, -1, 16},
     {"gather_rccl", "TUTU_GATHER_RCCL", &TutuCtx::Knobs::gather_rccl, 0, 2},
     {"flat", "TUTU_FLAT", &TutuCtx::Knobs::flat, 0, 1, true},
@@ -536,6 +541,7 @@ void launch_trace(TutuCtx* c, hipStream_t s, int grid, const TraceParams& tp) {
 		t8.inner_steps = ANY ? c->knobs.wide8_inner_steps_any : c->knobs.wide8_inner_steps;
 		t8.leaf_steps = c->knobs.wide8_leaf_steps;
 		t8.leaf_again = c->knobs.wide8_leaf_again;
+		t8.top_nodes = c->wide8_top;
 		if (c->wide_early) {
 			if (c->has_spheres) k_trace_wide8<ANY, true, true><<<g, b, c->ktrace_lds_bytes, s>>>(t8);
 			else k_trace_wide8<ANY, false, true><<<g, b, c->ktrace_lds_bytes, s>>>(t8);
@@ -718,6 +724,7 @@ int run_pass(TutuCtx* c, WorkSet& w, hipStream_t s, const TutuCameraFrame* cam, 
 		if (rc != TUTU_OK) return rc;
 		TraceParams tp;
 		tp.fin_w = 0.f;
+		tp.top_nodes = 0;
 		tp.deal_log2 = c->knobs.trace_deal >= 6 ? c->knobs.trace_deal : (c->knobs.trace_deal < 0 && !overlapped ? 6 : 0);
 		tp.sc = c->sc;
 		tp.rec = pp.out;
@@ -1384,8 +1391,13 @@ int tutu_hip_create(const TutuSceneDesc* scene, int device, TutuCtx** out) {
 		c->wide8_entries = std::max((int)c->hs.ref_depth + 1, (int)c->hs.wide8_depth + 2 + c->knobs.wide8_leaf_room);
 		c->ktrace_entries = c->wide8_entries;
 		c->ktrace_deep = 0;
+		// the top of the tree in LDS (device_shade.h: k_trace_wide8): what seven blocks per CU leave behind the stacks
+		const size_t stacks = (size_t)c->wide8_entries * 256 * sizeof(int);
+		const size_t per_block = ((160 * 1024) / 7) / 1024 * 1024 - 512;  // (LDS is handed out in granules: 23.2 KB asked for by seven blocks left room for six -- measured, closest-hit +17 %)
+		const size_t room = per_block > stacks ? (per_block - stacks) / 80 : 0;
+		c->wide8_top = (int)std::min<size_t>({(size_t)c->knobs.wide8_top, room, c->hs.wnodes8.size()});
 	}
-	c->ktrace_lds_bytes = (unsigned)((size_t)c->ktrace_entries * 256 * sizeof(int) + (c->lds_scene ? scene_bytes : 0));
+	c->ktrace_lds_bytes = (unsigned)((size_t)c->ktrace_entries * 256 * sizeof(int) + (c->lds_scene ? scene_bytes : 0) + (c->wide8 ? (size_t)c->wide8_top * 80 : 0));
 	// (+ the kernel's 32 B of static LDS: eight blocks of exactly 20 KB do NOT fit a CU, and the blocks that do not fit run
 	// after the others, alone -- a persistent grid must be resident as a whole)
 	c->trace_blocks_per_cu = (int)std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / ((size_t)c->ktrace_lds_bytes + 64)));
@@ -1508,6 +1520,10 @@ int tutu_hip_get_option(TutuCtx* c, const char* name, int* value) {
 	}
 	if (strcmp(name, "peer_access") == 0) {  // remote devices this context's device was given peer access to for the copy gather (-1: never asked)
 		*value = c->peer_access;
+		return TUTU_OK;
+	}
+	if (strcmp(name, "wide8_top_nodes") == 0) {  // eight-wide walk: node ids staged in LDS (0: none, or the scene walks another tree)
+		*value = c->wide8 ? c->wide8_top : 0;
 		return TUTU_OK;
 	}
 	if (strcmp(name, "last_trace_us") == 0) {
@@ -1928,6 +1944,7 @@ int lt_wavefront_batch(TutuCtx* c, hipStream_t s, BidirParams p) {
 	if ((rc = build_lists(c, w, s, p.rec.key, n_pad, nullptr, n_pad, meta0, nullptr, nullptr)) != TUTU_OK) return rc;
 	TraceParams tp;
 	tp.fin_w = 0.f;
+	tp.top_nodes = 0;
 	tp.deal_log2 = c->knobs.trace_deal >= 6 ? c->knobs.trace_deal : (c->knobs.trace_deal < 0 ? 6 : 0);
 	tp.sc = c->sc;
 	tp.rec = p.rec;
@@ -1989,6 +2006,7 @@ int bdpt_staged_batch(TutuCtx* c, hipStream_t s, BidirParams p) {
 	uint32_t* meta = w.list_meta.p;
 	TraceParams tp;
 	tp.fin_w = 0.f;
+	tp.top_nodes = 0;
 	tp.deal_log2 = c->knobs.trace_deal >= 6 ? c->knobs.trace_deal : (c->knobs.trace_deal < 0 ? 6 : 0);
 	tp.sc = c->sc;
 	tp.rec = p.rec;
@@ -2450,6 +2468,7 @@ static int run_trace_kernel(TutuCtx* c, uint32_t n, bool any) {
 	HIP_TRY(hipMemcpyAsync(w.list_meta.p + (any ? 1 : 0), &n, sizeof(uint32_t), hipMemcpyHostToDevice, s));
 	TraceParams tp;
 	tp.fin_w = 0.f;
+	tp.top_nodes = 0;
 	tp.deal_log2 = c->knobs.trace_deal >= 6 ? c->knobs.trace_deal : (c->knobs.trace_deal < 0 ? 6 : 0);
 	tp.sc = c->sc;
 	tp.rec = records_of(w, 0);
