@@ -40,8 +40,11 @@ def bounce(ctx, o, d):
     return (pos - din * np.float32(1e-3)).astype(np.float32), rand_dirs(len(pos), din)
 
 
-for name, mk, reps in (("c3 bunny", lambda: scenes.bunny_box(1024, 1024), 24), ("c5 veach", lambda: scenes.veach_room(800, 600, small_light=False), 6),
+WHICH = sys.argv[1:] or ["c3", "c5", "c4"]
+for name, mk, reps in (("c3 bunny", lambda: scenes.bunny_box(1024, 1024), 24), ("c5 veach", lambda: scenes.veach_room(800, 600, small_light=False), 48),
                        ("c4 broom", lambda: scenes.broom_room(1600, 900), 16)):
+    if name[:2] not in WHICH:
+        continue
     sc = mk()
     W, H = sc["width"], sc["height"]
     with tr.Context(sc) as ctx:
@@ -59,10 +62,12 @@ for name, mk, reps in (("c3 bunny", lambda: scenes.bunny_box(1024, 1024), 24), (
         lo, hi = verts.min(0), verts.max(0)
         for tag, (o, d) in (("segment 2", (o1, d1)), ("segment 3", (o2, d2)), ("segment 4", (o3, d3))):
             res = {}
+            m30 = morton(o, d, lo, hi, octant=False)
             orders = {"pixel order": np.arange(len(o)), "morton(origin) + octant": np.argsort(morton(o, d, lo, hi), kind="stable"),
-                      "morton(origin)": np.argsort(morton(o, d, lo, hi, octant=False), kind="stable"),
-                      "octant, then morton": np.argsort(morton(o, d, lo, hi, octant=False) | (morton(o, d, lo, hi) & 7) << 30, kind="stable"),
+                      "morton(origin)": np.argsort(m30, kind="stable"),
                       "shuffled": rng.permutation(len(o))}
+            for bits in (6, 9, 12, 15, 18):  # buckets only (what a one-pass counting sort gives): the top bits of the code, pixel order inside a bucket
+                orders[f"top {bits} bits"] = np.argsort(m30 >> (30 - bits), kind="stable")
             ref = None
             for k, idx in orders.items():
                 oo, dd = np.ascontiguousarray(o[idx]), np.ascontiguousarray(d[idx])
