@@ -133,7 +133,7 @@ def test_exact_sum_frame_is_the_reference_builds_bit_for_bit(tr, name):
     the order in which the reference's recursion returns (PathTracing.hpp:275-277, :133) -- instead of carried forward as a sum of
     throughput * term.  With the C library's functions restated for the device (csrc/device_libm.h) nothing else differed: every
     BASELINE frame is then the reference build's frame, all 0.64-1.44 M pixels of it, bit for bit (c2: 0.33 G samples; the knob costs
-    4-17 % of the frame rate, DESIGN.md 2.6, so the default keeps the forward sum and differs by the rounding of that sum alone: 1e-8)."""
+    4-13 % of the frame rate, DESIGN.md 0 item 10, so the default keeps the forward sum and differs by the rounding of that sum alone: 1e-8)."""
     from tuturenderer_amd import scenes
 
     z = np.load(golden_path(f"frame_{name}.npz"))

@@ -100,7 +100,7 @@ struct PassParams {
 	int n_mats;
 	// Knob "exact_sum": the radiance is NOT carried forward as sum of beta * term.  The reference's traceRay is a recursion that adds
 	// from the tail -- L_v = S_v + L_{v+1} * coe_v (PathTracing.hpp:275-277), L_v = L_{v+1} * cos * f_r / pdf (:133) -- so every
-	// vertex v a path continues from logs what its level needs (2 x 16 B at xlog[(2 v + k) * xstride + home]: S_v xyz | pdf or 0,
+	// vertex v a path continues from logs what its level needs (32 B in one piece at xlog[2 * (v * xstride + home) + k]: S_v xyz | pdf or 0,
 	// coe_v or f_r xyz | cos), beta stays 1, the value a path ends with is its deepest level's, and k_unwind folds the levels in the
 	// reference's order.  Null: the forward sum (the same real number, rounded in another order: 10-34 % of the samples differ in
 	// a last bit).
@@ -602,9 +602,9 @@ __global__ void __launch_bounds__(256) k_shade(PassParams pp) {
 						} else {
 							tp = tp * coe;
 							if (pp.xlog) {  // level depth-1 is complete: S = what the vertex gathered (its light sample), coe; a new level starts
-								float4* lg = pp.xlog + (size_t)(2 * (depth - 1)) * pp.xstride + home;
+								float4* lg = pp.xlog + 2 * ((size_t)(depth - 1) * pp.xstride + home);
 								lg[0] = make_float4(Lsum.x, Lsum.y, Lsum.z, 0.f);
-								lg[pp.xstride] = make_float4(coe.x, coe.y, coe.z, 0.f);
+								lg[1] = make_float4(coe.x, coe.y, coe.z, 0.f);
 								Lsum = mk1(0.f);
 								logged_prev = true;
 							} else {
@@ -670,9 +670,9 @@ __global__ void __launch_bounds__(256) k_shade(PassParams pp) {
 					// :128-133 -- the reference traces the continuation and then drops it when pdf < MIN_DIVISOR
 					if (!(p < TUTU_MIN_DIVISOR || depth + 1 > TUTU_MAX_DEPTH)) {
 						if (pp.xlog) {
-							float4* lg = pp.xlog + (size_t)(2 * depth) * pp.xstride + home;
+							float4* lg = pp.xlog + 2 * ((size_t)depth * pp.xstride + home);
 							lg[0] = make_float4(0.f, 0.f, 0.f, p);
-							lg[pp.xstride] = make_float4(f_r.x, f_r.y, f_r.z, cosv);
+							lg[1] = make_float4(f_r.x, f_r.y, f_r.z, cosv);
 						} else {
 							beta = ((beta * cosv) * f_r) / p;
 						}
@@ -2087,7 +2087,8 @@ __global__ void __launch_bounds__(256) k_unwind(float4* F, const float4* xlog, u
 	const float4 f = F[h];
 	V3 L = mk(f.x, f.y, f.z);
 	for (int v = __float_as_int(f.w) - 1; v >= 0; v--) {
-		const float4 a = xlog[(size_t)(2 * v) * xstride + h], b = xlog[(size_t)(2 * v + 1) * xstride + h];
+		const float4* lg = xlog + 2 * ((size_t)v * xstride + h);
+		const float4 a = lg[0], b = lg[1];
 		if (a.w != 0.f) L = ((L * b.w) * mk(b.x, b.y, b.z)) / a.w;          // calcForRefractive: Li * cos * f_r / pdf (:133)
 		else L = mk(a.x, a.y, a.z) + (L * mk(b.x, b.y, b.z));                // sampleValue + (Li * coe) (:277)
 	}
