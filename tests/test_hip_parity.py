@@ -502,6 +502,9 @@ def test_stand_in_scenes_per_sample_parity(tr, name):
     with tr.Context(sc) as ctx:
         info = ctx.info()
         L = ctx.trace_samples(pix, smp, pc.KEY0, key1)
+        ctx.set_option("exact_sum", 1)
+        Lx = ctx.trace_samples(pix, smp, pc.KEY0, key1)
+        ctx.set_option("exact_sum", 0)
         cam = tr.camera_frame_array(sc)
         x, y = (pix % sc["width"]).astype(np.float32), (pix // sc["width"]).astype(np.float32)
         p = cam[0] + x[:, None] * cam[1] + y[:, None] * cam[2] + cam[4] + cam[4]  # PathTracing.hpp:503 [sic]
@@ -522,8 +525,11 @@ def test_stand_in_scenes_per_sample_parity(tr, name):
     assert info["depth"] >= 15
     assert (nan_g != nan_w).mean() < 1e-3
     assert tri_bad < 2e-3 and t_bad < 1e-2
-    assert bad < 5e-3, bad
+    assert bad == 0.0, bad  # (round 5: no sample takes another path than the reference's)
     assert abs(L[fin].mean() - want[fin].mean()) < 2e-2 * max(want[fin].mean(), 1e-3)
+    # ... and folded in the reference's order (knob exact_sum) every sample is the reference build's, bit for bit
+    n_bits = int(((Lx.view(np.uint32) != want.view(np.uint32)) & ~(np.isnan(Lx) & np.isnan(want))).any(1).sum())
+    assert n_bits == 0, n_bits
 
 
 # ------------------------------------------------------------------------------------------------------------
@@ -691,6 +697,9 @@ def _frame_checks(tr, port, sc, key1, spp, n_probe_pixels=12, n_samples=2000, lo
         pix = rng.integers(0, W * H, n_samples).astype(np.uint32)
         smp = rng.integers(0, spp, n_samples).astype(np.uint32)
         Lg = ctx.trace_samples(pix, smp, pc.KEY0, key1)
+        ctx.set_option("exact_sum", 1)
+        Lx = ctx.trace_samples(pix, smp, pc.KEY0, key1)
+        ctx.set_option("exact_sum", 0)
     S = port.scene(sc)
     Lw = S.trace_samples(pix, smp, pc.KEY0, key1)
     low = S.render(low_spp, pc.KEY0, key1, nthreads=16)
@@ -699,6 +708,7 @@ def _frame_checks(tr, port, sc, key1, spp, n_probe_pixels=12, n_samples=2000, lo
     err = np.abs(Lg[fin] - Lw[fin]).max(1)
     scale = np.maximum(np.abs(Lw[fin]).max(1), 1e-3)
     assert (err <= 5e-6 * scale + 1e-7).all(), float((err / scale).max())  # (every sample takes the reference's path: module docstring)
+    assert not ((Lx.view(np.uint32) != Lw.view(np.uint32)) & ~(np.isnan(Lx) & np.isnan(Lw))).any()  # knob exact_sum: the CPU restatement's bits
     # Monte-Carlo error of the low-spp CPU mean: per-channel variance of its pixels / number of pixels (plus the frame's own, smaller)
     for ch in range(3):
         sigma = low[..., ch].std() / np.sqrt(low[..., ch].size) * 1.5
