@@ -159,3 +159,19 @@ def test_bench_busy_probe_and_configs_without_a_gpu():
         time.sleep(0.12)
     s = p.summary()
     assert "samples" in s and (s["samples"] == 0 or 0 <= s["max_percent"] <= 100)
+
+
+def test_every_python_option_name_is_one_the_library_knows():
+    """tuturenderer_amd.Context.options() asks tutu_hip_get_option for every name in OPTION_NAMES (on a GPU box an unknown name raises);
+    the same check without a GPU, against the library's source: the knob table and the read-only names of tutu_hip_get_option."""
+    import os
+    import re
+
+    import tuturenderer_amd
+
+    src = open(os.path.join(os.path.dirname(tuturenderer_amd.__file__), "csrc", "tutu_hip.hip")).read()
+    known = set(re.findall(r'\{"([a-z0-9_]+)", "TUTU_[A-Z0-9_]+", &TutuCtx::Knobs::', src)) | set(re.findall(r'strcmp\(name, "([a-z0-9_]+)"\) == 0', src))
+    missing = [n for n in tuturenderer_amd.Context.OPTION_NAMES if n not in known]
+    assert not missing, missing
+    for new in ("exact_sum", "trace_deal", "wide8_top", "wide8_top_nodes", "last_trace_us"):  # round 5
+        assert new in tuturenderer_amd.Context.OPTION_NAMES and new in known
