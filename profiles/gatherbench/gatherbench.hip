@@ -117,7 +117,7 @@ int main() {
 	CK(hipEventCreate(&e1));
 	bool first = true;
 	for (int mb : {1, 16, 256}) {
-		for (int quads : {4, 5}) {
+		for (int quads : {4, 5, 3, 2}) {  // (round 5, late: 48-B and 32-B nodes -- what a compressed four-wide node would be worth)
 			const size_t n_nodes = ((size_t)mb << 20) / 64;  // (the node count is kept; an 80-B node table is 1.25 x the bytes)
 			std::vector<uint32_t> h((size_t)n_nodes * quads * 4);
 			uint32_t x = 12345u;
@@ -136,6 +136,8 @@ int main() {
 						CK(hipEventRecord(e0));
 						if (variant == 1) hipLaunchKernelGGL(k_coop, dim3(blocks), dim3(256), 0, 0, p);
 						else if (quads == 4) hipLaunchKernelGGL(k_own<4>, dim3(blocks), dim3(256), 0, 0, p);
+						else if (quads == 3) hipLaunchKernelGGL(k_own<3>, dim3(blocks), dim3(256), 0, 0, p);
+						else if (quads == 2) hipLaunchKernelGGL(k_own<2>, dim3(blocks), dim3(256), 0, 0, p);
 						else hipLaunchKernelGGL(k_own<5>, dim3(blocks), dim3(256), 0, 0, p);
 						CK(hipEventRecord(e1));
 						CK(hipEventSynchronize(e1));
