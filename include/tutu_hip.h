@@ -398,6 +398,13 @@ int tutu_hip_quantise(TutuCtx* ctx, uint32_t n, const float* values, int32_t* le
  *   [1,32] (create-only); environment only (host tree build): TUTU_WIDE8_SLOTS = 2 kd slots + tables (default), 1 octant slots, 0 tree order.
  *   "gather_rccl" TUTU_GATHER_RCCL [0,2] (tutu_hip_render_multi(_device), option of the FIRST context: the pieces travel by one grouped
  *   RCCL send / recv: 0 never, 1 when the contexts sit on several devices, 2 always -- a context on the root's device by a self send / recv).
+ *   Round 5, later: "exact_sum" TUTU_EXACT_SUM {0,1} (PathTracing: every path's radiance is folded from its deepest vertex back, the order in
+ *   which the reference's recursive traceRay returns it (PathTracing.hpp:275-277, :133), instead of summed forward: frames and per-sample
+ *   radiances are then the reference build's bit for bit; 224 B more per path slot, allocated on first use; 4-13 % of the frame rate) |
+ *   "trace_deal" TUTU_TRACE_DEAL {-1, 0, 6..16} (persistent walks: log2 of the chunk of list positions dealt round-robin to the waves, 0 =
+ *   one contiguous range per wave, -1 = auto: 6 for a pass that runs by itself, 0 when passes overlap) | "wide8_top" TUTU_WIDE8_TOP [0,592]
+ *   (create-only: node ids of the eight-wide tree staged in LDS at most, default 40; read-only fact "wide8_top_nodes") | read-only
+ *   "last_trace_us" (duration of the kernel behind the last tutu_hip_trace_closest / tutu_hip_trace_any call: measuring tools).
  *   Read-only facts: "wide8_tree", "wide8_depth", "wide8_nodes", "wide8_entries", "gather_path" (how the last N-context frame was gathered:
  *   0 copies, 1 RCCL, -1 none yet), "peer_access", "rccl_available",
  *   "wide_tree", "wide_depth", "fast_depth", "stack_entries", "stack_entries_hbm", "trace_blocks_per_cu",
