@@ -1,4 +1,4 @@
-// sinf / cosf / acosf / tanf with the bits of the C library the reference is built against.
+// sinf / cosf / acosf / tanf / powf / atanf / atan2f with the bits of the C library the reference is built against.
 //
 // Round 5.  The path's arithmetic is fp32 + - * / sqrt (identical on host and device) and four library functions: the direction
 // samplers call sin / cos of 2 pi xi (Material.hpp:221, 243, 294-295; IIntegrator.hpp:204-205), the microfacet shadowing term
@@ -13,12 +13,15 @@
 //   acosf         fdlibm's float rational approximation (e_acosf.c), no fused operations;
 //   atanf, atan2f fdlibm's float code (s_atanf.c, e_atan2f.c), no fused operations -- the sphere's texture parametrisation (Sphere.hpp:64);
 //   tanf          fdlibm's float kernel (k_tanf.c) behind the double-precision argument reduction of s_tanf.c / the sincosf
-//                 tables (not fused there).
+//                 tables (not fused there);
+//   powf          ARM's table-driven log2 / exp2 in double (e_powf.c, 16- and 32-entry tables), in the -mfma variant: the Fresnel terms'
+//                 powf(x, 5.f) (global.hpp:258) -- NOT the correctly rounded x^5 for 1.4e-4 of all arguments.  (powf(x, 2.f) is folded
+//                 into x * x by the reference build's compiler: device_math.h.)
 // Every fp operation below is one IEEE operation in the order the library performs it; the file is compiled with
 // -ffp-contract=off on both sides, so host and device produce the library's bits.  Pinned exhaustively: tests/tools/libm_check.c
 // compiles THIS header for the host and compares all 2^32 arguments of each function with the C library of the machine it runs
-// on (tests/test_libm_restatement.py runs a 1-in-509 sample of it in the CPU suite and the whole of it on request); the device
-// functions are compared with the host library through tutu_hip_eval_fn (tests/test_hip_parity.py).
+// on (tests/test_libm_restatement.py runs two strided samples of it in the CPU suite; stride 1 = all of it, 0 differ, four CPU-minutes); the device
+// functions are compared with the host library through tutu_hip_eval_fn (TUTU_FN_LIBM; tests/test_hip_parity.py).
 // Not a copy of library source: constants and operation order only, as published (ARM optimized-routines v20.02 sincosf; fdlibm 5.3).
 #pragma once
 #include <stdint.h>
